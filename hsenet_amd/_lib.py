@@ -1,0 +1,109 @@
+"""ctypes binding of libhsenet_hip.so (the C ABI declared in include/hsenet_hip.h).
+
+There is NO fallback: if the shared object is missing or fails to load, or a call returns a negative
+status, this module raises.  No torch types cross the boundary: callers pass ``tensor.data_ptr()`` and sizes.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libhsenet_hip.so")
+
+HS_OK, HS_ERR_SHAPE, HS_ERR_ARCH, HS_ERR_LAUNCH, HS_ERR_ARG = 0, -1, -2, -3, -4
+PREC_BF16, PREC_F32 = 0, 1
+GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
+EPI_BIAS, EPI_GELU, EPI_GELU_BWD, EPI_RESID, EPI_ATOMIC, EPI_BIAS_M = 1, 2, 4, 8, 16, 32
+
+_ERR = {HS_ERR_SHAPE: "unsupported shape/alignment", HS_ERR_ARCH: "no gfx950 device", HS_ERR_LAUNCH: "HIP launch error",
+        HS_ERR_ARG: "bad argument"}
+
+
+class HsError(RuntimeError):
+    pass
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
+                ("lda", C.c_int64), ("ldb", C.c_int64), ("batch", C.c_int),
+                ("strideA", C.c_int64), ("strideB", C.c_int64), ("strideC", C.c_int64),
+                ("out_f32", C.c_void_p), ("out_bf16", C.c_void_p), ("ldc", C.c_int64),
+                ("bias", C.c_void_p), ("resid", C.c_void_p), ("aux", C.c_void_p), ("aux_out", C.c_void_p),
+                ("alpha", C.c_float), ("flags", C.c_int), ("layout", C.c_int), ("split_k", C.c_int)]
+
+
+class VitDesc(C.Structure):
+    _fields_ = [("B", C.c_int), ("N", C.c_int), ("d", C.c_int), ("H", C.c_int), ("mlp", C.c_int), ("L", C.c_int),
+                ("prec", C.c_int), ("save_for_bwd", C.c_int)]
+
+
+_vp, _i, _f, _i64, _sz = C.c_void_p, C.c_int, C.c_float, C.c_int64, C.c_size_t
+
+# name -> argtypes (restype int unless listed in _RESTYPE); mirrors include/hsenet_hip.h one to one
+SIGNATURES = {
+    "hs_version": [],
+    "hs_device_check": [_i],
+    "hs_gemm": [C.POINTER(GemmArgs), _i, _vp],
+    "hs_patchify": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "hs_assemble_tokens": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "hs_assemble_tokens_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "hs_layernorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp],
+    "hs_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
+    "hs_attn_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "hs_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "hs_cross_attn_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "hs_cross_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "hs_rowdot_sigmoid_fwd": [_vp, _vp, _vp, _vp, _i, _i, _vp],
+    "hs_rowdot_sigmoid_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
+    "hs_pool3d_fwd": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "hs_pool3d_bwd": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "hs_window_attn_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "hs_window_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "hs_colsum": [_vp, _i, _vp, _i, _i, _i64, _vp],
+    "hs_cast_bf16": [_vp, _vp, _i64, _vp],
+    "hs_cast_f32": [_vp, _vp, _i64, _vp],
+    "hs_gelu_fwd": [_vp, _vp, _i64, _vp],
+    "hs_gelu_bwd": [_vp, _vp, _vp, _i64, _vp],
+    "hs_l2norm_fwd": [_vp, _vp, _i, _i, _f, _vp],
+    "hs_l2norm_bwd": [_vp, _vp, _vp, _i, _i, _f, _vp],
+    "hs_adamw": [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _f, _i, _vp],
+    "hs_vit_workspace_bytes": [C.POINTER(VitDesc)],
+    "hs_vit_blocks_fwd": [C.POINTER(VitDesc), _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
+    "hs_vit_blocks_bwd": [C.POINTER(VitDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _vp],
+}
+_RESTYPE = {"hs_vit_workspace_bytes": _sz}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def load() -> C.CDLL:
+    """Load (once) and type the shared library.  Raises HsError if it is absent — build it with
+    ``python -m hsenet_amd.build`` (or ``__graft_entry__.build()``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise HsError(f"{LIB_PATH} is missing: the HIP extension has not been built "
+                          "(run `python -m hsenet_amd.build`); hsenet_amd has no CPU/PyTorch fallback")
+        try:
+            lib = C.CDLL(LIB_PATH)
+        except OSError as e:  # pragma: no cover
+            raise HsError(f"cannot load {LIB_PATH}: {e}") from e
+        for name, args in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+            fn.argtypes = args
+            fn.restype = _RESTYPE.get(name, C.c_int)
+        _lib = lib
+    return _lib
+
+
+def call(name: str, *args) -> None:
+    rc = getattr(load(), name)(*args)
+    if rc != HS_OK:
+        raise HsError(f"{name} failed: {rc} ({_ERR.get(rc, 'unknown')})")

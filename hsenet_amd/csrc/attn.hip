@@ -1,0 +1,547 @@
+// K4: global multi-head self-attention core of MONAI SABlock (reference hot loops
+// multimodal_encoder/vit.py:352-354,464-466): softmax(q k^T dh^-0.5) v, unmasked, dh = 64.
+//
+// Flash-style (the N x N matrix never exists).  All kernels put the index that the SECOND product sums over
+// on the accumulator's ROW (register) axis, so the first product's accumulator is directly the next MFMA's
+// B operand after a bf16 pack (cdna guide section 3, "An accumulator tile as the next MFMA's operand"):
+//   fwd  : S^T[key][q] = K Q^T        -> P^T (softmax is lane-local + one half-swap) -> O^T[d][q] += V^T P^T
+//   dq   : S^T, dP^T = V dO^T          -> dS^T                                       -> dQ^T[d][q] += K^T dS^T
+//   dkdv : S[q][key] = Q K^T, dP = dO V^T -> P, dS                                    -> dV^T += dO^T P ; dK^T += Q^T dS
+// K/V (fwd, dq) or Q/dO (dkdv) tiles live in LDS image R (common.h): read by rows (ds_read_b128) for the first
+// product and by columns (ds_read_b64_tr_b16) for the second — one image, no transposed copy.
+// Tiles are staged global -> registers (range-checked buffer loads: rows >= N read 0) -> LDS, written after
+// the MFMA phase, one barrier per tile, double-buffered.
+#include "common.h"
+
+#define NEG_INF (-__builtin_inff())
+
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[r] = 0.f;
+    return z;
+}
+__device__ __forceinline__ bf16x8 pack8(const f32x16& a, int s) {  // registers 8s..8s+7 -> bf16x8 (k-step s)
+    u32x4 u;
+    u[0] = pack2bf(a[8 * s + 0], a[8 * s + 1]);
+    u[1] = pack2bf(a[8 * s + 2], a[8 * s + 3]);
+    u[2] = pack2bf(a[8 * s + 4], a[8 * s + 5]);
+    u[3] = pack2bf(a[8 * s + 6], a[8 * s + 7]);
+    return __builtin_bit_cast(bf16x8, u);
+}
+// column (transposed) fragment of image R: element j <-> row rowbase + 8(j>>2) + 4h + (j&3), column db*32 + (lane&31)
+__device__ __forceinline__ bf16x8 tr_frag(const char* img, int rowbase, int db, int lane) {
+    const int g = lane >> 4, h = g >> 1, p = lane & 3, q = (lane >> 2) & 3;
+    const int col = db * 32 + 16 * (g & 1) + 4 * p;
+    const int r1 = rowbase + 4 * h + q;
+    const bf16x4 a = lds_tr16(img + offR(r1, col >> 3) + 8 * (p & 1));
+    const bf16x4 b = lds_tr16(img + offR(r1 + 8, col >> 3) + 8 * (p & 1));
+    return cat4(a, b);
+}
+__device__ __forceinline__ bf16x8 row_frag(const char* img, int row, int ks, int h) {
+    return *(const bf16x8*)(img + offR(row, 2 * ks + h));
+}
+// store a [d][query] accumulator pair as rows of a [..][ld] bf16 matrix: lane owns one query row
+__device__ __forceinline__ void store_dT(bf16_t* rowptr, const f32x16 (&acc)[2], float mul, int h) {
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            u32x2 v;
+            v[0] = pack2bf(acc[db][4 * g4 + 0] * mul, acc[db][4 * g4 + 1] * mul);
+            v[1] = pack2bf(acc[db][4 * g4 + 2] * mul, acc[db][4 * g4 + 3] * mul);
+            *(u32x2*)(rowptr + db * 32 + 8 * g4 + 4 * h) = v;
+        }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// forward, bf16.  grid (ceil(N/128), H, B), 4 waves x 32 queries, 64-key tiles.
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
+                                                            float* __restrict__ lse, int N, int H, float scale) {
+    __shared__ __attribute__((aligned(16))) char smem[32768];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, c = lane & 31;
+    const int b = blockIdx.z, head = blockIdx.y, q0 = blockIdx.x * 128 + wave * 32;
+    const int Dm = H * 64, D3 = 3 * Dm;
+    const bf16_t* base = qkv + (long)b * N * D3;
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(base, (size_t)N * D3 * 2);
+    const float c2 = scale * 1.44269504088896341f;
+
+    const int qrow = min(q0 + c, N - 1);
+    bf16x8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+        qf[ks] = __builtin_bit_cast(bf16x8, buf_load16(rs, (unsigned)(((long)qrow * D3 + head * 64 + ks * 16 + 8 * h) * 2)));
+
+    u32x4 rk[2], rv[2];
+    auto gload = [&](int t) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int idx = it * 256 + tid, key = t * 64 + (idx >> 3);
+            const unsigned off = key < N ? (unsigned)(((long)key * D3 + Dm + head * 64 + (idx & 7) * 8) * 2) : HS_OOB_OFF;
+            rk[it] = buf_load16(rs, off);
+            rv[it] = buf_load16(rs, key < N ? off + Dm * 2 : HS_OOB_OFF);
+        }
+    };
+    auto swrite = [&](int st) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int idx = it * 256 + tid, o_ = offR(idx >> 3, idx & 7);
+            *(u32x4*)(smem + st * 16384 + o_) = rk[it];
+            *(u32x4*)(smem + st * 16384 + 8192 + o_) = rv[it];
+        }
+    };
+
+    float m = NEG_INF, l = 0.f;
+    f32x16 oacc[2] = {zero16(), zero16()};
+    const int nt = (N + 63) >> 6;
+    gload(0);
+    swrite(0);
+    __syncthreads();
+    int cur = 0;
+    for (int t = 0; t < nt; ++t) {
+        const bool more = t + 1 < nt;
+        if (more) gload(t + 1);
+        const char* Kl = smem + cur * 16384;
+        const char* Vl = Kl + 8192;
+        f32x16 s[2] = {zero16(), zero16()};
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Kl, kb * 32 + c, ks, h), qf[ks], s[kb], 0, 0, 0);
+        if (t == nt - 1 && (N & 63)) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (t * 64 + kb * 32 + acc_row(r, h) >= N) s[kb][r] = NEG_INF;
+        }
+        float mx = s[0][0];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mn = fmaxf(m, mx);
+        const float alpha = __builtin_amdgcn_exp2f((m - mn) * c2);
+        const float mc = mn * c2;
+        float rs_ = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __builtin_amdgcn_exp2f(s[kb][r] * c2 - mc);
+                s[kb][r] = p;
+                rs_ += p;
+            }
+        rs_ += __shfl_xor(rs_, 32, 64);
+        l = l * alpha + rs_;
+        m = mn;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp) {
+                const bf16x8 pf = pack8(s[kb], sp);
+#pragma unroll
+                for (int db = 0; db < 2; ++db)
+                    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Vl, kb * 32 + 16 * sp, db, lane), pf,
+                                                                      oacc[db], 0, 0, 0);
+            }
+        if (more) swrite(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+    const int query = q0 + c;
+    if (query < N) {
+        store_dT(o + ((long)b * N + query) * Dm + head * 64, oacc, 1.0f / l, h);
+        if (h == 0) lse[((long)b * H + head) * N + query] = m * scale + __logf(l);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// forward, exact f32 (parity mode): same data flow with v_mfma_f32_32x32x2_f32.  K/V tiles are fp32 images
+// with 256-B rows and 16-B chunk c of row r at c ^ (r & 15).  The k (= d) order inside a group of 8 is permuted
+// identically for K and Q (half h takes d = 8s+4h+e at MFMA step e); the PV product takes the accumulator
+// registers as they stand (half h of register r holds key acc_row(r,h)).
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int offF(int r, int c) { return r * 256 + ((c ^ (r & 15)) << 4); }
+
+__global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const float* __restrict__ qkv, float* __restrict__ o,
+                                                           float* __restrict__ lse, int N, int H, float scale) {
+    __shared__ __attribute__((aligned(16))) char smem[65536];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, c = lane & 31;
+    const int b = blockIdx.z, head = blockIdx.y, q0 = blockIdx.x * 128 + wave * 32;
+    const int Dm = H * 64, D3 = 3 * Dm;
+    const float* base = qkv + (long)b * N * D3;
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(base, (size_t)N * D3 * 4);
+    const float c2 = scale * 1.44269504088896341f;
+    const int qrow = min(q0 + c, N - 1);
+    f32x4 qf[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+        qf[s] = __builtin_bit_cast(f32x4, buf_load16(rs, (unsigned)(((long)qrow * D3 + head * 64 + 8 * s + 4 * h) * 4)));
+    u32x4 rk[4], rv[4];
+    auto gload = [&](int t) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int idx = it * 256 + tid, key = t * 64 + (idx >> 4);
+            const unsigned off = key < N ? (unsigned)(((long)key * D3 + Dm + head * 64 + (idx & 15) * 4) * 4) : HS_OOB_OFF;
+            rk[it] = buf_load16(rs, off);
+            rv[it] = buf_load16(rs, key < N ? off + Dm * 4 : HS_OOB_OFF);
+        }
+    };
+    auto swrite = [&](int st) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int idx = it * 256 + tid, o_ = offF(idx >> 4, idx & 15);
+            *(u32x4*)(smem + st * 32768 + o_) = rk[it];
+            *(u32x4*)(smem + st * 32768 + 16384 + o_) = rv[it];
+        }
+    };
+    float m = NEG_INF, l = 0.f;
+    f32x16 oacc[2] = {zero16(), zero16()};
+    const int nt = (N + 63) >> 6;
+    gload(0);
+    swrite(0);
+    __syncthreads();
+    int cur = 0;
+    for (int t = 0; t < nt; ++t) {
+        const bool more = t + 1 < nt;
+        if (more) gload(t + 1);
+        const char* Kl = smem + cur * 32768;
+        const char* Vl = Kl + 16384;
+        f32x16 s[2] = {zero16(), zero16()};
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int s8 = 0; s8 < 8; ++s8) {
+                const f32x4 a = *(const f32x4*)(Kl + offF(kb * 32 + c, 2 * s8 + h));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s[kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], qf[s8][e], s[kb], 0, 0, 0);
+            }
+        if (t == nt - 1 && (N & 63)) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (t * 64 + kb * 32 + acc_row(r, h) >= N) s[kb][r] = NEG_INF;
+        }
+        float mx = s[0][0];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mn = fmaxf(m, mx);
+        const float alpha = exp2f((m - mn) * c2);
+        float rs_ = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = exp2f((s[kb][r] - mn) * c2);
+                s[kb][r] = p;
+                rs_ += p;
+            }
+        rs_ += __shfl_xor(rs_, 32, 64);
+        l = l * alpha + rs_;
+        m = mn;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kb * 32 + acc_row(r, h);
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    const int d = db * 32 + c;
+                    const float a = *(const float*)(Vl + offF(key, d >> 2) + (d & 3) * 4);
+                    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, s[kb][r], oacc[db], 0, 0, 0);
+                }
+            }
+        if (more) swrite(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+    const int query = q0 + c;
+    if (query < N) {
+        const float inv = 1.0f / l;
+        float* orow = o + ((long)b * N + query) * Dm + head * 64;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = oacc[db][4 * g4 + e] * inv;
+                *(f32x4*)(orow + db * 32 + 8 * g4 + 4 * h) = v;
+            }
+        if (h == 0 && lse) lse[((long)b * H + head) * N + query] = m * scale + logf(l);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// backward, bf16
+// ------------------------------------------------------------------------------------------------------
+// delta[b,h,n] = sum_d dO * O   (8 lanes per (n, head) row of 64)
+__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ d_o,
+                                                         float* __restrict__ delta, int B, int N, int H) {
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)B * N * H * 8;
+    float acc = 0.f;
+    const bool ok = gid < total;
+    if (ok) {
+        const u32x4 a = *(const u32x4*)(o + gid * 8);
+        const u32x4 g = *(const u32x4*)(d_o + gid * 8);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            acc += __uint_as_float(a[i] << 16) * __uint_as_float(g[i] << 16);
+            acc += __uint_as_float(a[i] & 0xffff0000u) * __uint_as_float(g[i] & 0xffff0000u);
+        }
+    }
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    acc += __shfl_xor(acc, 4, 64);
+    if (ok && (threadIdx.x & 7) == 0) {
+        const long row = gid >> 3;  // (b*N + n)*H + head
+        const int head = (int)(row % H);
+        const long bn = row / H;
+        const int n = (int)(bn % N), b = (int)(bn / N);
+        delta[((long)b * H + head) * N + n] = acc;
+    }
+}
+
+// dK, dV: grid (ceil(N/128), H, B); each wave owns 32 keys, sweeps all queries in 64-row tiles.
+__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
+                                                            const float* __restrict__ lse, const float* __restrict__ delta,
+                                                            bf16_t* __restrict__ dqkv, int N, int H, float scale) {
+    // stage: Q image 8 KiB | dO image 8 KiB | -lse/scale [64] f32 | -delta [64] f32
+    __shared__ __attribute__((aligned(16))) char smem[2 * 16896];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, c = lane & 31;
+    const int b = blockIdx.z, head = blockIdx.y, k0 = blockIdx.x * 128 + wave * 32;
+    const int Dm = H * 64, D3 = 3 * Dm;
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(qkv + (long)b * N * D3, (size_t)N * D3 * 2);
+    const __amdgpu_buffer_rsrc_t rsd = make_rsrc(d_o + (long)b * N * Dm, (size_t)N * Dm * 2);
+    const float* lse_b = lse + ((long)b * H + head) * N;
+    const float* del_b = delta + ((long)b * H + head) * N;
+    const float c2 = scale * 1.44269504088896341f, inv_scale = 1.0f / scale;
+
+    const int key = k0 + c;
+    bf16x8 kf[4], vf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const unsigned off = key < N ? (unsigned)(((long)key * D3 + Dm + head * 64 + ks * 16 + 8 * h) * 2) : HS_OOB_OFF;
+        kf[ks] = __builtin_bit_cast(bf16x8, buf_load16(rs, off));
+        vf[ks] = __builtin_bit_cast(bf16x8, buf_load16(rs, key < N ? off + Dm * 2 : HS_OOB_OFF));
+    }
+    u32x4 rq[2], rd[2];
+    float rstat = 0.f;
+    auto gload = [&](int t) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int idx = it * 256 + tid, q = t * 64 + (idx >> 3);
+            rq[it] = buf_load16(rs, q < N ? (unsigned)(((long)q * D3 + head * 64 + (idx & 7) * 8) * 2) : HS_OOB_OFF);
+            rd[it] = buf_load16(rsd, q < N ? (unsigned)(((long)q * Dm + head * 64 + (idx & 7) * 8) * 2) : HS_OOB_OFF);
+        }
+        if (tid < 128) {
+            const int q = t * 64 + (tid & 63);
+            if (tid < 64) rstat = q < N ? -lse_b[q] * inv_scale : NEG_INF;
+            else rstat = q < N ? -del_b[q] : 0.f;
+        }
+    };
+    auto swrite = [&](int st) {
+        char* sb = smem + st * 16896;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int idx = it * 256 + tid, o_ = offR(idx >> 3, idx & 7);
+            *(u32x4*)(sb + o_) = rq[it];
+            *(u32x4*)(sb + 8192 + o_) = rd[it];
+        }
+        if (tid < 128) *(float*)(sb + 16384 + tid * 4) = rstat;
+    };
+    f32x16 dk[2] = {zero16(), zero16()}, dv[2] = {zero16(), zero16()};
+    const int nt = (N + 63) >> 6;
+    gload(0);
+    swrite(0);
+    __syncthreads();
+    int cur = 0;
+    for (int t = 0; t < nt; ++t) {
+        const bool more = t + 1 < nt;
+        if (more) gload(t + 1);
+        const char* Ql = smem + cur * 16896;
+        const char* Dl = Ql + 8192;
+        const float* Ls = (const float*)(Ql + 16384);
+        const float* Ds = Ls + 64;
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            f32x16 s, dp;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const f32x4 lv = *(const f32x4*)(Ls + qb * 32 + 8 * g4 + 4 * h);
+                const f32x4 dl = *(const f32x4*)(Ds + qb * 32 + 8 * g4 + 4 * h);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    s[4 * g4 + e] = lv[e];
+                    dp[4 * g4 + e] = dl[e];
+                }
+            }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Ql, qb * 32 + c, ks, h), kf[ks], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Dl, qb * 32 + c, ks, h), vf[ks], dp, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __builtin_amdgcn_exp2f(s[r] * c2);
+                s[r] = p;
+                dp[r] = p * dp[r];
+            }
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp) {
+                const bf16x8 pf = pack8(s, sp), dsf = pack8(dp, sp);
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Dl, qb * 32 + 16 * sp, db, lane), pf, dv[db], 0, 0, 0);
+                    dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Ql, qb * 32 + 16 * sp, db, lane), dsf, dk[db], 0, 0, 0);
+                }
+            }
+        }
+        if (more) swrite(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+    if (key < N) {
+        bf16_t* row = dqkv + ((long)b * N + key) * D3 + head * 64;
+        store_dT(row + Dm, dk, scale, h);
+        store_dT(row + 2 * Dm, dv, 1.0f, h);
+    }
+}
+
+// dQ: grid (ceil(N/128), H, B); each wave owns 32 queries, sweeps all keys in 64-row tiles.
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
+                                                          const float* __restrict__ lse, const float* __restrict__ delta,
+                                                          bf16_t* __restrict__ dqkv, int N, int H, float scale) {
+    __shared__ __attribute__((aligned(16))) char smem[32768];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, c = lane & 31;
+    const int b = blockIdx.z, head = blockIdx.y, q0 = blockIdx.x * 128 + wave * 32;
+    const int Dm = H * 64, D3 = 3 * Dm;
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(qkv + (long)b * N * D3, (size_t)N * D3 * 2);
+    const __amdgpu_buffer_rsrc_t rsd = make_rsrc(d_o + (long)b * N * Dm, (size_t)N * Dm * 2);
+    const float c2 = scale * 1.44269504088896341f;
+    const int qrow = min(q0 + c, N - 1);
+    bf16x8 qf[4], dof[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        qf[ks] = __builtin_bit_cast(bf16x8, buf_load16(rs, (unsigned)(((long)qrow * D3 + head * 64 + ks * 16 + 8 * h) * 2)));
+        dof[ks] = __builtin_bit_cast(bf16x8, buf_load16(rsd, (unsigned)(((long)qrow * Dm + head * 64 + ks * 16 + 8 * h) * 2)));
+    }
+    const float lq = lse[((long)b * H + head) * N + qrow] * 1.44269504088896341f;
+    const float dq_ = delta[((long)b * H + head) * N + qrow];
+    u32x4 rk[2], rv[2];
+    auto gload = [&](int t) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int idx = it * 256 + tid, key = t * 64 + (idx >> 3);
+            const unsigned off = key < N ? (unsigned)(((long)key * D3 + Dm + head * 64 + (idx & 7) * 8) * 2) : HS_OOB_OFF;
+            rk[it] = buf_load16(rs, off);
+            rv[it] = buf_load16(rs, key < N ? off + Dm * 2 : HS_OOB_OFF);
+        }
+    };
+    auto swrite = [&](int st) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int idx = it * 256 + tid, o_ = offR(idx >> 3, idx & 7);
+            *(u32x4*)(smem + st * 16384 + o_) = rk[it];
+            *(u32x4*)(smem + st * 16384 + 8192 + o_) = rv[it];
+        }
+    };
+    f32x16 dq[2] = {zero16(), zero16()};
+    const int nt = (N + 63) >> 6;
+    gload(0);
+    swrite(0);
+    __syncthreads();
+    int cur = 0;
+    for (int t = 0; t < nt; ++t) {
+        const bool more = t + 1 < nt;
+        if (more) gload(t + 1);
+        const char* Kl = smem + cur * 16384;
+        const char* Vl = Kl + 8192;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            f32x16 st = zero16(), dpt = zero16();
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Kl, kb * 32 + c, ks, h), qf[ks], st, 0, 0, 0);
+                dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Vl, kb * 32 + c, ks, h), dof[ks], dpt, 0, 0, 0);
+            }
+            const bool tail = (t == nt - 1) && (N & 63);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float p = __builtin_amdgcn_exp2f(st[r] * c2 - lq);
+                if (tail && t * 64 + kb * 32 + acc_row(r, h) >= N) p = 0.f;
+                dpt[r] = p * (dpt[r] - dq_);
+            }
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp) {
+                const bf16x8 dsf = pack8(dpt, sp);
+#pragma unroll
+                for (int db = 0; db < 2; ++db)
+                    dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Kl, kb * 32 + 16 * sp, db, lane), dsf, dq[db], 0, 0, 0);
+            }
+        }
+        if (more) swrite(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+    const int query = q0 + c;
+    if (query < N) store_dT(dqkv + ((long)b * N + query) * D3 + head * 64, dq, scale, h);
+}
+
+extern "C" int hs_attn_fwd(const void* qkv, void* o, float* lse, int B, int N, int H, int dh, int prec, void* stream) {
+    if (!qkv || !o) return HS_ERR_ARG;
+    if (dh != 64 || B < 1 || N < 1 || H < 1) return HS_ERR_SHAPE;
+    const size_t esz = prec == HS_PREC_BF16 ? 2 : 4;
+    if ((size_t)N * 3 * H * 64 * esz >= HS_MAX_RECORDS) return HS_ERR_SHAPE;
+    if (((uintptr_t)qkv | (uintptr_t)o) & 15) return HS_ERR_SHAPE;
+    const float scale = 0.125f;  // dh^-0.5
+    dim3 grid((N + 127) / 128, H, B);
+    hipStream_t s = (hipStream_t)stream;
+    if (prec == HS_PREC_BF16) {
+        if (!lse) return HS_ERR_ARG;
+        hipLaunchKernelGGL(attn_fwd_bf16_kernel, grid, dim3(256), 0, s, (const bf16_t*)qkv, (bf16_t*)o, lse, N, H, scale);
+    } else if (prec == HS_PREC_F32) {
+        hipLaunchKernelGGL(attn_fwd_f32_kernel, grid, dim3(256), 0, s, (const float*)qkv, (float*)o, lse, N, H, scale);
+    } else {
+        return HS_ERR_ARG;
+    }
+    HS_CHECK_LAUNCH();
+    return HS_OK;
+}
+
+extern "C" int hs_attn_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv, float* delta_ws,
+                           int B, int N, int H, int dh, void* stream) {
+    if (!qkv || !o || !d_o || !lse || !dqkv || !delta_ws) return HS_ERR_ARG;
+    if (dh != 64 || B < 1 || N < 1 || H < 1) return HS_ERR_SHAPE;
+    if ((size_t)N * 3 * H * 64 * 2 >= HS_MAX_RECORDS) return HS_ERR_SHAPE;
+    if (((uintptr_t)qkv | (uintptr_t)o | (uintptr_t)d_o | (uintptr_t)dqkv) & 15) return HS_ERR_SHAPE;
+    const float scale = 0.125f;
+    hipStream_t s = (hipStream_t)stream;
+    const long total = (long)B * N * H * 8;
+    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const bf16_t*)o,
+                       (const bf16_t*)d_o, delta_ws, B, N, H);
+    dim3 grid((N + 127) / 128, H, B);
+    hipLaunchKernelGGL(attn_bwd_dkdv_kernel, grid, dim3(256), 0, s, (const bf16_t*)qkv, (const bf16_t*)d_o, lse, delta_ws,
+                       (bf16_t*)dqkv, N, H, scale);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, s, (const bf16_t*)qkv, (const bf16_t*)d_o, lse, delta_ws,
+                       (bf16_t*)dqkv, N, H, scale);
+    HS_CHECK_LAUNCH();
+    return HS_OK;
+}

@@ -1,0 +1,90 @@
+// Shared device/host helpers for the hsenet_amd HIP kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/hsenet_hip.h"
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits
+typedef __attribute__((ext_vector_type(8))) short bf16x8;   // one MFMA A/B fragment (4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) short bf16x4;   // one ds_read_b64_tr_b16 result
+typedef __attribute__((ext_vector_type(16))) float f32x16;  // 32x32 MFMA accumulator
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+#define HS_WAVE 64
+#define LDS_PTR(T) __attribute__((address_space(3))) T*
+
+// offset that is out of range for every buffer descriptor we build (num_records is clamped below it)
+#define HS_OOB_OFF 0x7FFFFFF0u
+#define HS_MAX_RECORDS 0x7FFFFFF0u
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
+
+// round-to-nearest-even f32 -> bf16 through the compiler's cast (v_cvt_pk_bf16_f32; NaN stays NaN)
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(unsigned short, b);
+}
+__device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
+    typedef __attribute__((ext_vector_type(2))) float f2;
+    f2 v = {lo, hi};
+    bf2 r = __builtin_convertvector(v, bf2);
+    return __builtin_bit_cast(unsigned, r);
+}
+
+// row in a 32x32 MFMA accumulator held in register r by a lane of half h (cdna guide section 3)
+__device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// exact (erf) GELU and its derivative, as nn.GELU() / MONAI act="GELU"
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Buffer descriptor with hardware range checking: loads past `bytes` return 0.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, size_t bytes) {
+    unsigned n = bytes > (size_t)HS_MAX_RECORDS ? HS_MAX_RECORDS : (unsigned)bytes;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, n, 0x00020000);
+}
+__device__ __forceinline__ u32x4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+}
+
+// ---- LDS images -----------------------------------------------------------------------------
+// Image R: [rows][64 bf16] (128-B rows), read by rows with ds_read_b128 (MFMA operand whose k is
+// contiguous in memory) AND by columns with ds_read_b64_tr_b16.  16-B chunk c of row r sits at
+// chunk c ^ swzR(r).  Derivation in DESIGN.md ("LDS images"): conflict-free for both read kinds.
+__device__ __forceinline__ int swzR(int r) { return (((r >> 1) & 1) << 2) | (((r >> 3) & 1) << 1) | ((r >> 2) & 1); }
+__device__ __forceinline__ int offR(int r, int c) { return r * 128 + ((c ^ swzR(r)) << 4); }
+// Image T: [rows][128 bf16] (256-B rows), read only by columns (ds_read_b64_tr_b16): the operand
+// whose k index is the memory row.  Swizzle (b) of the cdna guide T10.
+__device__ __forceinline__ int offT(int r, int c) { return r * 256 + ((c ^ (((r & 3) << 2) | ((r >> 2) & 3))) << 4); }
+
+__device__ __forceinline__ bf16x4 lds_tr16(const char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(bf16x4))(p));
+}
+__device__ __forceinline__ bf16x8 cat4(bf16x4 a, bf16x4 b) {
+    bf16x8 r;
+    r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3];
+    r[4] = b[0]; r[5] = b[1]; r[6] = b[2]; r[7] = b[3];
+    return r;
+}
+
+#define HS_CHECK_LAUNCH()                                   \
+    do {                                                    \
+        hipError_t e__ = hipGetLastError();                 \
+        if (e__ != hipSuccess) return HS_ERR_LAUNCH;        \
+    } while (0)

@@ -1,0 +1,170 @@
+// K2: LayerNorm forward / backward (nn.LayerNorm(d), eps=1e-5): MONAI TransformerBlock.norm1/norm2, the final
+// `norm` (multimodal_encoder/vit.py:355,467) and the post-attention norms of regular_attention (vit.py:62) and
+// resolution_attention_v3 (spatial_pooling_projector.py:82).  HBM-bound: one wavefront per row, the row lives
+// in registers (d <= 1024), mean/variance by wave shuffles in fp32 (two-pass, like PyTorch's kernel), 16-B
+// accesses.  The forward can fuse the residual add in front (LN(x + resid)) and emit bf16 for the next GEMM.
+#include "common.h"
+
+#define LN_MAXCH 4  // float4 chunks per lane -> d <= 1024
+
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ resid,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            float* __restrict__ y, bf16_t* __restrict__ yb,
+                                                            float* __restrict__ mean, float* __restrict__ rstd, int rows,
+                                                            int d, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nch = d >> 2;
+    const float* xr = x + (long)row * d;
+    f32x4 v[LN_MAXCH];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXCH; ++i) {
+        const int ch = lane + 64 * i;
+        if (ch < nch) {
+            v[i] = *(const f32x4*)(xr + ch * 4);
+            if (resid) {
+                const f32x4 r = *(const f32x4*)(resid + (long)row * d + ch * 4);
+                v[i] += r;
+            }
+            sum += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+        }
+    }
+    const float mu = wave_sum(sum) / d;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXCH; ++i) {
+        const int ch = lane + 64 * i;
+        if (ch < nch) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float t = v[i][e] - mu;
+                sq += t * t;
+            }
+        }
+    }
+    const float rs = rsqrtf(wave_sum(sq) / d + eps);
+    if (lane == 0) {
+        if (mean) mean[row] = mu;
+        if (rstd) rstd[row] = rs;
+    }
+#pragma unroll
+    for (int i = 0; i < LN_MAXCH; ++i) {
+        const int ch = lane + 64 * i;
+        if (ch < nch) {
+            const f32x4 g = *(const f32x4*)(gamma + ch * 4);
+            const f32x4 b = *(const f32x4*)(beta + ch * 4);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mu) * rs * g[e] + b[e];
+            if (y) *(f32x4*)(y + (long)row * d + ch * 4) = o;
+            if (yb) {
+                u32x2 pk;
+                pk[0] = pack2bf(o[0], o[1]);
+                pk[1] = pack2bf(o[2], o[3]);
+                *(u32x2*)(yb + (long)row * d + ch * 4) = pk;
+            }
+        }
+    }
+}
+
+// Each wave walks rows (grid-stride), keeps its dgamma/dbeta partials in registers, then the block reduces
+// through LDS and issues one float atomic per column.
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                            const float* __restrict__ resid, const float* __restrict__ gamma,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            const float* __restrict__ dx_in, float* __restrict__ dx,
+                                                            bf16_t* __restrict__ dxb, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, int rows, int d) {
+    __shared__ float red[2][4][LN_MAXCH * 256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nch = d >> 2;
+    f32x4 g[LN_MAXCH], dg[LN_MAXCH], db[LN_MAXCH];
+#pragma unroll
+    for (int i = 0; i < LN_MAXCH; ++i) {
+        const int ch = lane + 64 * i;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { dg[i][e] = 0.f; db[i][e] = 0.f; g[i][e] = 0.f; }
+        if (ch < nch) g[i] = *(const f32x4*)(gamma + ch * 4);
+    }
+    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+        const float mu = mean[row], rs = rstd[row];
+        f32x4 xh[LN_MAXCH], gy[LN_MAXCH];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXCH; ++i) {
+            const int ch = lane + 64 * i;
+            if (ch < nch) {
+                f32x4 xv = *(const f32x4*)(x + (long)row * d + ch * 4);
+                if (resid) xv += *(const f32x4*)(resid + (long)row * d + ch * 4);
+                const f32x4 dv = *(const f32x4*)(dy + (long)row * d + ch * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    xh[i][e] = (xv[e] - mu) * rs;
+                    gy[i][e] = dv[e] * g[i][e];
+                    s1 += gy[i][e];
+                    s2 += gy[i][e] * xh[i][e];
+                    dg[i][e] += dv[e] * xh[i][e];
+                    db[i][e] += dv[e];
+                }
+            }
+        }
+        const float c1 = wave_sum(s1) / d, c2 = wave_sum(s2) / d;
+#pragma unroll
+        for (int i = 0; i < LN_MAXCH; ++i) {
+            const int ch = lane + 64 * i;
+            if (ch < nch) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = rs * (gy[i][e] - c1 - xh[i][e] * c2);
+                if (dx_in) o += *(const f32x4*)(dx_in + (long)row * d + ch * 4);
+                if (dx) *(f32x4*)(dx + (long)row * d + ch * 4) = o;
+                if (dxb) {
+                    u32x2 pk;
+                    pk[0] = pack2bf(o[0], o[1]);
+                    pk[1] = pack2bf(o[2], o[3]);
+                    *(u32x2*)(dxb + (long)row * d + ch * 4) = pk;
+                }
+            }
+        }
+    }
+    if (!dgamma && !dbeta) return;
+#pragma unroll
+    for (int i = 0; i < LN_MAXCH; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            red[0][wave][(lane + 64 * i) * 4 + e] = dg[i][e];
+            red[1][wave][(lane + 64 * i) * 4 + e] = db[i][e];
+        }
+    __syncthreads();
+    for (int col = threadIdx.x; col < d; col += 256) {
+        const float a = red[0][0][col] + red[0][1][col] + red[0][2][col] + red[0][3][col];
+        const float b = red[1][0][col] + red[1][1][col] + red[1][2][col] + red[1][3][col];
+        if (dgamma) atomicAdd(&dgamma[col], a);
+        if (dbeta) atomicAdd(&dbeta[col], b);
+    }
+}
+
+extern "C" int hs_layernorm_fwd(const float* x, const float* resid, const float* gamma, const float* beta, float* y_f32,
+                                void* y_bf16, float* mean, float* rstd, int rows, int d, float eps, void* stream) {
+    if (!x || !gamma || !beta || (!y_f32 && !y_bf16)) return HS_ERR_ARG;
+    if (rows < 1 || d < 4 || (d & 3) || d > LN_MAXCH * 256) return HS_ERR_SHAPE;
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, resid, gamma, beta,
+                       y_f32, (bf16_t*)y_bf16, mean, rstd, rows, d, eps);
+    HS_CHECK_LAUNCH();
+    return HS_OK;
+}
+
+extern "C" int hs_layernorm_bwd(const float* dy, const float* x, const float* resid, const float* gamma, const float* mean,
+                                const float* rstd, const float* dx_in, float* dx, void* dx_bf16, float* dgamma,
+                                float* dbeta, int rows, int d, void* stream) {
+    if (!dy || !x || !gamma || !mean || !rstd || (!dx && !dx_bf16)) return HS_ERR_ARG;
+    if (rows < 1 || d < 4 || (d & 3) || d > LN_MAXCH * 256) return HS_ERR_SHAPE;
+    int blocks = (rows + 3) / 4;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, x, resid, gamma, mean, rstd,
+                       dx_in, dx, (bf16_t*)dx_bf16, dgamma, dbeta, rows, d);
+    HS_CHECK_LAUNCH();
+    return HS_OK;
+}

@@ -1,0 +1,715 @@
+// K1 / K5 / K6 / K7 / K8: the HBM-bound kernels around the GEMMs (see include/hsenet_hip.h for the reference
+// operator sequence each replaces).  All use 16-B accesses per lane and wave-shuffle reductions.
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------------
+// K1 patchify: x.clone() + rearrange 'b c (h p1)(w p2)(d p3) -> b (h w d)(p1 p2 p3 c)' (vit.py:437,455).
+// Fast path (C == 1, p3 % 8 == 0): a lane reads 8 consecutive voxels along W (32 B), so a wave reads 2 KiB
+// contiguous, and writes them as 8 consecutive features of one patch row.
+// ------------------------------------------------------------------------------------------------------
+template <bool BF16>
+__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ vol, void* __restrict__ out, int B, int D,
+                                                       int H, int W, int p1, int p2, int p3) {
+    const int W8 = W >> 3;
+    const long total = (long)B * D * H * W8;
+    const long g = (long)blockIdx.x * 256 + threadIdx.x;
+    if (g >= total) return;
+    const int w0 = (int)(g % W8) * 8;
+    long t = g / W8;
+    const int hh = (int)(t % H); t /= H;
+    const int dd = (int)(t % D);
+    const int b = (int)(t / D);
+    const int gh = H / p2, gw = W / p3;
+    const long Np = (long)(D / p1) * gh * gw;
+    const int Pd = p1 * p2 * p3;
+    const long patch = ((long)(dd / p1) * gh + hh / p2) * gw + w0 / p3;
+    const int feat = ((dd % p1) * p2 + hh % p2) * p3 + (w0 % p3);
+    const f32x4 a = *(const f32x4*)(vol + g * 8);
+    const f32x4 c = *(const f32x4*)(vol + g * 8 + 4);
+    const long o = (b * Np + patch) * Pd + feat;
+    if (BF16) {
+        u32x4 pk;
+        pk[0] = pack2bf(a[0], a[1]); pk[1] = pack2bf(a[2], a[3]);
+        pk[2] = pack2bf(c[0], c[1]); pk[3] = pack2bf(c[2], c[3]);
+        *(u32x4*)((bf16_t*)out + o) = pk;
+    } else {
+        *(f32x4*)((float*)out + o) = a;
+        *(f32x4*)((float*)out + o + 4) = c;
+    }
+}
+// generic path: one element per thread (any C, any patch size)
+template <bool BF16>
+__global__ __launch_bounds__(256) void patchify_generic_kernel(const float* __restrict__ vol, void* __restrict__ out, int B,
+                                                               int C, int D, int H, int W, int p1, int p2, int p3) {
+    const long total = (long)B * C * D * H * W;
+    const long g = (long)blockIdx.x * 256 + threadIdx.x;
+    if (g >= total) return;
+    const int ww = (int)(g % W);
+    long t = g / W;
+    const int hh = (int)(t % H); t /= H;
+    const int dd = (int)(t % D); t /= D;
+    const int cc = (int)(t % C);
+    const int b = (int)(t / C);
+    const int gh = H / p2, gw = W / p3;
+    const long Np = (long)(D / p1) * gh * gw;
+    const long Pd = (long)p1 * p2 * p3 * C;
+    const long patch = ((long)(dd / p1) * gh + hh / p2) * gw + ww / p3;
+    const long feat = ((long)((dd % p1) * p2 + hh % p2) * p3 + (ww % p3)) * C + cc;
+    const long o = (b * Np + patch) * Pd + feat;
+    if (BF16) ((bf16_t*)out)[o] = f2bf(vol[g]); else ((float*)out)[o] = vol[g];
+}
+
+extern "C" int hs_patchify(const float* vol, void* out, int B, int C, int D, int H, int W, int p1, int p2, int p3, int prec,
+                           void* stream) {
+    if (!vol || !out) return HS_ERR_ARG;
+    if (B < 1 || C < 1 || p1 < 1 || p2 < 1 || p3 < 1 || D % p1 || H % p2 || W % p3) return HS_ERR_SHAPE;
+    if (prec != HS_PREC_BF16 && prec != HS_PREC_F32) return HS_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (C == 1 && (p3 % 8) == 0 && !(((uintptr_t)vol | (uintptr_t)out) & 15)) {
+        const long total = (long)B * D * H * (W / 8);
+        dim3 grid((unsigned)((total + 255) / 256));
+        if (prec == HS_PREC_BF16) hipLaunchKernelGGL(patchify_kernel<true>, grid, dim3(256), 0, s, vol, out, B, D, H, W, p1, p2, p3);
+        else hipLaunchKernelGGL(patchify_kernel<false>, grid, dim3(256), 0, s, vol, out, B, D, H, W, p1, p2, p3);
+    } else {
+        const long total = (long)B * C * D * H * W;
+        dim3 grid((unsigned)((total + 255) / 256));
+        if (prec == HS_PREC_BF16) hipLaunchKernelGGL(patchify_generic_kernel<true>, grid, dim3(256), 0, s, vol, out, B, C, D, H, W, p1, p2, p3);
+        else hipLaunchKernelGGL(patchify_generic_kernel<false>, grid, dim3(256), 0, s, vol, out, B, C, D, H, W, p1, p2, p3);
+    }
+    HS_CHECK_LAUNCH();
+    return HS_OK;
+}
+
+// tokens = cat(cls, (pe + pos) * score)   (vit.py:345-349, 459-461; pos add = PatchEmbeddingBlock.forward)
+// cls == NULL (classification=False): no cls row, tokens is [B][Np][d].
+__global__ __launch_bounds__(256) void assemble_tokens_kernel(const float* __restrict__ pe, const float* __restrict__ pos,
+                                                              const float* __restrict__ cls, const float* __restrict__ score,
+                                                              float* __restrict__ tokens, float* __restrict__ pe_out, int B,
+                                                              int Np, int d) {
+    const int d4 = d >> 2;
+    const int c0 = cls ? 1 : 0, Nt = Np + c0;
+    const long total = (long)B * Nt * d4;
+    const long g = (long)blockIdx.x * 256 + threadIdx.x;
+    if (g >= total) return;
+    const int ch = (int)(g % d4);
+    const long row = g / d4;
+    const int n = (int)(row % Nt);
+    const int b = (int)(row / Nt);
+    f32x4 v;
+    if (n < c0) {
+        v = *(const f32x4*)(cls + ch * 4);
+    } else {
+        const long pr = (long)b * Np + (n - c0);
+        v = *(const f32x4*)(pe + pr * d + ch * 4);
+        if (pos) v += *(const f32x4*)(pos + (long)(n - c0) * d + ch * 4);
+        if (pe_out) *(f32x4*)(pe_out + pr * d + ch * 4) = v;
+        if (score) v *= score[pr];
+    }
+    *(f32x4*)(tokens + row * d + ch * 4) = v;
+}
+extern "C" int hs_assemble_tokens(const float* pe, const float* pos, const float* cls, const float* score, float* tokens,
+                                  float* pe_out, int B, int Np, int d, void* stream) {
+    if (!pe || !tokens) return HS_ERR_ARG;
+    if (B < 1 || Np < 1 || d < 4 || (d & 3)) return HS_ERR_SHAPE;
+    const long total = (long)B * (Np + (cls ? 1 : 0)) * (d / 4);
+    hipLaunchKernelGGL(assemble_tokens_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pe, pos,
+                       cls, score, tokens, pe_out, B, Np, d);
+    HS_CHECK_LAUNCH();
+    return HS_OK;
+}
+
+// one wave per patch row p (all batches): dpe = dtok*score, dscore = <dtok, pe_pos>, dpos[p] += sum_b dpe.
+// has_cls: dtok is [B][Np+1][d] and wave p == Np reduces the cls row; else dtok is [B][Np][d].
+__global__ __launch_bounds__(256) void assemble_tokens_bwd_kernel(const float* __restrict__ dtok, const float* __restrict__ pe_pos,
+                                                                  const float* __restrict__ score, float* __restrict__ dpe,
+                                                                  float* __restrict__ dpos, float* __restrict__ dcls,
+                                                                  float* __restrict__ dscore, int B, int Np, int d, int has_cls) {
+    const int lane = threadIdx.x & 63;
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);   // p == Np handles the cls row
+    const int Nt = Np + has_cls;
+    if (p >= Nt) return;
+    const int nch = d >> 2;
+    for (int ch = lane; ch < nch; ch += 64) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < B; ++b) {
+            if (p == Np) {
+                acc += *(const f32x4*)(dtok + ((long)b * Nt) * d + ch * 4);
+            } else {
+                f32x4 g = *(const f32x4*)(dtok + ((long)b * Nt + has_cls + p) * d + ch * 4);
+                if (score) g *= score[(long)b * Np + p];
+                if (dpe) *(f32x4*)(dpe + ((long)b * Np + p) * d + ch * 4) = g;
+                acc += g;
+            }
+        }
+        if (p == Np) { if (dcls) { float* o = dcls + ch * 4; for (int e = 0; e < 4; ++e) atomicAdd(o + e, acc[e]); } }
+        else if (dpos) { float* o = dpos + (long)p * d + ch * 4; for (int e = 0; e < 4; ++e) atomicAdd(o + e, acc[e]); }
+    }
+    if (score && dscore && p < Np) {
+        for (int b = 0; b < B; ++b) {
+            float s = 0.f;
+            for (int ch = lane; ch < nch; ch += 64) {
+                const f32x4 g = *(const f32x4*)(dtok + ((long)b * Nt + has_cls + p) * d + ch * 4);
+                const f32x4 x = *(const f32x4*)(pe_pos + ((long)b * Np + p) * d + ch * 4);
+                s += g[0] * x[0] + g[1] * x[1] + g[2] * x[2] + g[3] * x[3];
+            }
+            s = wave_sum(s);
+            if (lane == 0) dscore[(long)b * Np + p] = s;
+        }
+    }
+}
+// dcls == NULL  <=>  the forward had no cls row (dtok is [B][Np][d])
+extern "C" int hs_assemble_tokens_bwd(const float* dtok, const float* pe_pos, const float* score, float* dpe, float* dpos,
+                                      float* dcls, float* dscore, int B, int Np, int d, void* stream) {
+    if (!dtok) return HS_ERR_ARG;
+    if (score && dscore && !pe_pos) return HS_ERR_ARG;
+    if (B < 1 || Np < 1 || d < 4 || (d & 3)) return HS_ERR_SHAPE;
+    const int has_cls = dcls ? 1 : 0;
+    hipLaunchKernelGGL(assemble_tokens_bwd_kernel, dim3((Np + has_cls + 3) / 4), dim3(256), 0, (hipStream_t)stream, dtok, pe_pos, score,
+                       dpe, dpos, dcls, dscore, B, Np, d, has_cls);
+    HS_CHECK_LAUNCH();
+    return HS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// row softmax (fwd, in place) and its backward, rows of n <= 64: one wave per row.  Used by the single-head
+// cross-attention of regular_attention (vit.py:25-33): scores [B*nq][nk=32].
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ s, long rows, int n) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float v = lane < n ? s[row * n + lane] : -__builtin_inff();
+    const float m = wave_max(v);
+    const float e = lane < n ? __expf(v - m) : 0.f;
+    const float z = wave_sum(e);
+    if (lane < n) s[row * n + lane] = e / z;
+}
+// ds = p * (dp - sum(p*dp)), in place on dp
+__global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(const float* __restrict__ p, float* __restrict__ dp, long rows, int n) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float pv = lane < n ? p[row * n + lane] : 0.f;
+    const float dv = lane < n ? dp[row * n + lane] : 0.f;
+    const float dot = wave_sum(pv * dv);
+    if (lane < n) dp[row * n + lane] = pv * (dv - dot);
+}
+
+static int launch_f32_gemm(int layout, const float* A, const float* Bm, float* C, int M, int N, int K, long lda, long ldb,
+                           long ldc, int batch, long sA, long sB, long sC, float alpha, int flags, int split_k, void* stream) {
+    hs_gemm_args g = {};
+    g.A = A; g.B = Bm; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.batch = batch;
+    g.strideA = sA; g.strideB = sB; g.strideC = sC; g.out_f32 = C; g.ldc = ldc; g.alpha = alpha; g.flags = flags;
+    g.layout = layout; g.split_k = split_k;
+    return hs_gemm(&g, HS_PREC_F32, stream);
+}
+
+// K5 core as exact-f32 MFMA GEMMs + a 32-wide row softmax (tiny FLOPs: 4*nq*nk*d per volume).
+extern "C" int hs_cross_attn_fwd(const float* q, const float* k, const float* v, float* out, float* p, int B, int nq, int nk,
+                                 int d, void* stream) {
+    if (!q || !k || !v || !out || !p) return HS_ERR_ARG;
+    if (B < 1 || nq < 1 || nk < 4 || nk > 64 || (nk & 3) || (d & 3)) return HS_ERR_SHAPE;
+    const float alpha = 1.0f / sqrtf((float)d);
+    int rc = launch_f32_gemm(HS_GEMM_NT, q, k, p, nq, nk, d, d, d, nk, B, (long)nq * d, (long)nk * d, (long)nq * nk, alpha, 0, 1, stream);
+    if (rc) return rc;
+    const long rows = (long)B * nq;
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p, rows, nk);
+    HS_CHECK_LAUNCH();
+    // out = P V : A = P [nq][nk], B = V stored [K=nk][N=d]
+    return launch_f32_gemm(HS_GEMM_NN, p, v, out, nq, d, nk, nk, d, d, B, (long)nq * nk, (long)nk * d, (long)nq * d, 1.0f, 0, 1, stream);
+}
+// ws: fp32 scratch [B][nq][nk].  dq written; dk, dv written (not accumulated).
+extern "C" int hs_cross_attn_bwd(const float* q, const float* k, const float* v, const float* p, const float* dout, float* dq,
+                                 float* dk, float* dv, float* ws, int B, int nq, int nk, int d, void* stream) {
+    if (!q || !k || !v || !p || !dout || !dq || !dk || !dv || !ws) return HS_ERR_ARG;
+    if (B < 1 || nq < 4 || (nq & 3) || nk < 4 || nk > 64 || (nk & 3) || (d & 3)) return HS_ERR_SHAPE;
+    const float alpha = 1.0f / sqrtf((float)d);
+    const long sq = (long)nq * d, sk = (long)nk * d, sp = (long)nq * nk;
+    // dP = dOut V^T
+    int rc = launch_f32_gemm(HS_GEMM_NT, dout, v, ws, nq, nk, d, d, d, nk, B, sq, sk, sp, 1.0f, 0, 1, stream);
+    if (rc) return rc;
+    const long rows = (long)B * nq;
+    hipLaunchKernelGGL(softmax_rows_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p, ws, rows, nk);
+    HS_CHECK_LAUNCH();
+    // dQ = dS K * alpha ;  dK = dS^T Q * alpha ; dV = P^T dOut
+    if ((rc = launch_f32_gemm(HS_GEMM_NN, ws, k, dq, nq, d, nk, nk, d, d, B, sp, sk, sq, alpha, 0, 1, stream))) return rc;
+    if ((rc = launch_f32_gemm(HS_GEMM_TN, ws, q, dk, nk, d, nq, nk, d, d, B, sp, sq, sk, alpha, 0, 1, stream))) return rc;
+    return launch_f32_gemm(HS_GEMM_TN, p, dout, dv, nk, d, nq, nk, d, d, B, sp, sq, sk, 1.0f, 0, 1, stream);
+}
+
+// patch_score_proj + Sigmoid (vit.py:338-339): one wave per row
+__global__ __launch_bounds__(256) void rowdot_sigmoid_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                 const float* __restrict__ b, float* __restrict__ score, int rows,
+                                                                 int d) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float s = 0.f;
+    for (int ch = lane; ch < (d >> 2); ch += 64) {
+        const f32x4 a = *(const f32x4*)(x + (long)row * d + ch * 4);
+        const f32x4 ww = *(const f32x4*)(w + ch * 4);
+        s += a[0] * ww[0] + a[1] * ww[1] + a[2] * ww[2] + a[3] * ww[3];
+    }
+    s = wave_sum(s) + b[0];
+    if (lane == 0) score[row] = 1.0f / (1.0f + __expf(-s));
+}
+#define RD_MAXCH 4
+__global__ __launch_bounds__(256) void rowdot_sigmoid_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                 const float* __restrict__ score, const float* __restrict__ dscore,
+                                                                 float* __restrict__ dx, float* __restrict__ dw, float* __restrict__ db,
+                                                                 int rows, int d) {
+    __shared__ float red[4][RD_MAXCH * 256];
+    __shared__ float redb[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nch = d >> 2;
+    f32x4 wv[RD_MAXCH], acc[RD_MAXCH];
+#pragma unroll
+    for (int i = 0; i < RD_MAXCH; ++i) {
+        const int ch = lane + 64 * i;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { acc[i][e] = 0.f; wv[i][e] = 0.f; }
+        if (ch < nch) wv[i] = *(const f32x4*)(w + ch * 4);
+    }
+    float bacc = 0.f;
+    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+        const float s = score[row];
+        const float ds = dscore[row] * s * (1.0f - s);
+        bacc += ds;
+#pragma unroll
+        for (int i = 0; i < RD_MAXCH; ++i) {
+            const int ch = lane + 64 * i;
+            if (ch < nch) {
+                const f32x4 xv = *(const f32x4*)(x + (long)row * d + ch * 4);
+                acc[i] += xv * ds;
+                if (dx) *(f32x4*)(dx + (long)row * d + ch * 4) = wv[i] * ds;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < RD_MAXCH; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[wave][(lane + 64 * i) * 4 + e] = acc[i][e];
+    if (lane == 0) redb[wave] = bacc;
+    __syncthreads();
+    for (int col = threadIdx.x; col < d; col += 256)
+        if (dw) atomicAdd(&dw[col], red[0][col] + red[1][col] + red[2][col] + red[3][col]);
+    if (threadIdx.x == 0 && db) atomicAdd(db, redb[0] + redb[1] + redb[2] + redb[3]);
+}
+extern "C" int hs_rowdot_sigmoid_fwd(const float* x, const float* w, const float* b, float* score, int rows, int d, void* stream) {
+    if (!x || !w || !b || !score) return HS_ERR_ARG;
+    if (rows < 1 || d < 4 || (d & 3)) return HS_ERR_SHAPE;
+    hipLaunchKernelGGL(rowdot_sigmoid_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, w, b, score, rows, d);
+    HS_CHECK_LAUNCH();
+    return HS_OK;
+}
+extern "C" int hs_rowdot_sigmoid_bwd(const float* x, const float* w, const float* score, const float* dscore, float* dx,
+                                     float* dw, float* db, int rows, int d, void* stream) {
+    if (!x || !w || !score || !dscore) return HS_ERR_ARG;
+    if (rows < 1 || d < 4 || (d & 3) || d > RD_MAXCH * 256) return HS_ERR_SHAPE;
+    int blocks = (rows + 3) / 4;
+    if (blocks > 512) blocks = 512;
+    hipLaunchKernelGGL(rowdot_sigmoid_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, w, score, dscore, dx, dw, db,
+                       rows, d);
+    HS_CHECK_LAUNCH();
+    return HS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// K6 Spatial Packer window step (spatial_pooling_projector.py:62-76,138-141)
+// ------------------------------------------------------------------------------------------------------
+struct Win { int gd, gh, gw, kd, kh, kw, cd, ch, cw, nwin, cells, tokens; };
+__host__ __device__ inline Win make_win(int gd, int gh, int gw, int kd, int kh, int kw) {
+    Win w;
+    w.gd = gd; w.gh = gh; w.gw = gw; w.kd = kd; w.kh = kh; w.kw = kw;
+    w.cd = gd / kd; w.ch = gh / kh; w.cw = gw / kw;
+    w.nwin = kd * kh * kw; w.cells = w.cd * w.ch * w.cw; w.tokens = gd * gh * gw;
+    return w;
+}
+// token index of child j of cell c (children beyond the pooled region do not exist: avg_pool3d floors)
+__device__ __forceinline__ int child_token(const Win& w, int cell, int j) {
+    const int cw_ = cell % w.cw, ch_ = (cell / w.cw) % w.ch, cd_ = cell / (w.cw * w.ch);
+    const int jw = j % w.kw, jh = (j / w.kw) % w.kh, jd = j / (w.kw * w.kh);
+    return ((cd_ * w.kd + jd) * w.gh + (ch_ * w.kh + jh)) * w.gw + (cw_ * w.kw + jw);
+}
+
+__global__ __launch_bounds__(256) void pool3d_fwd_kernel(const float* __restrict__ hr, float* __restrict__ lr, int B, Win w, int d) {
+    const int d4 = d >> 2;
+    const long total = (long)B * w.cells * d4;
+    const long g = (long)blockIdx.x * 256 + threadIdx.x;
+    if (g >= total) return;
+    const int chn = (int)(g % d4);
+    const long bc = g / d4;
+    const int cell = (int)(bc % w.cells), b = (int)(bc / w.cells);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < w.nwin; ++j) acc += *(const f32x4*)(hr + ((long)b * w.tokens + child_token(w, cell, j)) * d + chn * 4);
+    *(f32x4*)(lr + bc * d + chn * 4) = acc * (1.0f / w.nwin);
+}
+__global__ __launch_bounds__(256) void pool3d_bwd_kernel(const float* __restrict__ dlr, float* __restrict__ dhr, int B, Win w, int d,
+                                                         int accumulate) {
+    const int d4 = d >> 2;
+    const long total = (long)B * w.tokens * d4;
+    const long g = (long)blockIdx.x * 256 + threadIdx.x;
+    if (g >= total) return;
+    const int chn = (int)(g % d4);
+    const long bt = g / d4;
+    const int tok = (int)(bt % w.tokens), b = (int)(bt / w.tokens);
+    const int tw = tok % w.gw, th = (tok / w.gw) % w.gh, td = tok / (w.gw * w.gh);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    const int cd_ = td / w.kd, ch_ = th / w.kh, cw_ = tw / w.kw;
+    if (cd_ < w.cd && ch_ < w.ch && cw_ < w.cw) {
+        const int cell = (cd_ * w.ch + ch_) * w.cw + cw_;
+        v = *(const f32x4*)(dlr + ((long)b * w.cells + cell) * d + chn * 4) * (1.0f / w.nwin);
+    }
+    float* o = dhr + bt * d + chn * 4;
+    if (accumulate) v += *(const f32x4*)o;
+    *(f32x4*)o = v;
+}
+
+#define WA_MAXCH 4
+// one wave per (b, cell): 1 query vs nwin (<=64) children, single head of width d
+template <bool BWD>
+__global__ __launch_bounds__(256) void window_attn_kernel(const float* __restrict__ q, const float* __restrict__ kv,
+                                                          const float* __restrict__ dout, float* __restrict__ out,
+                                                          float* __restrict__ dq, float* __restrict__ dkv, int B, Win w, int d) {
+    const int lane = threadIdx.x & 63;
+    const long bc = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (bc >= (long)B * w.cells) return;
+    const int cell = (int)(bc % w.cells), b = (int)(bc / w.cells);
+    const int nch = d >> 2;
+    const float alpha = rsqrtf((float)d);
+    f32x4 qv[WA_MAXCH], gv[WA_MAXCH];
+#pragma unroll
+    for (int i = 0; i < WA_MAXCH; ++i) {
+        const int ch = lane + 64 * i;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { qv[i][e] = 0.f; gv[i][e] = 0.f; }
+        if (ch < nch) {
+            qv[i] = *(const f32x4*)(q + bc * d + ch * 4);
+            if (BWD) gv[i] = *(const f32x4*)(dout + bc * d + ch * 4);
+        }
+    }
+    const float* kvb = kv + (long)b * w.tokens * 2 * d;
+    float sc = -__builtin_inff(), dpl = 0.f;
+    for (int j = 0; j < w.nwin; ++j) {
+        const float* kr = kvb + (long)child_token(w, cell, j) * 2 * d;
+        float s = 0.f, t = 0.f;
+#pragma unroll
+        for (int i = 0; i < WA_MAXCH; ++i) {
+            const int ch = lane + 64 * i;
+            if (ch < nch) {
+                const f32x4 kk = *(const f32x4*)(kr + ch * 4);
+                s += qv[i][0] * kk[0] + qv[i][1] * kk[1] + qv[i][2] * kk[2] + qv[i][3] * kk[3];
+                if (BWD) {
+                    const f32x4 vv = *(const f32x4*)(kr + d + ch * 4);
+                    t += gv[i][0] * vv[0] + gv[i][1] * vv[1] + gv[i][2] * vv[2] + gv[i][3] * vv[3];
+                }
+            }
+        }
+        s = wave_sum(s) * alpha;
+        if (BWD) t = wave_sum(t);
+        if (lane == j) { sc = s; dpl = t; }
+    }
+    const float m = wave_max(sc);
+    const float e = lane < w.nwin ? __expf(sc - m) : 0.f;
+    const float p = e / wave_sum(e);
+    if (!BWD) {
+        f32x4 acc[WA_MAXCH];
+#pragma unroll
+        for (int i = 0; i < WA_MAXCH; ++i)
+#pragma unroll
+            for (int e2 = 0; e2 < 4; ++e2) acc[i][e2] = 0.f;
+        for (int j = 0; j < w.nwin; ++j) {
+            const float pj = __shfl(p, j, 64);
+            const float* vr = kvb + (long)child_token(w, cell, j) * 2 * d + d;
+#pragma unroll
+            for (int i = 0; i < WA_MAXCH; ++i) {
+                const int ch = lane + 64 * i;
+                if (ch < nch) acc[i] += *(const f32x4*)(vr + ch * 4) * pj;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < WA_MAXCH; ++i) {
+            const int ch = lane + 64 * i;
+            if (ch < nch) *(f32x4*)(out + bc * d + ch * 4) = acc[i];
+        }
+    } else {
+        const float dot = wave_sum(p * dpl);
+        const float ds = p * (dpl - dot);
+        f32x4 acc[WA_MAXCH];
+#pragma unroll
+        for (int i = 0; i < WA_MAXCH; ++i)
+#pragma unroll
+            for (int e2 = 0; e2 < 4; ++e2) acc[i][e2] = 0.f;
+        float* dkvb = dkv + (long)b * w.tokens * 2 * d;
+        for (int j = 0; j < w.nwin; ++j) {
+            const float dsj = __shfl(ds, j, 64) * alpha, pj = __shfl(p, j, 64);
+            const long tok = child_token(w, cell, j);
+            const float* kr = kvb + tok * 2 * d;
+            float* dkr = dkvb + tok * 2 * d;
+#pragma unroll
+            for (int i = 0; i < WA_MAXCH; ++i) {
+                const int ch = lane + 64 * i;
+                if (ch < nch) {
+                    acc[i] += *(const f32x4*)(kr + ch * 4) * dsj;
+                    *(f32x4*)(dkr + ch * 4) = qv[i] * dsj;
+                    *(f32x4*)(dkr + d + ch * 4) = gv[i] * pj;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < WA_MAXCH; ++i) {
+            const int ch = lane + 64 * i;
+            if (ch < nch) *(f32x4*)(dq + bc * d + ch * 4) = acc[i];
+        }
+    }
+}
+
+static int win_check(int B, int gd, int gh, int gw, int kd, int kh, int kw, int d) {
+    if (B < 1 || gd < 1 || gh < 1 || gw < 1 || kd < 1 || kh < 1 || kw < 1 || d < 4 || (d & 3)) return HS_ERR_SHAPE;
+    if (kd > gd || kh > gh || kw > gw || kd * kh * kw > 64) return HS_ERR_SHAPE;
+    return HS_OK;
+}
+extern "C" int hs_pool3d_fwd(const float* hr, float* lr, int B, int gd, int gh, int gw, int kd, int kh, int kw, int d, void* stream) {
+    if (!hr || !lr) return HS_ERR_ARG;
+    int rc = win_check(B, gd, gh, gw, kd, kh, kw, d);
+    if (rc) return rc;
+    const Win w = make_win(gd, gh, gw, kd, kh, kw);
+    const long total = (long)B * w.cells * (d / 4);
+    hipLaunchKernelGGL(pool3d_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, hr, lr, B, w, d);
+    HS_CHECK_LAUNCH();
+    return HS_OK;
+}
+extern "C" int hs_pool3d_bwd(const float* dlr, float* dhr, int B, int gd, int gh, int gw, int kd, int kh, int kw, int d,
+                             int accumulate, void* stream) {
+    if (!dlr || !dhr) return HS_ERR_ARG;
+    int rc = win_check(B, gd, gh, gw, kd, kh, kw, d);
+    if (rc) return rc;
+    const Win w = make_win(gd, gh, gw, kd, kh, kw);
+    const long total = (long)B * w.tokens * (d / 4);
+    hipLaunchKernelGGL(pool3d_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dlr, dhr, B, w, d,
+                       accumulate);
+    HS_CHECK_LAUNCH();
+    return HS_OK;
+}
+extern "C" int hs_window_attn_fwd(const float* q, const float* kv, float* out, int B, int gd, int gh, int gw, int kd, int kh,
+                                  int kw, int d, void* stream) {
+    if (!q || !kv || !out) return HS_ERR_ARG;
+    int rc = win_check(B, gd, gh, gw, kd, kh, kw, d);
+    if (rc) return rc;
+    if (d > WA_MAXCH * 256) return HS_ERR_SHAPE;
+    const Win w = make_win(gd, gh, gw, kd, kh, kw);
+    const long waves = (long)B * w.cells;
+    hipLaunchKernelGGL(window_attn_kernel<false>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, q, kv,
+                       (const float*)nullptr, out, (float*)nullptr, (float*)nullptr, B, w, d);
+    HS_CHECK_LAUNCH();
+    return HS_OK;
+}
+// dkv rows of tokens outside every window (grid not divisible by the kernel) are NOT written: caller zeroes dkv then.
+extern "C" int hs_window_attn_bwd(const float* q, const float* kv, const float* dout, float* dq, float* dkv, int B, int gd,
+                                  int gh, int gw, int kd, int kh, int kw, int d, void* stream) {
+    if (!q || !kv || !dout || !dq || !dkv) return HS_ERR_ARG;
+    int rc = win_check(B, gd, gh, gw, kd, kh, kw, d);
+    if (rc) return rc;
+    if (d > WA_MAXCH * 256) return HS_ERR_SHAPE;
+    const Win w = make_win(gd, gh, gw, kd, kh, kw);
+    const long waves = (long)B * w.cells;
+    hipLaunchKernelGGL(window_attn_kernel<true>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, q, kv, dout,
+                       (float*)nullptr, dq, dkv, B, w, d);
+    HS_CHECK_LAUNCH();
+    return HS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// K7/K8
+// ------------------------------------------------------------------------------------------------------
+// out[n] += sum_m x[m][n].  Block: 32 column groups (16 B each) x 8 row lanes; grid (col strips, row chunks).
+template <bool BF16>
+__global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ x, float* __restrict__ out, int M, int N, long ldx,
+                                                     int rows_per_block) {
+    constexpr int V = BF16 ? 8 : 4;
+    __shared__ float red[8][32 * V];
+    const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int col0 = (blockIdx.x * 32 + cg) * V;
+    const int r0 = blockIdx.y * rows_per_block;
+    const int r1 = min(M, r0 + rows_per_block);
+    float acc[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) acc[e] = 0.f;
+    if (col0 < N) {
+        for (int r = r0 + rl; r < r1; r += 8) {
+            if (BF16) {
+                const u32x4 v = *(const u32x4*)((const bf16_t*)x + (long)r * ldx + col0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc[2 * i] += __uint_as_float(v[i] << 16);
+                    acc[2 * i + 1] += __uint_as_float(v[i] & 0xffff0000u);
+                }
+            } else {
+                const f32x4 v = *(const f32x4*)((const float*)x + (long)r * ldx + col0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] += v[e];
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < V; ++e) red[rl][cg * V + e] = acc[e];
+    __syncthreads();
+    if (threadIdx.x < 32 * V) {
+        const int col = blockIdx.x * 32 * V + threadIdx.x;
+        if (col < N) {
+            float s = 0.f;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) s += red[r][threadIdx.x];
+            atomicAdd(&out[col], s);
+        }
+    }
+}
+extern "C" int hs_colsum(const void* x, int is_bf16, float* out, int M, int N, int64_t ldx, void* stream) {
+    if (!x || !out) return HS_ERR_ARG;
+    const int V = is_bf16 ? 8 : 4;
+    if (M < 1 || N < V || (N % V) || (ldx % V) || ((uintptr_t)x & 15)) return HS_ERR_SHAPE;
+    const int rpb = 512;
+    dim3 grid((N + 32 * V - 1) / (32 * V), (M + rpb - 1) / rpb);
+    if (is_bf16) hipLaunchKernelGGL(colsum_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, out, M, N, (long)ldx, rpb);
+    else hipLaunchKernelGGL(colsum_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, out, M, N, (long)ldx, rpb);
+    HS_CHECK_LAUNCH();
+    return HS_OK;
+}
+
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, long n) {
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (i + 8 <= n) {
+        const f32x4 a = *(const f32x4*)(x + i), c = *(const f32x4*)(x + i + 4);
+        u32x4 pk;
+        pk[0] = pack2bf(a[0], a[1]); pk[1] = pack2bf(a[2], a[3]); pk[2] = pack2bf(c[0], c[1]); pk[3] = pack2bf(c[2], c[3]);
+        *(u32x4*)(y + i) = pk;
+    } else {
+        for (long j = i; j < n; ++j) y[j] = f2bf(x[j]);
+    }
+}
+__global__ __launch_bounds__(256) void cast_f32_kernel(const bf16_t* __restrict__ x, float* __restrict__ y, long n) {
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (i + 8 <= n) {
+        const u32x4 v = *(const u32x4*)(x + i);
+        f32x4 a, c;
+        a[0] = __uint_as_float(v[0] << 16); a[1] = __uint_as_float(v[0] & 0xffff0000u);
+        a[2] = __uint_as_float(v[1] << 16); a[3] = __uint_as_float(v[1] & 0xffff0000u);
+        c[0] = __uint_as_float(v[2] << 16); c[1] = __uint_as_float(v[2] & 0xffff0000u);
+        c[2] = __uint_as_float(v[3] << 16); c[3] = __uint_as_float(v[3] & 0xffff0000u);
+        *(f32x4*)(y + i) = a;
+        *(f32x4*)(y + i + 4) = c;
+    } else {
+        for (long j = i; j < n; ++j) y[j] = bf2f(x[j]);
+    }
+}
+extern "C" int hs_cast_bf16(const float* x, void* y, int64_t n, void* stream) {
+    if (!x || !y) return HS_ERR_ARG;
+    if (n < 1 || (((uintptr_t)x | (uintptr_t)y) & 15)) return HS_ERR_SHAPE;
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)((n + 2047) / 2048)), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)y, (long)n);
+    HS_CHECK_LAUNCH();
+    return HS_OK;
+}
+extern "C" int hs_cast_f32(const void* x, float* y, int64_t n, void* stream) {
+    if (!x || !y) return HS_ERR_ARG;
+    if (n < 1 || (((uintptr_t)x | (uintptr_t)y) & 15)) return HS_ERR_SHAPE;
+    hipLaunchKernelGGL(cast_f32_kernel, dim3((unsigned)((n + 2047) / 2048)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, y, (long)n);
+    HS_CHECK_LAUNCH();
+    return HS_OK;
+}
+
+__global__ __launch_bounds__(256) void gelu_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ y, long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    y[i] = dy ? dy[i] * gelu_grad_f(x[i]) : gelu_f(x[i]);
+}
+extern "C" int hs_gelu_fwd(const float* x, float* y, int64_t n, void* stream) {
+    if (!x || !y) return HS_ERR_ARG;
+    if (n < 1) return HS_ERR_SHAPE;
+    hipLaunchKernelGGL(gelu_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, (const float*)nullptr, y, (long)n);
+    HS_CHECK_LAUNCH();
+    return HS_OK;
+}
+extern "C" int hs_gelu_bwd(const float* x, const float* dy, float* dx, int64_t n, void* stream) {
+    if (!x || !dy || !dx) return HS_ERR_ARG;
+    if (n < 1) return HS_ERR_SHAPE;
+    hipLaunchKernelGGL(gelu_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, (long)n);
+    HS_CHECK_LAUNCH();
+    return HS_OK;
+}
+
+// F.normalize(dim=-1): one wave per row
+__global__ __launch_bounds__(256) void l2norm_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ y,
+                                                     int rows, int d, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float ss = 0.f, dot = 0.f;
+    for (int i = lane; i < d; i += 64) {
+        const float v = x[(long)row * d + i];
+        ss += v * v;
+        if (dy) dot += v * dy[(long)row * d + i];
+    }
+    ss = wave_sum(ss);
+    const float nrm = sqrtf(ss);
+    const float inv = 1.0f / fmaxf(nrm, eps);
+    if (!dy) {
+        for (int i = lane; i < d; i += 64) y[(long)row * d + i] = x[(long)row * d + i] * inv;
+    } else {
+        dot = wave_sum(dot);
+        // y = x/n: dx = dy/n - x * <x,dy>/n^3   (clamped branch nrm<eps: dx = dy/eps)
+        const float k = nrm > eps ? dot * inv * inv * inv : 0.f;
+        for (int i = lane; i < d; i += 64) y[(long)row * d + i] = dy[(long)row * d + i] * inv - x[(long)row * d + i] * k;
+    }
+}
+extern "C" int hs_l2norm_fwd(const float* x, float* y, int rows, int d, float eps, void* stream) {
+    if (!x || !y) return HS_ERR_ARG;
+    if (rows < 1 || d < 1) return HS_ERR_SHAPE;
+    hipLaunchKernelGGL(l2norm_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, (const float*)nullptr, y, rows, d, eps);
+    HS_CHECK_LAUNCH();
+    return HS_OK;
+}
+extern "C" int hs_l2norm_bwd(const float* x, const float* dy, float* dx, int rows, int d, float eps, void* stream) {
+    if (!x || !dy || !dx) return HS_ERR_ARG;
+    if (rows < 1 || d < 1) return HS_ERR_SHAPE;
+    hipLaunchKernelGGL(l2norm_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, dy, dx, rows, d, eps);
+    HS_CHECK_LAUNCH();
+    return HS_OK;
+}
+
+// torch.optim.AdamW semantics (decoupled weight decay, bias correction), one pass over a flat buffer
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, long n, float lr, float b1, float b2, float eps, float wd,
+                                                    float gs, float bc1, float bc2s) {
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    const int cnt = (int)min((long)4, n - i);
+    for (int e = 0; e < cnt; ++e) {
+        const float gr = g[i + e] * gs;
+        float pv = p[i + e] * (1.0f - lr * wd);
+        const float mv = b1 * m[i + e] + (1.0f - b1) * gr;
+        const float vv = b2 * v[i + e] + (1.0f - b2) * gr * gr;
+        m[i + e] = mv;
+        v[i + e] = vv;
+        pv -= (lr / bc1) * mv / (sqrtf(vv) / bc2s + eps);
+        p[i + e] = pv;
+    }
+}
+extern "C" int hs_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                        float weight_decay, float grad_scale, int step, void* stream) {
+    if (!p || !g || !m || !v) return HS_ERR_ARG;
+    if (n < 1 || step < 1) return HS_ERR_SHAPE;
+    const float bc1 = 1.0f - powf(beta1, (float)step);
+    const float bc2s = sqrtf(1.0f - powf(beta2, (float)step));
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, lr,
+                       beta1, beta2, eps, weight_decay, grad_scale, bc1, bc2s);
+    HS_CHECK_LAUNCH();
+    return HS_OK;
+}
+
+extern "C" int hs_version(void) { return 1; }
+extern "C" int hs_device_check(int dev) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return HS_ERR_ARCH;
+    const char* a = prop.gcnArchName;
+    return (a[0] == 'g' && a[1] == 'f' && a[2] == 'x' && a[3] == '9' && a[4] == '5' && a[5] == '0') ? HS_OK : HS_ERR_ARCH;
+}

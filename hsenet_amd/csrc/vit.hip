@@ -1,0 +1,222 @@
+// Fused encoder driver: the reference's hot loops `for blk in self.blocks: x = blk(x)` + `self.norm(x)`
+// (multimodal_encoder/vit.py:464-467 and 352-355) enqueued as one kernel sequence on one stream, forward and
+// backward.  Host-side only: it sequences the kernels of gemm.hip / attn.hip / norm.hip / small.hip.
+//
+// Per block (MONAI TransformerBlock, pre-LN):            kernels
+//   h1 = LN1(x)                                          layernorm_fwd (fp32 in, bf16 out, stats saved)
+//   qkv = h1 Wqkv^T                                      gemm NT -> bf16 [M][3d]
+//   o = softmax(q k^T / 8) v                             attn_fwd (flash, lse saved)
+//   xm = x + o Wo^T + bo                                 gemm NT, epilogue bias+residual -> fp32
+//   h2 = LN2(xm)                                         layernorm_fwd
+//   a = gelu(h2 W1^T + b1)                               gemm NT, epilogue bias+GELU -> bf16 (z saved)
+//   x' = xm + a W2^T + b2                                gemm NT, epilogue bias+residual -> fp32 (= hidden[l])
+// The residual stream (x, xm) is fp32 throughout, as under the reference's autocast policy.
+#include "common.h"
+
+namespace {
+
+struct Layout {
+    size_t wbf, xmid, h1, h2, qkv, o, lse, z, a, stats, fstats, dx, dh, dxb, dob, dz, dqkv, delta, total;
+    size_t per_w;  // bf16 weight elements per layer
+};
+
+inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
+
+Layout make_layout(const hs_vit_desc& c) {
+    Layout L;
+    const size_t M = (size_t)c.B * c.N, d = c.d, mlp = c.mlp;
+    const size_t Ls = c.save_for_bwd ? c.L : 1;
+    const size_t es = c.prec == HS_PREC_BF16 ? 2 : 4;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += al(bytes); return o; };
+    L.per_w = 3 * d * d + d * d + mlp * d + d * mlp;
+    L.wbf = take(c.prec == HS_PREC_BF16 ? (size_t)c.L * L.per_w * 2 : 0);
+    L.xmid = take(Ls * M * d * 4);
+    L.h1 = take(Ls * M * d * es);
+    L.h2 = take(Ls * M * d * es);
+    L.qkv = take(Ls * M * 3 * d * es);
+    L.o = take(Ls * M * d * es);
+    L.lse = take(Ls * (size_t)c.B * c.H * c.N * 4);
+    L.z = take(Ls * M * mlp * es);
+    L.a = take(Ls * M * mlp * es);
+    L.stats = take(Ls * 4 * M * 4);
+    L.fstats = take(2 * M * 4);
+    const bool bwd = c.save_for_bwd && c.prec == HS_PREC_BF16;
+    L.dx = take(bwd ? M * d * 4 : 0);
+    L.dh = take(bwd ? M * d * 4 : 0);
+    L.dxb = take(bwd ? M * d * 2 : 0);
+    L.dob = take(bwd ? M * d * 2 : 0);
+    L.dz = take(bwd ? M * mlp * 2 : 0);
+    L.dqkv = take(bwd ? M * 3 * d * 2 : 0);
+    L.delta = take(bwd ? (size_t)c.B * c.H * c.N * 4 : 0);
+    L.total = off;
+    return L;
+}
+
+int check_desc(const hs_vit_desc* c) {
+    if (!c) return HS_ERR_ARG;
+    if (c->B < 1 || c->N < 1 || c->L < 1 || c->H < 1) return HS_ERR_SHAPE;
+    if (c->d != c->H * 64) return HS_ERR_SHAPE;  // attention kernels are specialised for head_dim 64
+    if ((c->d & 7) || (c->mlp & 7) || c->d > 1024) return HS_ERR_SHAPE;
+    if (c->prec != HS_PREC_BF16 && c->prec != HS_PREC_F32) return HS_ERR_ARG;
+    return HS_OK;
+}
+
+// indices into the per-layer parameter list (MONAI state-dict order)
+enum { P_W1 = 0, P_B1, P_W2, P_B2, P_N1W, P_N1B, P_WO, P_BO, P_WQKV, P_N2W, P_N2B, P_COUNT };
+
+int gemm(int prec, int layout, const void* A, const void* Bm, int M, int N, int K, long lda, long ldb, float* of32, void* obf,
+         long ldc, const float* bias, const float* resid, const void* aux, void* aux_out, int flags, int split_k, void* s) {
+    hs_gemm_args g = {};
+    g.A = A; g.B = Bm; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.batch = 1;
+    g.out_f32 = of32; g.out_bf16 = obf; g.ldc = ldc; g.bias = bias; g.resid = resid; g.aux = aux; g.aux_out = aux_out;
+    g.alpha = 1.0f; g.flags = flags; g.layout = layout; g.split_k = split_k;
+    return hs_gemm(&g, prec, s);
+}
+
+// split-K factor for a wgrad whose output has `tiles` 128x128 tiles and `K` reduction rows
+int wgrad_split(int Mo, int No, int K) {
+    const int tiles = ((Mo + 127) / 128) * ((No + 127) / 128);
+    const int kt = (K + 63) / 64;
+    int s = (768 + tiles - 1) / tiles;
+    if (s > kt / 2) s = kt / 2;
+    if (s < 1) s = 1;
+    return s;
+}
+
+#define RC(x) do { int rc__ = (x); if (rc__ != HS_OK) return rc__; } while (0)
+
+}  // namespace
+
+extern "C" size_t hs_vit_workspace_bytes(const hs_vit_desc* desc) {
+    if (check_desc(desc) != HS_OK) return 0;
+    return make_layout(*desc).total;
+}
+
+extern "C" int hs_vit_blocks_fwd(const hs_vit_desc* desc, const float* x0, const float* const* lp, const float* const* np,
+                                 float* y, float* hidden, void* ws, size_t ws_bytes, void* stream) {
+    RC(check_desc(desc));
+    if (!x0 || !lp || !np || !y || !hidden || !ws) return HS_ERR_ARG;
+    const hs_vit_desc& c = *desc;
+    const Layout L = make_layout(c);
+    if (ws_bytes < L.total || ((uintptr_t)ws & 255)) return HS_ERR_SHAPE;
+    char* w = (char*)ws;
+    const int M = c.B * c.N, d = c.d, mlp = c.mlp;
+    const size_t Md = (size_t)M * d;
+    const bool bf = c.prec == HS_PREC_BF16;
+    const size_t es = bf ? 2 : 4;
+
+    if (bf) {
+        for (int l = 0; l < c.L; ++l) {
+            bf16_t* wl = (bf16_t*)(w + L.wbf) + (size_t)l * L.per_w;
+            const float* const* p = lp + (size_t)l * P_COUNT;
+            RC(hs_cast_bf16(p[P_WQKV], wl, (int64_t)3 * d * d, stream));
+            RC(hs_cast_bf16(p[P_WO], wl + 3 * d * d, (int64_t)d * d, stream));
+            RC(hs_cast_bf16(p[P_W1], wl + 4 * d * d, (int64_t)mlp * d, stream));
+            RC(hs_cast_bf16(p[P_W2], wl + 4 * d * d + (size_t)mlp * d, (int64_t)d * mlp, stream));
+        }
+    }
+    for (int l = 0; l < c.L; ++l) {
+        const size_t ls = c.save_for_bwd ? l : 0;
+        const float* const* p = lp + (size_t)l * P_COUNT;
+        const float* xin = l == 0 ? x0 : hidden + (size_t)(l - 1) * Md;
+        float* xout = hidden + (size_t)l * Md;
+        float* xmid = (float*)(w + L.xmid) + ls * Md;
+        char* h1 = w + L.h1 + ls * Md * es;
+        char* h2 = w + L.h2 + ls * Md * es;
+        char* qkv = w + L.qkv + ls * Md * 3 * es;
+        char* o = w + L.o + ls * Md * es;
+        float* lse = (float*)(w + L.lse) + ls * (size_t)c.B * c.H * c.N;
+        char* z = w + L.z + ls * (size_t)M * mlp * es;
+        char* a = w + L.a + ls * (size_t)M * mlp * es;
+        float* st = (float*)(w + L.stats) + ls * 4 * (size_t)M;
+        const void *wqkv, *wo, *w1, *w2;
+        if (bf) {
+            const bf16_t* wl = (const bf16_t*)(w + L.wbf) + (size_t)l * L.per_w;
+            wqkv = wl; wo = wl + 3 * d * d; w1 = wl + 4 * d * d; w2 = wl + 4 * d * d + (size_t)mlp * d;
+        } else {
+            wqkv = p[P_WQKV]; wo = p[P_WO]; w1 = p[P_W1]; w2 = p[P_W2];
+        }
+        RC(hs_layernorm_fwd(xin, nullptr, p[P_N1W], p[P_N1B], bf ? nullptr : (float*)h1, bf ? h1 : nullptr, st, st + M, M, d, 1e-5f, stream));
+        RC(gemm(c.prec, HS_GEMM_NT, h1, wqkv, M, 3 * d, d, d, d, bf ? nullptr : (float*)qkv, bf ? qkv : nullptr, 3 * d, nullptr, nullptr,
+                nullptr, nullptr, 0, 1, stream));
+        RC(hs_attn_fwd(qkv, o, lse, c.B, c.N, c.H, 64, c.prec, stream));
+        RC(gemm(c.prec, HS_GEMM_NT, o, wo, M, d, d, d, d, xmid, nullptr, d, p[P_BO], xin, nullptr, nullptr, HS_EPI_BIAS | HS_EPI_RESID, 1, stream));
+        RC(hs_layernorm_fwd(xmid, nullptr, p[P_N2W], p[P_N2B], bf ? nullptr : (float*)h2, bf ? h2 : nullptr, st + 2 * M, st + 3 * M, M, d, 1e-5f, stream));
+        RC(gemm(c.prec, HS_GEMM_NT, h2, w1, M, mlp, d, d, d, bf ? nullptr : (float*)a, bf ? a : nullptr, mlp, p[P_B1], nullptr, nullptr,
+                c.save_for_bwd ? z : nullptr, HS_EPI_BIAS | HS_EPI_GELU, 1, stream));
+        RC(gemm(c.prec, HS_GEMM_NT, a, w2, M, d, mlp, mlp, mlp, xout, nullptr, d, p[P_B2], xmid, nullptr, nullptr, HS_EPI_BIAS | HS_EPI_RESID, 1, stream));
+    }
+    float* fs = (float*)(w + L.fstats);
+    RC(hs_layernorm_fwd(hidden + (size_t)(c.L - 1) * Md, nullptr, np[0], np[1], y, nullptr, fs, fs + M, M, d, 1e-5f, stream));
+    return HS_OK;
+}
+
+extern "C" int hs_vit_blocks_bwd(const hs_vit_desc* desc, const float* x0, const float* const* lp, const float* const* np,
+                                 const float* dy, float* dx0, float* const* lg, float* const* ng, const float* hidden, void* ws,
+                                 size_t ws_bytes, int l_hi, int l_lo, void* stream) {
+    RC(check_desc(desc));
+    const hs_vit_desc& c = *desc;
+    if (c.prec != HS_PREC_BF16 || !c.save_for_bwd) return HS_ERR_ARG;
+    if (!x0 || !lp || !np || !lg || !hidden || !ws) return HS_ERR_ARG;
+    if (l_lo < 0 || l_hi > c.L || l_lo >= l_hi) return HS_ERR_SHAPE;
+    if (l_hi == c.L && (!dy || !ng)) return HS_ERR_ARG;
+    if (l_lo == 0 && !dx0) return HS_ERR_ARG;
+    const Layout L = make_layout(c);
+    if (ws_bytes < L.total || ((uintptr_t)ws & 255)) return HS_ERR_SHAPE;
+    char* w = (char*)ws;
+    const int M = c.B * c.N, d = c.d, mlp = c.mlp;
+    const size_t Md = (size_t)M * d;
+    float* dx = (float*)(w + L.dx);
+    float* dh = (float*)(w + L.dh);
+    bf16_t* dxb = (bf16_t*)(w + L.dxb);
+    bf16_t* dob = (bf16_t*)(w + L.dob);
+    bf16_t* dz = (bf16_t*)(w + L.dz);
+    bf16_t* dqkv = (bf16_t*)(w + L.dqkv);
+    float* delta = (float*)(w + L.delta);
+    const int P = HS_PREC_BF16;
+
+    if (l_hi == c.L) {
+        const float* fs = (const float*)(w + L.fstats);
+        RC(hs_layernorm_bwd(dy, hidden + (size_t)(c.L - 1) * Md, nullptr, np[0], fs, fs + M, nullptr, dx, dxb, ng[0], ng[1], M, d, stream));
+    }
+    for (int l = l_hi - 1; l >= l_lo; --l) {
+        const float* const* p = lp + (size_t)l * P_COUNT;
+        float* const* g = lg + (size_t)l * P_COUNT;
+        const float* xin = l == 0 ? x0 : hidden + (size_t)(l - 1) * Md;
+        const float* xmid = (const float*)(w + L.xmid) + (size_t)l * Md;
+        const bf16_t* h1 = (const bf16_t*)(w + L.h1) + (size_t)l * Md;
+        const bf16_t* h2 = (const bf16_t*)(w + L.h2) + (size_t)l * Md;
+        const bf16_t* qkv = (const bf16_t*)(w + L.qkv) + (size_t)l * Md * 3;
+        const bf16_t* o = (const bf16_t*)(w + L.o) + (size_t)l * Md;
+        const float* lse = (const float*)(w + L.lse) + (size_t)l * c.B * c.H * c.N;
+        const bf16_t* z = (const bf16_t*)(w + L.z) + (size_t)l * M * mlp;
+        const bf16_t* a = (const bf16_t*)(w + L.a) + (size_t)l * M * mlp;
+        const float* st = (const float*)(w + L.stats) + (size_t)l * 4 * M;
+        const bf16_t* wl = (const bf16_t*)(w + L.wbf) + (size_t)l * L.per_w;
+        const bf16_t *wqkv = wl, *wo = wl + 3 * d * d, *w1 = wl + 4 * d * d, *w2 = wl + 4 * d * d + (size_t)mlp * d;
+
+        // ---- MLP branch: x' = xm + W2 gelu(W1 h2 + b1) + b2
+        RC(hs_colsum(dxb, 1, g[P_B2], M, d, d, stream));
+        RC(gemm(P, HS_GEMM_TN, dxb, a, d, mlp, M, d, mlp, g[P_W2], nullptr, mlp, nullptr, nullptr, nullptr, nullptr, HS_EPI_ATOMIC,
+                wgrad_split(d, mlp, M), stream));
+        RC(gemm(P, HS_GEMM_NN, dxb, w2, M, mlp, d, d, mlp, nullptr, dz, mlp, nullptr, nullptr, z, nullptr, HS_EPI_GELU_BWD, 1, stream));
+        RC(hs_colsum(dz, 1, g[P_B1], M, mlp, mlp, stream));
+        RC(gemm(P, HS_GEMM_TN, dz, h2, mlp, d, M, mlp, d, g[P_W1], nullptr, d, nullptr, nullptr, nullptr, nullptr, HS_EPI_ATOMIC,
+                wgrad_split(mlp, d, M), stream));
+        RC(gemm(P, HS_GEMM_NN, dz, w1, M, d, mlp, mlp, d, dh, nullptr, d, nullptr, nullptr, nullptr, nullptr, 0, 1, stream));
+        RC(hs_layernorm_bwd(dh, xmid, nullptr, p[P_N2W], st + 2 * M, st + 3 * M, dx, dx, dxb, g[P_N2W], g[P_N2B], M, d, stream));
+        // ---- attention branch: xm = x + Wo attn(LN1 x) + bo
+        RC(hs_colsum(dxb, 1, g[P_BO], M, d, d, stream));
+        RC(gemm(P, HS_GEMM_TN, dxb, o, d, d, M, d, d, g[P_WO], nullptr, d, nullptr, nullptr, nullptr, nullptr, HS_EPI_ATOMIC,
+                wgrad_split(d, d, M), stream));
+        RC(gemm(P, HS_GEMM_NN, dxb, wo, M, d, d, d, d, nullptr, dob, d, nullptr, nullptr, nullptr, nullptr, 0, 1, stream));
+        RC(hs_attn_bwd(qkv, o, dob, lse, dqkv, delta, c.B, c.N, c.H, 64, stream));
+        RC(gemm(P, HS_GEMM_TN, dqkv, h1, 3 * d, d, M, 3 * d, d, g[P_WQKV], nullptr, d, nullptr, nullptr, nullptr, nullptr, HS_EPI_ATOMIC,
+                wgrad_split(3 * d, d, M), stream));
+        RC(gemm(P, HS_GEMM_NN, dqkv, wqkv, M, d, 3 * d, 3 * d, d, dh, nullptr, d, nullptr, nullptr, nullptr, nullptr, 0, 1, stream));
+        float* dxo = (l == 0) ? dx0 : dx;
+        RC(hs_layernorm_bwd(dh, xin, nullptr, p[P_N1W], st, st + M, dx, dxo, l == 0 ? nullptr : dxb, g[P_N1W], g[P_N1B], M, d, stream));
+    }
+    return HS_OK;
+}

@@ -1,0 +1,298 @@
+"""MI355X host mirror of the reference's LaMed 3D vision-encoder API
+(Preprint/LaMed/src/model/multimodal_encoder/{vit.py,builder.py}).
+
+Same class names, constructor signatures, forward signatures, return tuples, error behaviour and —
+load-bearing for train_VLM.py:477-503's positional checkpoint copy — the same ``state_dict()`` keys IN THE
+SAME ORDER (138 tensors for ViT_stage1, 150 for ViT_stage2).  The modules only *hold* parameters
+(``nn.Linear`` / ``nn.LayerNorm`` objects are containers here, their ``forward`` is never called); all
+arithmetic runs in libhsenet_hip.so through hsenet_amd.functional.  There is no CPU path: calling a module
+with CPU tensors raises.
+
+Dropout: MONAI blocks are built with dropout_rate=0.0 on this path (no-ops).  ``regular_attention`` hard-codes
+p=0.1 dropouts that fire in train() mode in the reference (vit.py:46-47); this implementation computes the
+eval-mode (deterministic) function in both modes — see DESIGN.md "Dropout".
+"""
+from __future__ import annotations
+
+from collections.abc import Sequence
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import functional as Fn
+from ._lib import PREC_BF16, PREC_F32
+
+
+def _prec(module) -> int:
+    p = getattr(module, "precision", None) or Fn.get_precision()
+    return {"bf16": PREC_BF16, "f32": PREC_F32}[p]
+
+
+class _Rearrange(nn.Module):
+    """Parameter-free placeholder at index 0 of ``patch_embeddings`` so the Linear keeps MONAI's key
+    ``patch_embeddings.1.*``; the rearrange itself is the hs_patchify kernel."""
+
+    def __init__(self, patch_size):
+        super().__init__()
+        self.patch_size = tuple(patch_size)
+
+
+class PatchEmbeddingBlock(nn.Module):
+    """MONAI 1.3.0 PatchEmbeddingBlock with pos_embed='perceptron' (reference ctor call vit.py:428-437)."""
+
+    def __init__(self, in_channels, img_size, patch_size, hidden_size, num_heads, pos_embed="perceptron",
+                 dropout_rate=0.0, spatial_dims=3):
+        super().__init__()
+        if not (0 <= dropout_rate <= 1):
+            raise ValueError("dropout_rate should be between 0 and 1.")
+        if hidden_size % num_heads != 0:
+            raise ValueError("hidden size should be divisible by num_heads.")
+        if pos_embed != "perceptron":
+            raise ValueError(f"pos_embed={pos_embed!r}: only 'perceptron' is on the HSENet hot path (vit.py:895-924)")
+        if spatial_dims != 3:
+            raise ValueError("only 3-D volumes are supported")
+        img_size = tuple(img_size) if isinstance(img_size, Sequence) else (img_size,) * 3
+        patch_size = tuple(patch_size) if isinstance(patch_size, Sequence) else (patch_size,) * 3
+        for m, p in zip(img_size, patch_size):
+            if m < p:
+                raise ValueError("patch_size should be smaller than img_size.")
+            if m % p != 0:
+                raise ValueError("patch_size should be divisible by img_size for perceptron.")
+        self.img_size, self.patch_size = img_size, patch_size
+        self.n_patches = int(np.prod([i // p for i, p in zip(img_size, patch_size)]))
+        self.patch_dim = int(in_channels * np.prod(patch_size))
+        self.patch_embeddings = nn.Sequential(_Rearrange(patch_size), nn.Linear(self.patch_dim, hidden_size))
+        self.position_embeddings = nn.Parameter(torch.zeros(1, self.n_patches, hidden_size))
+        self.dropout = nn.Dropout(dropout_rate)
+        nn.init.trunc_normal_(self.position_embeddings, mean=0.0, std=0.02, a=-2.0, b=2.0)
+        nn.init.trunc_normal_(self.patch_embeddings[1].weight, mean=0.0, std=0.02, a=-2.0, b=2.0)
+        nn.init.zeros_(self.patch_embeddings[1].bias)
+
+
+class MLPBlock(nn.Module):
+    def __init__(self, hidden_size, mlp_dim, dropout_rate=0.0):
+        super().__init__()
+        self.linear1 = nn.Linear(hidden_size, mlp_dim)
+        self.linear2 = nn.Linear(mlp_dim, hidden_size)
+
+
+class SABlock(nn.Module):
+    def __init__(self, hidden_size, num_heads, dropout_rate=0.0, qkv_bias=False, save_attn=False):
+        super().__init__()
+        self.out_proj = nn.Linear(hidden_size, hidden_size)
+        self.qkv = nn.Linear(hidden_size, hidden_size * 3, bias=qkv_bias)
+        self.num_heads = num_heads
+
+
+class TransformerBlock(nn.Module):
+    """MONAI TransformerBlock parameter container; registration order mlp, norm1, attn, norm2."""
+
+    def __init__(self, hidden_size, mlp_dim, num_heads, dropout_rate=0.0, qkv_bias=False, save_attn=False):
+        super().__init__()
+        if not (0 <= dropout_rate <= 1):
+            raise ValueError("dropout_rate should be between 0 and 1.")
+        if hidden_size % num_heads != 0:
+            raise ValueError("hidden_size should be divisible by num_heads.")
+        if qkv_bias:
+            raise ValueError("qkv_bias=True is not on the HSENet hot path (vit.py:440 passes False)")
+        if dropout_rate != 0.0:
+            raise ValueError("dropout_rate must be 0.0 (the reference builds its blocks with 0.0, CLIP_stage1.py:30)")
+        self.mlp = MLPBlock(hidden_size, mlp_dim, dropout_rate)
+        self.norm1 = nn.LayerNorm(hidden_size)
+        self.attn = SABlock(hidden_size, num_heads, dropout_rate, qkv_bias, save_attn)
+        self.norm2 = nn.LayerNorm(hidden_size)
+
+    def ordered_params(self):
+        return [self.mlp.linear1.weight, self.mlp.linear1.bias, self.mlp.linear2.weight, self.mlp.linear2.bias,
+                self.norm1.weight, self.norm1.bias, self.attn.out_proj.weight, self.attn.out_proj.bias,
+                self.attn.qkv.weight, self.norm2.weight, self.norm2.bias]
+
+
+class regular_attention(nn.Module):
+    """vit.py:36-64 — single-head cross-attention used as the slice-guided scorer of the 2E3 encoder."""
+
+    def __init__(self, in_channels=16, out_channels=8, emb_dim=768, output_dim=768, dropout=0.1, aropout=0.0):
+        super().__init__()
+        self.emb_dim = emb_dim
+        self.Wq = nn.Linear(emb_dim, emb_dim)
+        self.Wk = nn.Linear(emb_dim, emb_dim)
+        self.Wv = nn.Linear(emb_dim, emb_dim)
+        self.attn = None
+        self.output_linear = nn.Linear(emb_dim, emb_dim)
+        self.dropout = nn.Dropout(p=dropout)
+        self.dropout_2 = nn.Dropout(p=dropout)
+        self.norm = nn.LayerNorm(emb_dim)
+
+    def forward(self, Query, Key, Value, context=None, mask=None):
+        if mask is not None:
+            raise ValueError("mask is never passed on the HSENet path (vit.py:335)")
+        prec = _prec(self)
+        q = Fn.LinearFn.apply(Query, self.Wq.weight, self.Wq.bias, prec)
+        k = Fn.LinearFn.apply(Key, self.Wk.weight, self.Wk.bias, prec)
+        v = Fn.LinearFn.apply(Value, self.Wv.weight, self.Wv.bias, prec)
+        x, self.attn = Fn.CrossAttnFn.apply(q, k, v)
+        x = Fn.LinearFn.apply(x, self.output_linear.weight, self.output_linear.bias, prec)
+        x = Fn.LayerNormFn.apply(q, x, self.norm.weight, self.norm.bias, self.norm.eps)
+        return x, self.attn
+
+
+class _ViTBase(nn.Module):
+    def _build(self, in_channels, img_size, patch_size, hidden_size, mlp_dim, num_layers, num_heads, pos_embed,
+               classification, dropout_rate, spatial_dims, qkv_bias, save_attn):
+        if not (0 <= dropout_rate <= 1):
+            raise ValueError("dropout_rate should be between 0 and 1.")
+        if hidden_size % num_heads != 0:
+            raise ValueError("hidden_size should be divisible by num_heads.")
+        if hidden_size // num_heads != 64:
+            raise ValueError("the MI355X attention kernels are specialised for head_dim 64 (ViT-B 768/12, ViT-S 384/6)")
+        self.hidden_size = hidden_size
+        self.mlp_dim = mlp_dim
+        self.num_heads = num_heads
+        self.classification = classification
+        self.patch_embedding = PatchEmbeddingBlock(in_channels, img_size, patch_size, hidden_size, num_heads, pos_embed,
+                                                   dropout_rate, spatial_dims)
+        self.blocks = nn.ModuleList([TransformerBlock(hidden_size, mlp_dim, num_heads, dropout_rate, qkv_bias, save_attn)
+                                     for _ in range(num_layers)])
+
+    def _embed(self, x, prec):
+        pe = self.patch_embedding
+        lin = pe.patch_embeddings[1]
+        if tuple(x.shape[2:]) != pe.img_size:
+            raise ValueError(f"input volume {tuple(x.shape[2:])} does not match img_size {pe.img_size}")
+        return Fn.PatchEmbedFn.apply(x, lin.weight, lin.bias, pe.patch_size, prec)
+
+    def _stack(self, tokens, prec):
+        params = [p for blk in self.blocks for p in blk.ordered_params()] + [self.norm.weight, self.norm.bias]
+        y, hidden = Fn.BlocksFn.apply(tokens, self.num_heads, self.mlp_dim, prec, *params)
+        return y, [hidden[i] for i in range(hidden.shape[0])]
+
+
+class ViT_stage1(_ViTBase):
+    """vit.py:360-469 — the 3D-ViT encoder.  forward(x) -> (tokens [B,N,d] after `norm`, [hidden states])."""
+
+    def __init__(self, in_channels: int, img_size, patch_size, hidden_size: int = 768, mlp_dim: int = 3072,
+                 num_layers: int = 12, num_heads: int = 12, pos_embed: str = "conv", classification: bool = False,
+                 num_classes: int = 2, dropout_rate: float = 0.0, spatial_dims: int = 3, post_activation="Tanh",
+                 qkv_bias: bool = False, save_attn: bool = False) -> None:
+        super().__init__()
+        self._build(in_channels, img_size, patch_size, hidden_size, mlp_dim, num_layers, num_heads, pos_embed,
+                    classification, dropout_rate, spatial_dims, qkv_bias, save_attn)
+        self.norm = nn.LayerNorm(hidden_size)
+        if self.classification:
+            self.cls_token = nn.Parameter(torch.zeros(1, 1, hidden_size))
+
+    def forward(self, x, k=None, visual_encoder_2D=None, text_features=None, image_path=None):
+        prec = _prec(self)
+        pe = self._embed(x, prec)
+        cls = self.cls_token if hasattr(self, "cls_token") else None
+        tokens, _ = Fn.AssembleFn.apply(pe, self.patch_embedding.position_embeddings, cls, None)
+        return self._stack(tokens, prec)
+
+
+class ViT_stage2(_ViTBase):
+    """vit.py:222-357 — the 2D-enhanced "2E3" encoder: patch tokens are re-weighted by a slice-guided score
+    before the block stack.  forward(x, image_2d) -> (tokens, [hidden states])."""
+
+    def __init__(self, in_channels: int, img_size, patch_size, hidden_size: int = 768, mlp_dim: int = 3072,
+                 num_layers: int = 12, num_heads: int = 12, pos_embed: str = "conv", classification: bool = False,
+                 num_classes: int = 2, dropout_rate: float = 0.0, spatial_dims: int = 3, post_activation="Tanh",
+                 qkv_bias: bool = False, save_attn: bool = False) -> None:
+        super().__init__()
+        self._build(in_channels, img_size, patch_size, hidden_size, mlp_dim, num_layers, num_heads, pos_embed,
+                    classification, dropout_rate, spatial_dims, qkv_bias, save_attn)
+        self.patch_score_proj = nn.Linear(hidden_size, 1)
+        self.patch_score_norm = nn.Sigmoid()
+        self.slice_guided_attention = regular_attention()
+        self.norm = nn.LayerNorm(hidden_size)
+        if self.classification:
+            self.cls_token = nn.Parameter(torch.zeros(1, 1, hidden_size))
+
+    def forward(self, x, image_2d, k=None, visual_encoder_2D=None, text_features=None, image_path=None):
+        prec = _prec(self)
+        batch = x.size(0)
+        pe = self._embed(x, prec)
+        pos = self.patch_embedding.position_embeddings
+        cls = self.cls_token if hasattr(self, "cls_token") else None
+        xe = _PosAdd.apply(pe, pos)                   # x = patch_embedding(x): embedding + position (vit.py:325)
+        sem = image_2d.to(x.device).view(batch, 32, -1)                                   # vit.py:332
+        patch_score, _ = self.slice_guided_attention(xe, sem, sem)                         # vit.py:335
+        score = Fn.RowdotSigmoidFn.apply(patch_score, self.patch_score_proj.weight, self.patch_score_proj.bias)  # :338-339
+        tokens, _ = Fn.AssembleFn.apply(pe, pos, cls, score)                               # :345-349
+        return self._stack(tokens, prec)
+
+
+class _PosAdd(torch.autograd.Function):
+    """pe + position_embeddings as a differentiable op (the scorer's Query input, vit.py:325,335)."""
+
+    @staticmethod
+    def forward(ctx, pe, pos):
+        B, Np, d = pe.shape
+        out = torch.empty_like(pe)
+        Fn.L.call("hs_assemble_tokens", pe.contiguous().data_ptr(), pos.data_ptr(), None, None, out.data_ptr(), None, B, Np, d, Fn._s())
+        ctx.shape = pos.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = dout.contiguous()
+        B, Np, d = dout.shape
+        dpos = torch.zeros(ctx.shape, dtype=torch.float32, device=dout.device)
+        Fn.L.call("hs_assemble_tokens_bwd", dout.data_ptr(), None, None, None, dpos.data_ptr(), None, None, B, Np, d, Fn._s())
+        return dout, dpos
+
+
+class ViT3DTower_dual_encoders(nn.Module):
+    """vit.py:891-960 — runs the 3D-ViT then the 2E3-ViT on the same volume."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.select_layer = config.vision_select_layer
+        self.select_feature = config.vision_select_feature
+        self.remain_2d3d_ViT_type = getattr(config, "remain_2d3d_ViT_type", "dual_vits")
+        kw = dict(in_channels=self.config.image_channel, img_size=self.config.image_size, patch_size=self.config.patch_size,
+                  pos_embed="perceptron", spatial_dims=len(self.config.patch_size), classification=True)
+        self.vision_tower_stage1 = ViT_stage1(**kw)
+        self.vision_tower_stage2 = ViT_stage2(**kw)
+
+    def forward(self, images, images_2d):
+        f1, _ = self.vision_tower_stage1(images)
+        f2, _ = self.vision_tower_stage2(images, images_2d)
+        if self.select_feature == "patch":
+            f1, f2 = f1[:, 1:], f2[:, 1:]
+        elif self.select_feature == "cls_patch":
+            pass
+        else:
+            raise ValueError(f"Unexpected select feature: {self.select_feature}")
+        if self.remain_2d3d_ViT_type == "dual_vits":
+            return f1, f2
+        elif self.remain_2d3d_ViT_type == "3d_vit":
+            return f1
+        elif self.remain_2d3d_ViT_type == "2e3_vit":
+            return f2
+
+    @property
+    def dtype(self):
+        return self.vision_tower_stage1.norm.weight.dtype
+
+    @property
+    def device(self):
+        return self.vision_tower_stage1.norm.weight.device
+
+    @property
+    def hidden_size(self):
+        return self.vision_tower_stage1.hidden_size
+
+
+def build_vision_tower(config, **kwargs):
+    """multimodal_encoder/builder.py:4-11.  The legacy single-encoder 'vit3d' towers are ablations outside the
+    hot path and are not provided."""
+    vision_tower = getattr(config, "vision_tower", None)
+    if "vit_stage2_dual_encoders" in vision_tower.lower():
+        return ViT3DTower_dual_encoders(config, **kwargs)
+    elif "vit3d" in vision_tower.lower():
+        raise ValueError("vision tower 'vit3d' (legacy single-encoder ablation) is outside the MI355X hot path; "
+                         "use 'vit_stage2_dual_encoders'")
+    else:
+        raise ValueError(f"Unknown vision tower: {vision_tower}")

@@ -1,0 +1,493 @@
+"""Tensor-level wrappers and autograd Functions over the C ABI (hsenet_amd/_lib.py).
+
+torch is plumbing here (device memory, streams, autograd graph); all arithmetic runs in libhsenet_hip.so.
+Every entry point requires CUDA(ROCm) tensors and raises otherwise — there is no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib as L
+
+_PREC = {"bf16": L.PREC_BF16, "f32": L.PREC_F32}
+_default_precision = "bf16"
+
+
+def set_precision(p: str) -> None:
+    """'bf16' (default; the reference's autocast policy: bf16 MFMA inputs, fp32 accumulate/residual) or
+    'f32' (exact-f32 MFMA parity mode, forward-only for the block stack)."""
+    global _default_precision
+    if p not in _PREC:
+        raise ValueError(f"precision must be one of {list(_PREC)}")
+    _default_precision = p
+
+
+def get_precision() -> str:
+    return _default_precision
+
+
+def _s() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _need(*ts: Optional[torch.Tensor]) -> None:
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise L.HsError("hsenet_amd kernels need tensors on an MI355X ('cuda') device; there is no CPU fallback")
+        if not t.is_contiguous():
+            raise L.HsError("hsenet_amd kernels need contiguous tensors")
+
+
+def _f32(t: torch.Tensor) -> torch.Tensor:
+    return t if t.dtype == torch.float32 else t.float()
+
+
+# ----------------------------------------------------------------------------------------------------
+# raw ops
+# ----------------------------------------------------------------------------------------------------
+def gemm(A: torch.Tensor, Bm: torch.Tensor, layout: int, *, prec: int, out_f32: Optional[torch.Tensor] = None,
+         out_bf16: Optional[torch.Tensor] = None, bias=None, resid=None, aux=None, aux_out=None, alpha: float = 1.0,
+         flags: int = 0, split_k: int = 1) -> None:
+    """C[M,N] = sum_k A(m,k) B(n,k); 2-D or batched 3-D operands (see include/hsenet_hip.h)."""
+    _need(A, Bm, out_f32, out_bf16, bias, resid, aux, aux_out)
+    want = torch.bfloat16 if prec == L.PREC_BF16 else torch.float32
+    if A.dtype != want or Bm.dtype != want:
+        raise L.HsError(f"gemm operands must be {want}")
+    batch = A.shape[0] if A.dim() == 3 else 1
+    a2, b2 = A.shape[-2:], Bm.shape[-2:]
+    if layout == L.GEMM_NT:
+        M, K, N, K2 = a2[0], a2[1], b2[0], b2[1]
+    elif layout == L.GEMM_NN:
+        M, K, K2, N = a2[0], a2[1], b2[0], b2[1]
+    else:
+        K, M, K2, N = a2[0], a2[1], b2[0], b2[1]
+    if K != K2:
+        raise L.HsError(f"gemm inner dims differ: {K} vs {K2}")
+    out = out_f32 if out_f32 is not None else out_bf16
+    if out is None or tuple(out.shape[-2:]) != (M, N):
+        raise L.HsError("gemm output shape mismatch")
+    g = L.GemmArgs()
+    g.A, g.B, g.M, g.N, g.K = A.data_ptr(), Bm.data_ptr(), M, N, K
+    g.lda, g.ldb, g.batch = a2[1], b2[1], batch
+    g.strideA = a2[0] * a2[1] if A.dim() == 3 else 0
+    g.strideB = b2[0] * b2[1] if Bm.dim() == 3 else 0
+    g.strideC = M * N
+    g.out_f32, g.out_bf16, g.ldc = _p(out_f32), _p(out_bf16), N
+    g.bias, g.resid, g.aux, g.aux_out = _p(bias), _p(resid), _p(aux), _p(aux_out)
+    g.alpha, g.flags, g.layout, g.split_k = alpha, flags, layout, split_k
+    L.call("hs_gemm", C.byref(g), prec, _s())
+
+
+def cast_bf16(x: torch.Tensor) -> torch.Tensor:
+    _need(x)
+    y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    L.call("hs_cast_bf16", x.data_ptr(), y.data_ptr(), x.numel(), _s())
+    return y
+
+
+def cast_f32(x: torch.Tensor) -> torch.Tensor:
+    _need(x)
+    y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    L.call("hs_cast_f32", x.data_ptr(), y.data_ptr(), x.numel(), _s())
+    return y
+
+
+def colsum(x: torch.Tensor, out: torch.Tensor) -> None:
+    """out[n] += sum_m x[m, n] (x 2-D bf16 or fp32)."""
+    _need(x, out)
+    L.call("hs_colsum", x.data_ptr(), int(x.dtype == torch.bfloat16), out.data_ptr(), x.shape[0], x.shape[1], x.shape[1], _s())
+
+
+def _wgrad_split(Mo: int, No: int, K: int, tile: int = 128, kt: int = 64) -> int:
+    tiles = ((Mo + tile - 1) // tile) * ((No + tile - 1) // tile)
+    return max(1, min((K + kt - 1) // kt // 2, (768 + tiles - 1) // tiles))
+
+
+def attn_fwd(qkv: torch.Tensor, H: int, prec: int):
+    """qkv [B,N,3*H*64] -> (o [B,N,H*64], lse [B,H,N])."""
+    _need(qkv)
+    B, N, D3 = qkv.shape
+    o = torch.empty(B, N, D3 // 3, dtype=qkv.dtype, device=qkv.device)
+    lse = torch.empty(B, H, N, dtype=torch.float32, device=qkv.device)
+    L.call("hs_attn_fwd", qkv.data_ptr(), o.data_ptr(), lse.data_ptr(), B, N, H, 64, prec, _s())
+    return o, lse
+
+
+def attn_bwd(qkv, o, d_o, lse, H: int):
+    _need(qkv, o, d_o, lse)
+    B, N, _ = qkv.shape
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty(B, H, N, dtype=torch.float32, device=qkv.device)
+    L.call("hs_attn_bwd", qkv.data_ptr(), o.data_ptr(), d_o.data_ptr(), lse.data_ptr(), dqkv.data_ptr(), delta.data_ptr(),
+           B, N, H, 64, _s())
+    return dqkv
+
+
+def layernorm_fwd(x, gamma, beta, *, resid=None, want_f32=True, want_bf16=False, eps=1e-5):
+    _need(x, gamma, beta, resid)
+    rows, d = x.numel() // x.shape[-1], x.shape[-1]
+    y = torch.empty_like(x) if want_f32 else None
+    yb = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if want_bf16 else None
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty_like(mean)
+    L.call("hs_layernorm_fwd", x.data_ptr(), _p(resid), gamma.data_ptr(), beta.data_ptr(), _p(y), _p(yb), mean.data_ptr(),
+           rstd.data_ptr(), rows, d, eps, _s())
+    return y, yb, mean, rstd
+
+
+def adamw_step(p, g, m, v, *, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, grad_scale=1.0, step=1) -> None:
+    _need(p, g, m, v)
+    L.call("hs_adamw", p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, betas[0], betas[1], eps,
+           weight_decay, grad_scale, step, _s())
+
+
+# ----------------------------------------------------------------------------------------------------
+# autograd Functions (each mirrors one reference operator; file:line in the docstrings)
+# ----------------------------------------------------------------------------------------------------
+class LinearFn(torch.autograd.Function):
+    """nn.Linear (y = x W^T + b) on the MFMA GEMM; x fp32 [..., K] -> fp32 [..., N]."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, prec):
+        x = _f32(x).contiguous()
+        _need(x, weight, bias)
+        K, N = x.shape[-1], weight.shape[0]
+        x2 = x.view(-1, K)
+        y = torch.empty(x2.shape[0], N, dtype=torch.float32, device=x.device)
+        if prec == L.PREC_BF16:
+            xa, wa = cast_bf16(x2), cast_bf16(weight)
+        else:
+            xa, wa = x2, weight.contiguous()
+        gemm(xa, wa, L.GEMM_NT, prec=prec, out_f32=y, bias=bias, flags=L.EPI_BIAS if bias is not None else 0)
+        ctx.save_for_backward(xa, wa)
+        ctx.prec, ctx.has_bias, ctx.xshape = prec, bias is not None, x.shape
+        return y.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xa, wa = ctx.saved_tensors
+        prec = ctx.prec
+        dy2 = _f32(dy).contiguous().view(-1, wa.shape[0])
+        dya = cast_bf16(dy2) if prec == L.PREC_BF16 else dy2
+        M, N, K = xa.shape[0], wa.shape[0], wa.shape[1]
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(M, K, dtype=torch.float32, device=dy.device)
+            gemm(dya, wa, L.GEMM_NN, prec=prec, out_f32=dx)
+            dx = dx.view(ctx.xshape)
+        if ctx.needs_input_grad[1]:
+            dw = torch.zeros(N, K, dtype=torch.float32, device=dy.device)
+            tile, kt = (128, 64) if prec == L.PREC_BF16 else (64, 32)
+            gemm(dya, xa, L.GEMM_TN, prec=prec, out_f32=dw, flags=L.EPI_ATOMIC, split_k=_wgrad_split(N, K, M, tile, kt))
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = torch.zeros(N, dtype=torch.float32, device=dy.device)
+            colsum(dya, db)
+        return dx, dw, db, None
+
+
+class LayerNormFn(torch.autograd.Function):
+    """nn.LayerNorm over the last dim of (x + resid) (vit.py:62: norm(query_list + x))."""
+
+    @staticmethod
+    def forward(ctx, x, resid, gamma, beta, eps):
+        x = _f32(x).contiguous()
+        resid = None if resid is None else _f32(resid).contiguous()
+        y, _, mean, rstd = layernorm_fwd(x, gamma, beta, resid=resid, eps=eps)
+        ctx.save_for_backward(x, resid, gamma, mean, rstd)
+        ctx.has_resid = resid is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, resid, gamma, mean, rstd = ctx.saved_tensors
+        dy = _f32(dy).contiguous()
+        _need(dy)
+        rows, d = x.numel() // x.shape[-1], x.shape[-1]
+        dx = torch.empty_like(x)
+        dg = torch.zeros_like(gamma)
+        db = torch.zeros_like(gamma)
+        L.call("hs_layernorm_bwd", dy.data_ptr(), x.data_ptr(), _p(resid), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+               None, dx.data_ptr(), None, dg.data_ptr(), db.data_ptr(), rows, d, _s())
+        return dx, (dx if ctx.has_resid else None), dg, db, None
+
+
+class GeluFn(torch.autograd.Function):
+    """nn.GELU() exact erf (spatial_pooling_projector.py:129)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _f32(x).contiguous()
+        _need(x)
+        y = torch.empty_like(x)
+        L.call("hs_gelu_fwd", x.data_ptr(), y.data_ptr(), x.numel(), _s())
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = _f32(dy).contiguous()
+        dx = torch.empty_like(x)
+        L.call("hs_gelu_bwd", x.data_ptr(), dy.data_ptr(), dx.data_ptr(), x.numel(), _s())
+        return dx
+
+
+class L2NormFn(torch.autograd.Function):
+    """F.normalize(x, dim=-1) (CLIP_stage1.py:101)."""
+
+    @staticmethod
+    def forward(ctx, x, eps):
+        x = _f32(x).contiguous()
+        _need(x)
+        y = torch.empty_like(x)
+        L.call("hs_l2norm_fwd", x.data_ptr(), y.data_ptr(), x.numel() // x.shape[-1], x.shape[-1], eps, _s())
+        ctx.save_for_backward(x)
+        ctx.eps = eps
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = _f32(dy).contiguous()
+        dx = torch.empty_like(x)
+        L.call("hs_l2norm_bwd", x.data_ptr(), dy.data_ptr(), dx.data_ptr(), x.numel() // x.shape[-1], x.shape[-1], ctx.eps, _s())
+        return dx, None
+
+
+class PatchEmbedFn(torch.autograd.Function):
+    """MONAI PatchEmbeddingBlock's rearrange + Linear (vit.py:428-437,455): vol [B,C,D,H,W] fp32 ->
+    [B, Np, hidden] fp32 (bias included, position embedding NOT — AssembleFn adds it)."""
+
+    @staticmethod
+    def forward(ctx, vol, weight, bias, patch_size, prec):
+        vol = _f32(vol).contiguous()
+        _need(vol, weight, bias)
+        B, Cc, D, H, W = vol.shape
+        p1, p2, p3 = patch_size
+        Np, Pd, d = (D // p1) * (H // p2) * (W // p3), Cc * p1 * p2 * p3, weight.shape[0]
+        dt = torch.bfloat16 if prec == L.PREC_BF16 else torch.float32
+        patches = torch.empty(B * Np, Pd, dtype=dt, device=vol.device)
+        L.call("hs_patchify", vol.data_ptr(), patches.data_ptr(), B, Cc, D, H, W, p1, p2, p3, prec, _s())
+        wa = cast_bf16(weight) if prec == L.PREC_BF16 else weight.contiguous()
+        y = torch.empty(B * Np, d, dtype=torch.float32, device=vol.device)
+        gemm(patches, wa, L.GEMM_NT, prec=prec, out_f32=y, bias=bias, flags=L.EPI_BIAS)
+        ctx.save_for_backward(patches)
+        ctx.prec, ctx.wshape = prec, weight.shape
+        return y.view(B, Np, d)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (patches,) = ctx.saved_tensors
+        prec = ctx.prec
+        N, K = ctx.wshape
+        dy2 = _f32(dy).contiguous().view(-1, N)
+        dya = cast_bf16(dy2) if prec == L.PREC_BF16 else dy2
+        dw = torch.zeros(N, K, dtype=torch.float32, device=dy.device)
+        tile, kt = (128, 64) if prec == L.PREC_BF16 else (64, 32)
+        gemm(dya, patches, L.GEMM_TN, prec=prec, out_f32=dw, flags=L.EPI_ATOMIC,
+             split_k=_wgrad_split(N, K, patches.shape[0], tile, kt))
+        db = torch.zeros(N, dtype=torch.float32, device=dy.device)
+        colsum(dya, db)
+        return None, dw, db, None, None
+
+
+class AssembleFn(torch.autograd.Function):
+    """tokens = cat(cls, (pe + pos) * score) (vit.py:345-349,459-461).  Returns (tokens, pe+pos)."""
+
+    @staticmethod
+    def forward(ctx, pe, pos, cls, score):
+        pe = pe.contiguous()
+        _need(pe, pos, cls, score)
+        B, Np, d = pe.shape
+        tokens = torch.empty(B, Np + 1, d, dtype=torch.float32, device=pe.device)
+        pe_pos = torch.empty_like(pe)
+        L.call("hs_assemble_tokens", pe.data_ptr(), pos.data_ptr(), cls.data_ptr(), _p(score), tokens.data_ptr(), pe_pos.data_ptr(),
+               B, Np, d, _s())
+        ctx.save_for_backward(pe_pos, score)
+        ctx.shapes = (pos.shape, cls.shape)
+        ctx.mark_non_differentiable(pe_pos)
+        return tokens, pe_pos
+
+    @staticmethod
+    def backward(ctx, dtok, _unused):
+        pe_pos, score = ctx.saved_tensors
+        dtok = _f32(dtok).contiguous()
+        B, Np, d = pe_pos.shape
+        dpe = torch.empty_like(pe_pos)
+        dpos = torch.zeros(ctx.shapes[0], dtype=torch.float32, device=dtok.device)
+        dcls = torch.zeros(ctx.shapes[1], dtype=torch.float32, device=dtok.device)
+        dscore = torch.empty(B, Np, dtype=torch.float32, device=dtok.device) if score is not None else None
+        L.call("hs_assemble_tokens_bwd", dtok.data_ptr(), pe_pos.data_ptr(), _p(score), dpe.data_ptr(), dpos.data_ptr(), dcls.data_ptr(),
+               _p(dscore), B, Np, d, _s())
+        return dpe, dpos, dcls, dscore
+
+
+class CrossAttnFn(torch.autograd.Function):
+    """attention(query, key, value) of regular_attention (vit.py:25-33), eval mode: returns (P V, P)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v):
+        q, k, v = (_f32(t).contiguous() for t in (q, k, v))
+        _need(q, k, v)
+        B, nq, d = q.shape
+        nk = k.shape[1]
+        out = torch.empty_like(q)
+        p = torch.empty(B, nq, nk, dtype=torch.float32, device=q.device)
+        L.call("hs_cross_attn_fwd", q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), p.data_ptr(), B, nq, nk, d, _s())
+        ctx.save_for_backward(q, k, v, p)
+        ctx.mark_non_differentiable(p)
+        return out, p
+
+    @staticmethod
+    def backward(ctx, dout, _dp):
+        q, k, v, p = ctx.saved_tensors
+        dout = _f32(dout).contiguous()
+        B, nq, d = q.shape
+        nk = k.shape[1]
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        ws = torch.empty_like(p)
+        L.call("hs_cross_attn_bwd", q.data_ptr(), k.data_ptr(), v.data_ptr(), p.data_ptr(), dout.data_ptr(), dq.data_ptr(), dk.data_ptr(),
+               dv.data_ptr(), ws.data_ptr(), B, nq, nk, d, _s())
+        return dq, dk, dv
+
+
+class RowdotSigmoidFn(torch.autograd.Function):
+    """patch_score_proj (Linear(d,1)) + Sigmoid (vit.py:338-339): x [..., d] -> [...]."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x = _f32(x).contiguous()
+        w = w.contiguous()
+        _need(x, w, b)
+        rows, d = x.numel() // x.shape[-1], x.shape[-1]
+        score = torch.empty(x.shape[:-1], dtype=torch.float32, device=x.device)
+        L.call("hs_rowdot_sigmoid_fwd", x.data_ptr(), w.data_ptr(), b.data_ptr(), score.data_ptr(), rows, d, _s())
+        ctx.save_for_backward(x, w, score)
+        return score
+
+    @staticmethod
+    def backward(ctx, dscore):
+        x, w, score = ctx.saved_tensors
+        dscore = _f32(dscore).contiguous()
+        rows, d = x.numel() // x.shape[-1], x.shape[-1]
+        dx = torch.empty_like(x)
+        dw = torch.zeros_like(w)
+        db = torch.zeros(1, dtype=torch.float32, device=x.device)
+        L.call("hs_rowdot_sigmoid_bwd", x.data_ptr(), w.data_ptr(), score.data_ptr(), dscore.data_ptr(), dx.data_ptr(), dw.data_ptr(),
+               db.data_ptr(), rows, d, _s())
+        return dx, dw, db
+
+
+class Pool3dFn(torch.autograd.Function):
+    """F.avg_pool3d over the token grid (spatial_pooling_projector.py:141): hr [B,gd,gh,gw,d] -> [B,cells,d]."""
+
+    @staticmethod
+    def forward(ctx, hr, kernel):
+        hr = _f32(hr).contiguous()
+        _need(hr)
+        B, gd, gh, gw, d = hr.shape
+        kd, kh, kw = kernel
+        cells = (gd // kd) * (gh // kh) * (gw // kw)
+        lr = torch.empty(B, cells, d, dtype=torch.float32, device=hr.device)
+        L.call("hs_pool3d_fwd", hr.data_ptr(), lr.data_ptr(), B, gd, gh, gw, kd, kh, kw, d, _s())
+        ctx.geom = (B, gd, gh, gw, d, kd, kh, kw)
+        return lr
+
+    @staticmethod
+    def backward(ctx, dlr):
+        B, gd, gh, gw, d, kd, kh, kw = ctx.geom
+        dlr = _f32(dlr).contiguous()
+        dhr = torch.empty(B, gd, gh, gw, d, dtype=torch.float32, device=dlr.device)
+        L.call("hs_pool3d_bwd", dlr.data_ptr(), dhr.data_ptr(), B, gd, gh, gw, kd, kh, kw, d, 0, _s())
+        return dhr, None
+
+
+class WindowAttnFn(torch.autograd.Function):
+    """1 query per LR cell vs its kd*kh*kw HR children (spatial_pooling_projector.py:68-76), eval mode.
+    q [B,cells,d]; kv [B,tokens,2d] (k|v)."""
+
+    @staticmethod
+    def forward(ctx, q, kv, grid, kernel):
+        q, kv = _f32(q).contiguous(), _f32(kv).contiguous()
+        _need(q, kv)
+        B, cells, d = q.shape
+        out = torch.empty_like(q)
+        L.call("hs_window_attn_fwd", q.data_ptr(), kv.data_ptr(), out.data_ptr(), B, *grid, *kernel, d, _s())
+        ctx.save_for_backward(q, kv)
+        ctx.geom = (tuple(grid), tuple(kernel))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, kv = ctx.saved_tensors
+        grid, kernel = ctx.geom
+        dout = _f32(dout).contiguous()
+        B, cells, d = q.shape
+        dq = torch.empty_like(q)
+        dkv = torch.zeros_like(kv)
+        L.call("hs_window_attn_bwd", q.data_ptr(), kv.data_ptr(), dout.data_ptr(), dq.data_ptr(), dkv.data_ptr(), B, *grid, *kernel, d, _s())
+        return dq, dkv, None, None
+
+
+def _ptr_array(tensors: Sequence[torch.Tensor]):
+    arr = (C.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr()
+    return arr
+
+
+class BlocksFn(torch.autograd.Function):
+    """The 12 x TransformerBlock hot loop + final norm (vit.py:464-467 / 352-355) as ONE fused enqueue.
+
+    inputs: x0 [B,N,d] fp32, then L*11 block params in MONAI state-dict order, then norm.weight, norm.bias.
+    returns (y [B,N,d], hidden [L,B,N,d]).  Gradients flow through y only (the reference's callers never
+    differentiate the hidden-state list)."""
+
+    @staticmethod
+    def forward(ctx, x0, H, mlp, prec, *params):
+        x0 = _f32(x0).contiguous()
+        params = tuple(p.contiguous() for p in params)
+        _need(x0, *params)
+        B, N, d = x0.shape
+        Ln = (len(params) - 2) // 11
+        need_grad = torch.is_grad_enabled() and (x0.requires_grad or any(p.requires_grad for p in params))
+        if need_grad and prec != L.PREC_BF16:
+            raise L.HsError("the fused block stack differentiates in bf16 mode only (f32 is the forward parity mode)")
+        desc = L.VitDesc(B, N, d, H, mlp, Ln, prec, int(need_grad))
+        nbytes = L.load().hs_vit_workspace_bytes(C.byref(desc))
+        if nbytes == 0:
+            raise L.HsError(f"unsupported encoder geometry B={B} N={N} d={d} H={H} mlp={mlp} L={Ln}")
+        ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=x0.device)
+        off = (-ws.data_ptr()) % 256
+        y = torch.empty_like(x0)
+        hidden = torch.empty(Ln, B, N, d, dtype=torch.float32, device=x0.device)
+        lp, npar = _ptr_array(params[:-2]), _ptr_array(params[-2:])
+        L.call("hs_vit_blocks_fwd", C.byref(desc), x0.data_ptr(), lp, npar, y.data_ptr(), hidden.data_ptr(), ws.data_ptr() + off,
+               nbytes, _s())
+        if need_grad:
+            ctx.save_for_backward(x0, hidden, ws, *params)
+            ctx.desc, ctx.ws_off, ctx.nbytes = desc, off, nbytes
+        ctx.mark_non_differentiable(hidden)
+        return y, hidden
+
+    @staticmethod
+    def backward(ctx, dy, _dh):
+        x0, hidden, ws, *params = ctx.saved_tensors
+        desc = ctx.desc
+        dy = _f32(dy).contiguous()
+        dx0 = torch.empty_like(x0)
+        grads = [torch.zeros_like(p) for p in params]
+        lp, npar = _ptr_array(params[:-2]), _ptr_array(params[-2:])
+        lg, ng = _ptr_array(grads[:-2]), _ptr_array(grads[-2:])
+        L.call("hs_vit_blocks_bwd", C.byref(desc), x0.data_ptr(), lp, npar, dy.data_ptr(), dx0.data_ptr(), lg, ng, hidden.data_ptr(),
+               ws.data_ptr() + ctx.ws_off, ctx.nbytes, desc.L, 0, _s())
+        return (dx0, None, None, None, *grads)

@@ -1,0 +1,111 @@
+"""MI355X host mirror of the reference's Spatial Packer projector API
+(Preprint/LaMed/src/model/multimodal_projector/{spatial_pooling_projector.py,builder.py}).
+
+Same class names / constructor and forward signatures / ``proj_out_num`` / state-dict keys
+(``proj_mpls.{0,2}.*``, ``resolution_attention.{Wq,Wk,Wv,output_linear,norm}.*``).  Arithmetic runs in
+libhsenet_hip.so; the modules only hold parameters.  Eval-mode function (the hard-coded p=0.1 dropouts of
+``resolution_attention_v3`` are not applied) — see DESIGN.md "Dropout".
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import functional as Fn
+from .encoder import _prec
+
+
+class resolution_attention_v3(nn.Module):
+    """spatial_pooling_projector.py:48-83: one query per low-resolution cell attends to the cell's
+    high-resolution children (single head, d_k = 768); LN(q + output_linear(attn))."""
+
+    def __init__(self, in_channels=16, out_channels=8, emb_dim=768, output_dim=768, dropout=0.1, aropout=0.0):
+        super().__init__()
+        self.emb_dim = emb_dim
+        self.Wq = nn.Linear(emb_dim, emb_dim)
+        self.Wk = nn.Linear(emb_dim, emb_dim)
+        self.Wv = nn.Linear(emb_dim, emb_dim)
+        self.attn = None
+        self.output_linear = nn.Linear(emb_dim, emb_dim)
+        self.dropout = nn.Dropout(p=dropout)
+        self.dropout_2 = nn.Dropout(p=dropout)
+        self.norm = nn.LayerNorm(emb_dim)
+
+    def forward(self, LR_image, HR_image, kernel_size, context=None, mask=None):
+        if mask is not None:
+            raise ValueError("mask is never passed on the HSENet path (spatial_pooling_projector.py:142)")
+        prec = _prec(self)
+        B, gd, gh, gw, d = HR_image.shape
+        kernel = tuple(int(k) for k in kernel_size)
+        lr = LR_image.contiguous().view(B, -1, d)
+        q = Fn.LinearFn.apply(lr, self.Wq.weight, self.Wq.bias, prec)
+        # K and V projections of every HR token as ONE GEMM against [Wk; Wv]  (59 % of the packer's FLOPs)
+        wkv = torch.cat([self.Wk.weight, self.Wv.weight], dim=0)
+        bkv = torch.cat([self.Wk.bias, self.Wv.bias], dim=0)
+        kv = Fn.LinearFn.apply(HR_image.contiguous().view(B, gd * gh * gw, d), wkv, bkv, prec)
+        x = Fn.WindowAttnFn.apply(q, kv, (gd, gh, gw), kernel)
+        x = Fn.LinearFn.apply(x, self.output_linear.weight, self.output_linear.bias, prec)
+        return Fn.LayerNormFn.apply(q, x, self.norm.weight, self.norm.bias, self.norm.eps)
+
+
+class VisualPacker_3d_phi_v3(nn.Module):
+    """spatial_pooling_projector.py:121-153.  ``grid`` / ``kernel_size`` are keyword-only extensions: the
+    reference hard-codes the (8,16,16) token grid (:140) and kernel (1,4,4) (:132); BASELINE's 256^3 configs
+    have a (16,16,16) grid, for which the reference-sanctioned kernel is (2,4,4) (:166-167) -> still 128 tokens.
+    With the defaults this is the reference module exactly."""
+
+    def __init__(self, image_size, patch_size, in_dim, out_dim, layer_type, layer_num, pooling_type="spatial",
+                 pooling_size=2, *, grid=None, kernel_size=None):
+        super().__init__()
+        self.in_dim = in_dim
+        self.out_dim = out_dim
+        self.proj_mpls = nn.Sequential(nn.Linear(self.in_dim, self.out_dim), nn.GELU(), nn.Linear(self.out_dim, self.out_dim))
+        self.kernel_size = tuple(kernel_size) if kernel_size is not None else (1, 4, 4)
+        self.num_patches_pre = [img // pch for img, pch in zip(image_size, patch_size)]
+        self.num_patches_post = [self.num_patches_pre[i] // self.kernel_size[i] for i in range(len(self.num_patches_pre))]
+        self.grid = tuple(grid) if grid is not None else (8, 16, 16)
+        self.resolution_attention = resolution_attention_v3()
+
+    def forward(self, visual_inputs):
+        prec = _prec(self)
+        batch = visual_inputs.size(0)
+        HR = visual_inputs.contiguous().view(batch, *self.grid, 768)                    # :140
+        LR = Fn.Pool3dFn.apply(HR, self.kernel_size)                                    # :141 avg_pool3d
+        cd, ch, cw = (g // k for g, k in zip(self.grid, self.kernel_size))
+        feats = self.resolution_attention(LR.view(batch, cd, ch, cw, 768), HR, self.kernel_size)
+        h = Fn.LinearFn.apply(feats, self.proj_mpls[0].weight, self.proj_mpls[0].bias, prec)
+        h = Fn.GeluFn.apply(h)
+        h = Fn.LinearFn.apply(h, self.proj_mpls[2].weight, self.proj_mpls[2].bias, prec)
+        return h.view(batch, -1, self.out_dim)
+
+    @property
+    def proj_out_num(self):
+        num = 1
+        for n in self.num_patches_post:
+            num *= n
+        return num
+
+
+def build_mm_projector(config, delay_load=False, **kwargs):
+    """multimodal_projector/builder.py:81-106 (only the shipped 'VisualPacker_3d_phi_v3' branch; the
+    'baseline' branch of the reference names an un-imported class and cannot run there either)."""
+    projector_type = getattr(config, "mm_projector_type")
+    if projector_type == "VisualPacker_3d_phi_v3":
+        return VisualPacker_3d_phi_v3(image_size=config.image_size, patch_size=config.patch_size,
+                                      in_dim=config.mm_hidden_size, out_dim=config.hidden_size,
+                                      layer_type=config.proj_layer_type, layer_num=config.proj_layer_num,
+                                      pooling_type=config.proj_pooling_type, pooling_size=config.proj_pooling_size, **kwargs)
+    raise ValueError(f"Unknown projector type: {projector_type}")
+
+
+def encode_images(vision_tower, mm_projector, mm_projector2, images, images_2d):
+    """LamedMetaForCausalLM.encode_images, dual-encoder branch (lamed_arch.py:122-132): two packers, concat on
+    the token axis -> (B, 256, hidden).  ``mm_projector2=None`` reproduces the reference's bare-except fallback
+    to the shared projector (:129-131)."""
+    image_features = vision_tower(images, images_2d)
+    if isinstance(image_features, tuple):
+        f1, f2 = image_features
+        a = mm_projector(f1.contiguous())
+        b = (mm_projector2 if mm_projector2 is not None else mm_projector)(f2.contiguous())
+        return torch.cat([a, b], dim=1)
+    return mm_projector(image_features.contiguous())

@@ -1,0 +1,187 @@
+/* libhsenet_hip.so — C ABI of the MI355X (gfx950) kernels behind HSENet's dual 3D vision-encoder path.
+ *
+ * Every entry point takes raw DEVICE pointers, sizes and a hipStream_t (passed as void*), enqueues work on
+ * that stream and returns an int status (HS_OK, or a negative HS_ERR_*).  No entry point allocates, frees
+ * or synchronises (graph-capture safe); callers own every buffer, including workspaces whose size comes
+ * from hs_vit_workspace_bytes().  No torch types cross this boundary.
+ *
+ * The reference (YanzhaoShi/HSENet) has no native layer: each function below names the reference Python
+ * (or MONAI 1.3.0) operator sequence it replaces, relative to Preprint/LaMed/src/model/.  The Python host
+ * mirror of the reference's module API lives in hsenet_amd/{encoder,projector}.py; the binding a reference
+ * maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions: bf16 = raw uint16 bits.  "rows" = B*N tokens.  Matrices are row-major.  prec: HS_PREC_*.
+ */
+#ifndef HSENET_HIP_H
+#define HSENET_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HS_OK 0
+#define HS_ERR_SHAPE (-1)   /* unsupported / inconsistent shape or alignment */
+#define HS_ERR_ARCH (-2)    /* no gfx950 device */
+#define HS_ERR_LAUNCH (-3)  /* hip launch error */
+#define HS_ERR_ARG (-4)     /* null pointer / bad enum */
+
+#define HS_PREC_BF16 0      /* bf16 MFMA inputs, fp32 accumulate, fp32 residual stream (reference autocast policy) */
+#define HS_PREC_F32 1       /* exact-f32 MFMA (v_mfma_f32_32x32x2_f32): parity mode */
+
+/* GEMM operand layouts: C[M,N] = sum_k A(m,k) * B(n,k).  "T" = the operand is stored [K][dim] (k is the row). */
+#define HS_GEMM_NT 0        /* A[M][K], B[N][K]   : forward nn.Linear  y = x W^T                      */
+#define HS_GEMM_NN 1        /* A[M][K], B[K][N]   : dgrad              dx = dy W                     */
+#define HS_GEMM_TN 2        /* A[K][M], B[K][N]   : wgrad              dW = dy^T x                   */
+
+/* epilogue flags (applied in this order): v = alpha*acc; +bias[n]; GELU fwd (optionally save pre-act);
+ * *gelu'(aux[m,n]); +resid[m,n]; store fp32 (or atomicAdd when split_k>1) and/or bf16. */
+#define HS_EPI_BIAS 1
+#define HS_EPI_GELU 2
+#define HS_EPI_GELU_BWD 4
+#define HS_EPI_RESID 8
+#define HS_EPI_ATOMIC 16    /* out_f32 += v with float atomics (split-K wgrad; caller zeroes out_f32)          */
+#define HS_EPI_BIAS_M 32    /* bias indexed by m (row) instead of n                                         */
+
+typedef struct hs_gemm_args {
+    const void* A;          /* bf16 (HS_PREC_BF16) or float (HS_PREC_F32) */
+    const void* B;
+    int M, N, K;
+    int64_t lda, ldb;       /* row strides (elements) of A and B as stored */
+    int batch;              /* grid.z batches (>=1) */
+    int64_t strideA, strideB, strideC; /* batch strides, elements (strideC applies to every [M,N] tensor) */
+    float* out_f32;         /* [M][ldc] or NULL */
+    void* out_bf16;         /* [M][ldc] bf16 or NULL */
+    int64_t ldc;
+    const float* bias;      /* [N] (or [M] with HS_EPI_BIAS_M) */
+    const float* resid;     /* [M][ldc] fp32 */
+    const void* aux;        /* [M][ldc] pre-activation z for HS_EPI_GELU_BWD (bf16; float in F32 mode) */
+    void* aux_out;          /* [M][ldc] pre-activation saved by HS_EPI_GELU (bf16), or NULL */
+    float alpha;
+    int flags;
+    int layout;             /* HS_GEMM_* */
+    int split_k;            /* >=1; >1 requires HS_EPI_ATOMIC and batch==1 */
+} hs_gemm_args;
+
+/* ---- library ------------------------------------------------------------------------------------------ */
+int hs_version(void);
+/* HS_OK when device `dev` is gfx950 */
+int hs_device_check(int dev);
+
+/* ---- K3: GEMM family.  Replaces nn.Linear fwd/bwd inside MONAI SABlock/MLPBlock/PatchEmbeddingBlock
+ * (call sites multimodal_encoder/vit.py:428-443), regular_attention (vit.py:39-45,57-62),
+ * resolution_attention_v3 + proj_mpls (multimodal_projector/spatial_pooling_projector.py:51-57,73-82,127-131). */
+int hs_gemm(const hs_gemm_args* args, int prec, void* stream);
+
+/* ---- K1: 3D patch embedding.  Replaces x.clone() + einops 'b c (h p1)(w p2)(d p3) -> b (h w d)(p1 p2 p3 c)'
+ * (vit.py:437,455) = the A operand of the patch-embed Linear.  out: [B*Np][Pd] bf16 (prec 0) / float (prec 1). */
+int hs_patchify(const float* vol, void* out, int B, int C, int D, int H, int W, int p1, int p2, int p3, int prec,
+                void* stream);
+/* tokens[b,0,:] = cls; tokens[b,1+p,:] = (pe[b,p,:] + pos[p,:]) * (score ? score[b,p] : 1).   (vit.py:345-349,459-461)
+ * pe_out (optional) receives pe+pos (the un-weighted embedding, needed by the stage-2 scorer and its backward).
+ * cls == NULL (classification=False): no cls row is written and tokens is [B][Np][d]. */
+int hs_assemble_tokens(const float* pe, const float* pos, const float* cls, const float* score, float* tokens,
+                       float* pe_out, int B, int Np, int d, void* stream);
+/* backward of hs_assemble_tokens: dpe[b,p,:] = dtok[b,1+p,:]*score; dcls += sum_b dtok[b,0,:]; dpos += sum_b dpe;
+ * dscore[b,p] = <dtok[b,1+p,:], pe_pos[b,p,:]> (when score given). dpos/dcls accumulate (caller zeroes).
+ * dcls == NULL <=> the forward had no cls row (dtok is [B][Np][d]). */
+int hs_assemble_tokens_bwd(const float* dtok, const float* pe_pos, const float* score, float* dpe, float* dpos,
+                           float* dcls, float* dscore, int B, int Np, int d, void* stream);
+
+/* ---- K2: LayerNorm (nn.LayerNorm(d), eps 1e-5; MONAI TransformerBlock.norm1/2, vit.py:467, vit.py:62).
+ * x fp32 [rows][d]; optional resid added first (y = LN(x + resid)); writes y as fp32 and/or bf16; mean/rstd optional. */
+int hs_layernorm_fwd(const float* x, const float* resid, const float* gamma, const float* beta, float* y_f32,
+                     void* y_bf16, float* mean, float* rstd, int rows, int d, float eps, void* stream);
+/* dx = LNbwd(dy) (+ dx_in when accumulate!=0); also emits bf16 copy of the result; dgamma/dbeta accumulate
+ * atomically (caller zeroes).  x (and resid) are the forward inputs. */
+int hs_layernorm_bwd(const float* dy, const float* x, const float* resid, const float* gamma, const float* mean,
+                     const float* rstd, const float* dx_in, float* dx, void* dx_bf16, float* dgamma, float* dbeta,
+                     int rows, int d, void* stream);
+
+/* ---- K4: global multi-head self-attention core of MONAI SABlock: softmax(q k^T * dh^-0.5) v, no mask, no
+ * bias, non-causal (reached from the hot loops vit.py:352-354,464-466).  qkv: [B][N][3][H][dh] exactly as
+ * the qkv Linear emits it ('b n (qkv h dh)'); o: [B][N][H*dh]; lse: [B][H][N] fp32 (natural log-sum-exp of the
+ * scaled scores).  dh must be 64.  Flash-style: the N x N matrix is never materialised. */
+int hs_attn_fwd(const void* qkv, void* o, float* lse, int B, int N, int H, int dh, int prec, void* stream);
+/* dqkv from (qkv, o, do, lse); delta_ws: fp32 scratch [B][H][N].  bf16 only. */
+int hs_attn_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv, float* delta_ws,
+                int B, int N, int H, int dh, void* stream);
+
+/* ---- K5: slice-guided scoring core of regular_attention (vit.py:25-33,57-60): single head, d_k = d,
+ * P = softmax(q k^T / sqrt(d)) over nk keys (nk <= 64, nk % 4 == 0), out = P v.  q: [B][nq][d] fp32;
+ * k, v: [B][nk][d] fp32.  p: [B][nq][nk] fp32, REQUIRED (the attention map the reference returns; saved for bwd).
+ * Runs as exact-f32 MFMA GEMMs + a row softmax (4*nq*nk*d FLOPs: negligible).  Eval-mode (dropout off) — see
+ * DESIGN.md "Dropout". */
+int hs_cross_attn_fwd(const float* q, const float* k, const float* v, float* out, float* p, int B, int nq, int nk,
+                      int d, void* stream);
+/* backward: dq, dk, dv written.  ws: fp32 scratch [B][nq][nk].  nq % 4 == 0. */
+int hs_cross_attn_bwd(const float* q, const float* k, const float* v, const float* p, const float* dout, float* dq,
+                      float* dk, float* dv, float* ws, int B, int nq, int nk, int d, void* stream);
+/* score[r] = sigmoid(<x[r,:], w> + b)   (patch_score_proj + Sigmoid, vit.py:338-339).  x fp32 [rows][d]. */
+int hs_rowdot_sigmoid_fwd(const float* x, const float* w, const float* b, float* score, int rows, int d, void* stream);
+/* dx[r,:] = dscore[r]*s(1-s)*w ; dw += sum_r ..*x[r,:] ; db += sum_r ..   (dw/db accumulate atomically) */
+int hs_rowdot_sigmoid_bwd(const float* x, const float* w, const float* score, const float* dscore, float* dx,
+                          float* dw, float* db, int rows, int d, void* stream);
+
+/* ---- K6: Spatial Packer window step (spatial_pooling_projector.py:62-76,138-141).
+ * avg-pool: lr[b,cell,:] = mean over the cell's kd*kh*kw children of hr[b,child,:]; hr is the token grid
+ * [B][gd][gh][gw][d] fp32, cells ordered row-major over (gd/kd, gh/kh, gw/kw). */
+int hs_pool3d_fwd(const float* hr, float* lr, int B, int gd, int gh, int gw, int kd, int kh, int kw, int d, void* stream);
+int hs_pool3d_bwd(const float* dlr, float* dhr, int B, int gd, int gh, int gw, int kd, int kh, int kw, int d,
+                  int accumulate, void* stream);
+/* one query per cell vs its children: out[b,cell,:] = sum_j softmax_j(<q,k_j>/sqrt(d)) v_j.
+ * q: [B][cells][d]; kv: [B][gd*gh*gw][2*d] fp32 (k | v per token, as one fused Wk|Wv GEMM emits it). */
+int hs_window_attn_fwd(const float* q, const float* kv, float* out, int B, int gd, int gh, int gw, int kd, int kh,
+                       int kw, int d, void* stream);
+int hs_window_attn_bwd(const float* q, const float* kv, const float* dout, float* dq, float* dkv, int B, int gd,
+                       int gh, int gw, int kd, int kh, int kw, int d, void* stream);
+
+/* ---- K7/K8: small fused element/reduction kernels ------------------------------------------------------- */
+/* out[n] (+)= sum_m x[m][n]  (bias gradients).  x bf16 (is_bf16) or fp32.  accumulates atomically (caller zeroes). */
+int hs_colsum(const void* x, int is_bf16, float* out, int M, int N, int64_t ldx, void* stream);
+/* fp32 -> bf16 cast of n elements (weights before each step; activations at module boundaries) */
+int hs_cast_bf16(const float* x, void* y, int64_t n, void* stream);
+int hs_cast_f32(const void* x_bf16, float* y, int64_t n, void* stream);
+/* y = gelu(x) fp32, exact erf (nn.GELU in proj_mpls, spatial_pooling_projector.py:129) and its backward */
+int hs_gelu_fwd(const float* x, float* y, int64_t n, void* stream);
+int hs_gelu_bwd(const float* x, const float* dy, float* dx, int64_t n, void* stream);
+/* y[r,:] = x[r,:] / max(||x[r,:]||, eps)   (F.normalize, CLIP_stage1.py:101) and backward */
+int hs_l2norm_fwd(const float* x, float* y, int rows, int d, float eps, void* stream);
+int hs_l2norm_bwd(const float* x, const float* dy, float* dx, int rows, int d, float eps, void* stream);
+/* fused AdamW over a flat fp32 parameter buffer (optim="adamw_torch", train/train_CLIP_stage1.py:85).
+ * grad_scale multiplies the gradient first (1/world for DP mean). step >= 1. */
+int hs_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+             float weight_decay, float grad_scale, int step, void* stream);
+
+/* ---- fused encoder driver: the hot loops vit.py:464-467 / 352-355 (12 x MONAI TransformerBlock + final norm) as
+ * one enqueue.  All pointers are device pointers.
+ * layer_params: L*11 fp32 tensors in MONAI state-dict order per block:
+ *   [mlp.linear1.weight, mlp.linear1.bias, mlp.linear2.weight, mlp.linear2.bias, norm1.weight, norm1.bias,
+ *    attn.out_proj.weight, attn.out_proj.bias, attn.qkv.weight, norm2.weight, norm2.bias]
+ * norm_params: [norm.weight, norm.bias].  x0: tokens [B][N][d] fp32.  y: [B][N][d] fp32 (post-norm).
+ * hidden: [L][B][N][d] fp32 (the 12 hidden states the reference returns).  ws: workspace. */
+typedef struct hs_vit_desc {
+    int B, N, d, H, mlp, L;
+    int prec;            /* HS_PREC_* */
+    int save_for_bwd;    /* 1: keep per-layer activations in ws for hs_vit_blocks_bwd */
+} hs_vit_desc;
+
+size_t hs_vit_workspace_bytes(const hs_vit_desc* desc);
+int hs_vit_blocks_fwd(const hs_vit_desc* desc, const float* x0, const float* const* layer_params,
+                      const float* const* norm_params, float* y, float* hidden, void* ws, size_t ws_bytes, void* stream);
+/* backward of the above (bf16 mode, save_for_bwd=1 forward must have run on the same ws).
+ * dy: [B][N][d] fp32.  dx0: [B][N][d] fp32 out.  layer_grads / norm_grads: same order as the params; written
+ * (weights) or accumulated atomically (biases, LN): the caller zeroes all gradient buffers before the call.
+ * Layers are processed from l_hi-1 down to l_lo (inclusive), so a caller can interleave gradient all-reduce
+ * buckets: call with (L, L-3), then (L-3, L-6), ...  The final norm's backward runs when l_hi == L; dx0 is valid
+ * when l_lo == 0. */
+int hs_vit_blocks_bwd(const hs_vit_desc* desc, const float* x0, const float* const* layer_params,
+                      const float* const* norm_params, const float* dy, float* dx0, float* const* layer_grads,
+                      float* const* norm_grads, const float* hidden, void* ws, size_t ws_bytes, int l_hi, int l_lo,
+                      void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HSENET_HIP_H */

@@ -1,0 +1,302 @@
+"""Per-kernel parity tests (GPU): each HIP kernel, called through the C ABI, against a plain torch fp32/fp64
+statement of the same op on the same seeded inputs.  Tolerances are written next to each check."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def rnd(shape, seed, dev, scale=1.0):
+    g = np.random.default_rng(seed)
+    return torch.from_numpy(g.standard_normal(shape, dtype=np.float32) * scale).to(dev)
+
+
+GEMM_SHAPES = [(128, 128, 64), (300, 200, 192), (4097, 768, 768), (37, 2304, 128), (513, 8, 320), (64, 136, 72)]
+
+
+@pytest.mark.parametrize("layout", [0, 1, 2])
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+@pytest.mark.parametrize("prec", ["bf16", "f32"])
+def test_gemm_layouts(dev, layout, M, N, K, prec):
+    from hsenet_amd import functional as Fn, _lib as L
+    if layout == 2 and M % 8:
+        pytest.skip("TN needs M % 8 == 0 (16-B chunks along the contiguous axis)")
+    if layout != 0 and N % 8:
+        pytest.skip("NN/TN need N % 8 == 0")
+    P = L.PREC_BF16 if prec == "bf16" else L.PREC_F32
+    dt = torch.bfloat16 if prec == "bf16" else torch.float32
+    a = rnd((M, K), 1, dev).to(dt)
+    b = rnd((N, K), 2, dev).to(dt)
+    ref = a.double() @ b.double().t()
+    A = a if layout != 2 else a.t().contiguous()
+    Bm = b if layout == 0 else b.t().contiguous()
+    out = torch.full((M, N), float("nan"), device=dev)
+    Fn.gemm(A, Bm, layout, prec=P, out_f32=out)
+    torch.cuda.synchronize()
+    # same (rounded) inputs on both sides, fp32 accumulation: only summation order differs -> 2e-6 * sqrt(K) headroom
+    assert rel(out, ref) < 1e-5, rel(out, ref)
+
+
+def test_gemm_epilogues(dev):
+    from hsenet_amd import functional as Fn, _lib as L
+    M, N, K = 333, 256, 128
+    a, b = rnd((M, K), 3, dev).bfloat16(), rnd((N, K), 4, dev).bfloat16()
+    bias, resid = rnd((N,), 5, dev), rnd((M, N), 6, dev)
+    acc = a.double() @ b.double().t()
+    # bias + gelu, saving the bf16 pre-activation
+    o16 = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    z16 = torch.empty_like(o16)
+    Fn.gemm(a, b, L.GEMM_NT, prec=L.PREC_BF16, out_bf16=o16, bias=bias, aux_out=z16, flags=L.EPI_BIAS | L.EPI_GELU)
+    z = (acc + bias.double()).float()
+    assert rel(z16.float(), z) < 4e-3                      # bf16 rounding of the output: 2^-9
+    assert rel(o16.float(), F.gelu(z16.float())) < 4e-3    # gelu is evaluated on the rounded pre-activation
+    # bias + residual -> fp32
+    o32 = torch.empty(M, N, device=dev)
+    Fn.gemm(a, b, L.GEMM_NT, prec=L.PREC_BF16, out_f32=o32, bias=bias, resid=resid, flags=L.EPI_BIAS | L.EPI_RESID)
+    assert rel(o32, acc + bias.double() + resid.double()) < 1e-5
+    # gelu backward epilogue
+    zz = rnd((M, N), 7, dev).bfloat16()
+    Fn.gemm(a, b, L.GEMM_NT, prec=L.PREC_BF16, out_f32=o32, aux=zz, flags=L.EPI_GELU_BWD)
+    zr = zz.float().double().requires_grad_()
+    (g,) = torch.autograd.grad(F.gelu(zr).sum(), zr)
+    assert rel(o32, acc * g) < 1e-4
+    # split-K atomic accumulate on top of an existing value, alpha
+    base = rnd((M, N), 8, dev)
+    Mo = 336
+    a2 = rnd((1000, Mo), 9, dev).bfloat16()                         # stored [K=1000][M'=336]
+    b2 = rnd((1000, N), 10, dev).bfloat16()                         # stored [K=1000][N]
+    o = base[:Mo].clone()
+    Fn.gemm(a2, b2, L.GEMM_TN, prec=L.PREC_BF16, out_f32=o, flags=L.EPI_ATOMIC, split_k=5, alpha=0.5)
+    assert rel(o, base[:Mo].double() + 0.5 * (a2.double().t() @ b2.double())) < 1e-5
+
+
+def test_gemm_batched_f32(dev):
+    from hsenet_amd import functional as Fn, _lib as L
+    a, b = rnd((3, 70, 36), 11, dev), rnd((3, 32, 36), 12, dev)
+    out = torch.empty(3, 70, 32, device=dev)
+    Fn.gemm(a, b, L.GEMM_NT, prec=L.PREC_F32, out_f32=out, alpha=0.25)
+    assert rel(out, 0.25 * a.double() @ b.double().transpose(1, 2)) < 1e-6
+
+
+def sdpa_ref(qkv, H):
+    B, N, D3 = qkv.shape
+    q, k, v = qkv.double().view(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
+    s = q @ k.transpose(-1, -2) * 0.125
+    p = s.softmax(-1)
+    o = (p @ v).permute(0, 2, 1, 3).reshape(B, N, H * 64)
+    return o, torch.logsumexp(s, -1)
+
+
+@pytest.mark.parametrize("N", [1, 9, 64, 65, 200, 513, 2049])
+@pytest.mark.parametrize("prec", ["bf16", "f32"])
+def test_attn_fwd(dev, N, prec):
+    from hsenet_amd import functional as Fn, _lib as L
+    B, H = 2, 3
+    P = L.PREC_BF16 if prec == "bf16" else L.PREC_F32
+    qkv = rnd((B, N, 3 * H * 64), 20 + N, dev, 1.5)
+    qkv = qkv.bfloat16() if prec == "bf16" else qkv
+    o, lse = Fn.attn_fwd(qkv, H, P)
+    ro, rl = sdpa_ref(qkv, H)
+    # f32: exact-f32 MFMA + fp32 softmax -> 1e-5.  bf16: P is rounded to bf16 before PV (2^-9) and O to bf16 -> 6e-3
+    assert rel(o.float(), ro) < (1e-5 if prec == "f32" else 6e-3), rel(o.float(), ro)
+    assert rel(lse, rl) < 1e-5
+
+
+def test_attn_fwd_large_scores(dev):
+    """online-softmax rescale path: one key dominates from a late tile (cdna guide rule 26)."""
+    from hsenet_amd import functional as Fn, _lib as L
+    B, H, N = 1, 1, 300
+    qkv = rnd((B, N, 192), 31, dev, 0.5)
+    qkv[0, 250, 64:128] = qkv[0, 7, 0:64] * 40.0          # key 250 aligned with query 7, in the 4th key tile
+    for P, dt, tol in ((L.PREC_F32, torch.float32, 1e-5), (L.PREC_BF16, torch.bfloat16, 8e-3)):
+        x = qkv.to(dt)
+        o, lse = Fn.attn_fwd(x, H, P)
+        ro, rl = sdpa_ref(x, H)
+        assert rel(o.float(), ro) < tol
+        assert rel(lse, rl) < 1e-5
+
+
+@pytest.mark.parametrize("N", [9, 64, 65, 200, 513])
+def test_attn_bwd(dev, N):
+    from hsenet_amd import functional as Fn, _lib as L
+    B, H = 2, 2
+    qkv = rnd((B, N, 3 * H * 64), 40 + N, dev, 1.2).bfloat16()
+    d_o = rnd((B, N, H * 64), 41 + N, dev).bfloat16()
+    o, lse = Fn.attn_fwd(qkv, H, L.PREC_BF16)
+    dqkv = Fn.attn_bwd(qkv, o, d_o, lse, H)
+    x = qkv.double().requires_grad_()
+    ro, _ = sdpa_ref(x, H)
+    (g,) = torch.autograd.grad((ro * d_o.double()).sum(), x)
+    D = H * 64
+    for name, sl in (("dq", slice(0, D)), ("dk", slice(D, 2 * D)), ("dv", slice(2 * D, 3 * D))):
+        e = rel(dqkv[..., sl].float(), g[..., sl])
+        # P, dS and the outputs are rounded to bf16 (2^-9 each), delta uses the bf16-rounded O
+        assert e < 1.5e-2, (name, e)
+
+
+@pytest.mark.parametrize("rows,d", [(5, 768), (1030, 768), (64, 384), (7, 1024)])
+def test_layernorm(dev, rows, d):
+    from hsenet_amd import functional as Fn, _lib as L
+    x, r = rnd((rows, d), 50, dev, 2.0) + 0.3, rnd((rows, d), 51, dev)
+    g, b = 1 + 0.1 * rnd((d,), 52, dev), rnd((d,), 53, dev)
+    y, yb, mean, rstd = Fn.layernorm_fwd(x, g, b, resid=r, want_bf16=True)
+    xr = (x.double() + r.double()).requires_grad_()
+    gr, br = g.double().requires_grad_(), b.double().requires_grad_()
+    ref = F.layer_norm(xr, (d,), gr, br, 1e-5)
+    assert rel(y, ref) < 1e-6
+    assert rel(yb.float(), ref) < 4e-3
+    dy = rnd((rows, d), 54, dev)
+    gx, gg, gb = torch.autograd.grad((ref * dy.double()).sum(), (xr, gr, br))
+    out = Fn.LayerNormFn.apply(x.requires_grad_(), r.requires_grad_(), g.requires_grad_(), b.requires_grad_(), 1e-5)
+    out.backward(dy)
+    assert rel(x.grad, gx) < 1e-5 and rel(r.grad, gx) < 1e-5
+    assert rel(g.grad, gg) < 1e-5 and rel(b.grad, gb) < 1e-5
+
+
+@pytest.mark.parametrize("geom", [((2, 1, 8, 32, 32), (4, 16, 16)), ((1, 1, 32, 64, 48), (16, 16, 16)), ((1, 2, 4, 6, 10), (2, 3, 5))])
+@pytest.mark.parametrize("prec", ["bf16", "f32"])
+def test_patchify(dev, geom, prec):
+    from einops import rearrange
+    from hsenet_amd import _lib as L
+    shape, ps = geom
+    P = L.PREC_BF16 if prec == "bf16" else L.PREC_F32
+    vol = rnd(shape, 60, dev)
+    B, C, D, H, W = shape
+    Np, Pd = (D // ps[0]) * (H // ps[1]) * (W // ps[2]), C * ps[0] * ps[1] * ps[2]
+    out = torch.empty(B * Np, Pd, dtype=torch.bfloat16 if prec == "bf16" else torch.float32, device=dev)
+    L.call("hs_patchify", vol.data_ptr(), out.data_ptr(), B, C, D, H, W, *ps, P, torch.cuda.current_stream().cuda_stream)
+    ref = rearrange(vol, "b c (h p1) (w p2) (d p3) -> (b h w d) (p1 p2 p3 c)", p1=ps[0], p2=ps[1], p3=ps[2])
+    ref = ref.bfloat16() if prec == "bf16" else ref
+    assert torch.equal(out, ref)          # pure data movement (+ RNE cast): bit-exact
+
+
+def test_assemble_and_score(dev):
+    from hsenet_amd import functional as Fn
+    B, Np, d = 2, 24, 768
+    pe, pos, cls = rnd((B, Np, d), 70, dev).requires_grad_(), rnd((1, Np, d), 71, dev).requires_grad_(), rnd((1, 1, d), 72, dev).requires_grad_()
+    x = rnd((B, Np, d), 73, dev).requires_grad_()
+    w, b = (0.05 * rnd((1, d), 74, dev)).requires_grad_(), rnd((1,), 75, dev).requires_grad_()
+    score = Fn.RowdotSigmoidFn.apply(x, w, b)
+    tok, pe_pos = Fn.AssembleFn.apply(pe, pos, cls, score)
+    dy = rnd((B, Np + 1, d), 76, dev)
+    tok.backward(dy)
+    leaves = [t.detach().double().requires_grad_() for t in (pe, pos, cls, x, w, b)]
+    pe2, pos2, cls2, x2, w2, b2 = leaves
+    s2 = torch.sigmoid(x2 @ w2.t() + b2).squeeze(-1)
+    t2 = torch.cat([cls2.expand(B, -1, -1), (pe2 + pos2) * s2.unsqueeze(-1)], 1)
+    assert rel(tok, t2) < 1e-6 and rel(pe_pos, pe2 + pos2) < 1e-6 and rel(score, s2) < 1e-6
+    grads = torch.autograd.grad((t2 * dy.double()).sum(), leaves)
+    for mine, ref, name in zip((pe, pos, cls, x, w, b), grads, "pe pos cls x w b".split()):
+        assert rel(mine.grad, ref) < 1e-5, name
+
+
+def test_cross_attn(dev):
+    from hsenet_amd import functional as Fn
+    B, nq, nk, d = 2, 40, 32, 768
+    q, k, v = (rnd(s, 80 + i, dev).requires_grad_() for i, s in enumerate(((B, nq, d), (B, nk, d), (B, nk, d))))
+    out, p = Fn.CrossAttnFn.apply(q, k, v)
+    dy = rnd((B, nq, d), 84, dev)
+    out.backward(dy)
+    q2, k2, v2 = (t.detach().double().requires_grad_() for t in (q, k, v))
+    pr = (q2 @ k2.transpose(1, 2) / math.sqrt(d)).softmax(-1)
+    ref = pr @ v2
+    assert rel(out, ref) < 1e-5 and rel(p, pr) < 1e-5
+    for mine, r, name in zip((q, k, v), torch.autograd.grad((ref * dy.double()).sum(), (q2, k2, v2)), "qkv"):
+        assert rel(mine.grad, r) < 1e-5, name
+
+
+@pytest.mark.parametrize("grid,kernel", [((8, 16, 16), (1, 4, 4)), ((16, 16, 16), (2, 4, 4)), ((4, 4, 4), (2, 2, 2)), ((3, 5, 6), (1, 2, 3))])
+def test_pool_and_window_attn(dev, grid, kernel):
+    from hsenet_amd import functional as Fn
+    B, d = 2, 768
+    T = grid[0] * grid[1] * grid[2]
+    hr = rnd((B, *grid, d), 90, dev).requires_grad_()
+    lr = Fn.Pool3dFn.apply(hr, kernel)
+    hr2 = hr.detach().double().requires_grad_()
+    lr2 = F.avg_pool3d(hr2.permute(0, 4, 1, 2, 3), kernel_size=kernel).permute(0, 2, 3, 4, 1).reshape(B, -1, d)
+    assert rel(lr, lr2) < 1e-6
+    dl = rnd(tuple(lr.shape), 91, dev)
+    lr.backward(dl)
+    (g,) = torch.autograd.grad((lr2 * dl.double()).sum(), hr2)
+    assert rel(hr.grad, g) < 1e-6
+    if any(g_ % k_ for g_, k_ in zip(grid, kernel)):
+        return
+    cells = lr.shape[1]
+    q = rnd((B, cells, d), 92, dev).requires_grad_()
+    kv = rnd((B, T, 2 * d), 93, dev).requires_grad_()
+    out = Fn.WindowAttnFn.apply(q, kv, grid, kernel)
+    dy = rnd((B, cells, d), 94, dev)
+    out.backward(dy)
+    q2, kv2 = q.detach().double().requires_grad_(), kv.detach().double().requires_grad_()
+    kd, kh, kw = kernel
+    cd, ch, cw = grid[0] // kd, grid[1] // kh, grid[2] // kw
+
+    def windows(t):                                     # [B, T, d] -> [B, cells, nwin, d]
+        t = t.view(B, cd, kd, ch, kh, cw, kw, d).permute(0, 1, 3, 5, 2, 4, 6, 7)
+        return t.reshape(B, cells, kd * kh * kw, d)
+    kk, vv = windows(kv2[..., :d]), windows(kv2[..., d:])
+    p = (q2.unsqueeze(2) @ kk.transpose(-1, -2) / math.sqrt(d)).softmax(-1)
+    ref = (p @ vv).squeeze(2)
+    assert rel(out, ref) < 1e-5
+    gq, gkv = torch.autograd.grad((ref * dy.double()).sum(), (q2, kv2))
+    assert rel(q.grad, gq) < 1e-5 and rel(kv.grad, gkv) < 1e-5
+
+
+def test_linear_fn_and_misc(dev):
+    from hsenet_amd import functional as Fn, _lib as L
+    x = rnd((3, 50, 768), 100, dev).requires_grad_()
+    w, b = (0.03 * rnd((1536, 768), 101, dev)).requires_grad_(), rnd((1536,), 102, dev).requires_grad_()
+    dy = rnd((3, 50, 1536), 103, dev)
+    for P, tol in ((L.PREC_F32, 1e-5), (L.PREC_BF16, 6e-3)):
+        for t in (x, w, b):
+            t.grad = None
+        y = Fn.LinearFn.apply(x, w, b, P)
+        y.backward(dy)
+        x2, w2, b2 = (t.detach().double().requires_grad_() for t in (x, w, b))
+        ref = F.linear(x2, w2, b2)
+        assert rel(y, ref) < tol
+        for mine, r, name in zip((x, w, b), torch.autograd.grad((ref * dy.double()).sum(), (x2, w2, b2)), "xwb"):
+            assert rel(mine.grad, r) < tol, (name, rel(mine.grad, r))
+    # gelu / l2norm
+    z = rnd((1000,), 104, dev).requires_grad_()
+    g = Fn.GeluFn.apply(z)
+    g.backward(torch.ones_like(g))
+    z2 = z.detach().double().requires_grad_()
+    r = F.gelu(z2)
+    assert rel(g, r) < 1e-6 and rel(z.grad, torch.autograd.grad(r.sum(), z2)[0]) < 1e-5
+    u = rnd((9, 768), 105, dev).requires_grad_()
+    n = Fn.L2NormFn.apply(u, 1e-12)
+    dn = rnd((9, 768), 106, dev)
+    n.backward(dn)
+    u2 = u.detach().double().requires_grad_()
+    rn = F.normalize(u2, dim=-1)
+    assert rel(n, rn) < 1e-6 and rel(u.grad, torch.autograd.grad((rn * dn.double()).sum(), u2)[0]) < 1e-5
+    # colsum + casts
+    m = rnd((777, 768), 107, dev)
+    out = torch.zeros(768, device=dev)
+    Fn.colsum(m.bfloat16(), out)
+    assert rel(out, m.bfloat16().double().sum(0)) < 1e-5
+    assert torch.equal(Fn.cast_bf16(m), m.bfloat16()) and torch.equal(Fn.cast_f32(m.bfloat16()), m.bfloat16().float())
+
+
+def test_adamw(dev):
+    from hsenet_amd import functional as Fn
+    n = 10007
+    p, g = rnd((n,), 110, dev), rnd((n,), 111, dev)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    pr = p.clone().requires_grad_()
+    opt = torch.optim.AdamW([pr], lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.05)
+    for step in (1, 2, 3):
+        pr.grad = g.clone() * step
+        opt.step()
+        Fn.adamw_step(p, g * step, m, v, lr=1e-2, weight_decay=0.05, step=step)
+    assert rel(p, pr.detach()) < 1e-6
