@@ -459,7 +459,8 @@ class BlocksFn(torch.autograd.Function):
         _need(x0, *params)
         B, N, d = x0.shape
         Ln = (len(params) - 2) // 11
-        need_grad = torch.is_grad_enabled() and (x0.requires_grad or any(p.requires_grad for p in params))
+        # (autograd.Function.forward runs with grad mode off: ask ctx which inputs need gradients)
+        need_grad = any(ctx.needs_input_grad)
         if need_grad and prec != L.PREC_BF16:
             raise L.HsError("the fused block stack differentiates in bf16 mode only (f32 is the forward parity mode)")
         desc = L.VitDesc(B, N, d, H, mlp, Ln, prec, int(need_grad))

@@ -70,8 +70,8 @@ def test_gemm_epilogues(dev):
     (g,) = torch.autograd.grad(F.gelu(zr).sum(), zr)
     assert rel(o32, acc * g) < 1e-4
     # split-K atomic accumulate on top of an existing value, alpha
-    base = rnd((M, N), 8, dev)
     Mo = 336
+    base = rnd((Mo, N), 8, dev)
     a2 = rnd((1000, Mo), 9, dev).bfloat16()                         # stored [K=1000][M'=336]
     b2 = rnd((1000, N), 10, dev).bfloat16()                         # stored [K=1000][N]
     o = base[:Mo].clone()

@@ -17,6 +17,20 @@ def rel(a, b):
     return float((a - b).norm() / b.norm().clamp_min(1e-30))
 
 
+def grad_errs(named_mine, named_ref):
+    """per-parameter ||g - g_ref|| / max(||g_ref||, floor): the floor (1e-3 of the largest per-element RMS gradient,
+    scaled to the tensor's size) keeps mathematically-zero gradients — e.g. Wk.bias of a softmax attention, to
+    which the output is invariant — from turning rounding noise into a huge relative error."""
+    ref = {n: p.grad.double().cpu() for n, p in named_ref}
+    rms = max(float(g.norm()) / g.numel() ** 0.5 for g in ref.values())
+    out = {}
+    for n, p in named_mine:
+        assert p.grad is not None, n
+        g = ref[n]
+        out[n] = float((p.grad.double().cpu() - g).norm() / max(float(g.norm()), 1e-3 * rms * g.numel() ** 0.5))
+    return out
+
+
 def _load(mod, ref_module, seed, dev):
     from oracle import ref_cpu as R
     sd = R.seeded_state_dict(ref_module, seed)
@@ -182,7 +196,7 @@ def test_backward_vs_oracle(dev):
     x = R.synthetic_volume((B, 1) + img, 201)
     s = R.synthetic_slices(B, 202)
     for cls_h, cls_r, seed, args in ((H.ViT_stage1, R.ViT_stage1, 203, (x,)), (H.ViT_stage2, R.ViT_stage2, 204, (x, s))):
-        ref = cls_r(**kw)
+        ref = cls_r(**kw).eval()      # eval: regular_attention's hard-coded dropouts off (DESIGN.md 'Dropout')
         sd = R.seeded_state_dict(ref, seed)
         ref.load_state_dict(sd)
         yr, _ = ref(*args)
@@ -194,14 +208,10 @@ def test_backward_vs_oracle(dev):
         y, _ = m(*[a.to(dev) for a in args])
         assert rel(y, yr.detach()) < TOL_BF16
         (y * w.to(dev)).sum().backward()
-        worst = ("", 0.0)
-        for (name, p), (_, pr) in zip(m.named_parameters(), ref.named_parameters()):
-            assert p.grad is not None, name
-            e = rel(p.grad, pr.grad)
-            if e > worst[1]:
-                worst = (name, e)
-            assert e < 5e-2, (cls_h.__name__, name, e)
-        print(f"{cls_h.__name__} backward worst grad err: {worst[0]} {worst[1]:.2e}")
+        errs = grad_errs(m.named_parameters(), ref.named_parameters())
+        worst = max(errs, key=errs.get)
+        print(f"{cls_h.__name__} backward worst grad err: {worst} {errs[worst]:.2e}")
+        assert errs[worst] < 5e-2, (cls_h.__name__, worst, errs[worst])
 
 
 def test_packer_backward_vs_oracle(dev):
@@ -224,6 +234,7 @@ def test_packer_backward_vs_oracle(dev):
     (y * w.to(dev)).sum().backward()
     assert rel(y, yr.detach()) < TOL_BF16
     assert rel(xd.grad, xr.grad) < 5e-2
-    for (name, p), (_, pr) in zip(m.named_parameters(), ref.named_parameters()):
-        e = rel(p.grad, pr.grad)
-        assert e < 5e-2, (name, e)
+    errs = grad_errs(m.named_parameters(), ref.named_parameters())
+    worst = max(errs, key=errs.get)
+    print(f"packer backward worst grad err: {worst} {errs[worst]:.2e}")
+    assert errs[worst] < 5e-2, (worst, errs[worst])
