@@ -69,11 +69,16 @@ SIGNATURES = {
     "hs_l2norm_fwd": [_vp, _vp, _i, _i, _f, _vp],
     "hs_l2norm_bwd": [_vp, _vp, _vp, _i, _i, _f, _vp],
     "hs_adamw": [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _f, _i, _vp],
+    "hs_scale": [_vp, _vp, _f, _i64, _vp],
+    "hs_prof_enable": [_i],
+    "hs_prof_read": [_i, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)],
+    "hs_prof_name": [_i],
+    "hs_prof_count": [],
     "hs_vit_workspace_bytes": [C.POINTER(VitDesc)],
     "hs_vit_blocks_fwd": [C.POINTER(VitDesc), _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
     "hs_vit_blocks_bwd": [C.POINTER(VitDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _vp],
 }
-_RESTYPE = {"hs_vit_workspace_bytes": _sz}
+_RESTYPE = {"hs_vit_workspace_bytes": _sz, "hs_prof_name": C.c_char_p}
 
 _lib = None
 _lock = threading.Lock()

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libhsenet_hip.so")
-SOURCES = ["gemm.hip", "attn.hip", "norm.hip", "small.hip", "vit.hip"]
+SOURCES = ["gemm.hip", "attn.hip", "norm.hip", "small.hip", "vit.hip", "prof.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 

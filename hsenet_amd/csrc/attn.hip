@@ -514,6 +514,8 @@ extern "C" int hs_attn_fwd(const void* qkv, void* o, float* lse, int B, int N, i
     const float scale = 0.125f;  // dh^-0.5
     dim3 grid((N + 127) / 128, H, B);
     hipStream_t s = (hipStream_t)stream;
+    const double nn = (double)B * H * N * N * 64;
+    ProfScope prof(HS_PROF_ATTN_FWD, stream, 4.0 * nn, (double)B * N * H * 64 * 4 * esz);
     if (prec == HS_PREC_BF16) {
         if (!lse) return HS_ERR_ARG;
         hipLaunchKernelGGL(attn_fwd_bf16_kernel, grid, dim3(256), 0, s, (const bf16_t*)qkv, (bf16_t*)o, lse, N, H, scale);
@@ -535,13 +537,24 @@ extern "C" int hs_attn_bwd(const void* qkv, const void* o, const void* d_o, cons
     const float scale = 0.125f;
     hipStream_t s = (hipStream_t)stream;
     const long total = (long)B * N * H * 8;
-    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const bf16_t*)o,
-                       (const bf16_t*)d_o, delta_ws, B, N, H);
+    const double nn = (double)B * H * N * N * 64;   // algorithmic bwd = 5 products = 10*nn, split 6:4 over the two kernels
+    const double io = (double)B * N * H * 64 * 2;
+    {
+        ProfScope prof(HS_PROF_ATTN_DELTA, stream, 0, 2 * io);
+        hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const bf16_t*)o,
+                           (const bf16_t*)d_o, delta_ws, B, N, H);
+    }
     dim3 grid((N + 127) / 128, H, B);
-    hipLaunchKernelGGL(attn_bwd_dkdv_kernel, grid, dim3(256), 0, s, (const bf16_t*)qkv, (const bf16_t*)d_o, lse, delta_ws,
-                       (bf16_t*)dqkv, N, H, scale);
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, s, (const bf16_t*)qkv, (const bf16_t*)d_o, lse, delta_ws,
-                       (bf16_t*)dqkv, N, H, scale);
+    {
+        ProfScope prof(HS_PROF_ATTN_DKDV, stream, 6.0 * nn, 6 * io);
+        hipLaunchKernelGGL(attn_bwd_dkdv_kernel, grid, dim3(256), 0, s, (const bf16_t*)qkv, (const bf16_t*)d_o, lse, delta_ws,
+                           (bf16_t*)dqkv, N, H, scale);
+    }
+    {
+        ProfScope prof(HS_PROF_ATTN_DQ, stream, 4.0 * nn, 5 * io);
+        hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, s, (const bf16_t*)qkv, (const bf16_t*)d_o, lse, delta_ws,
+                           (bf16_t*)dqkv, N, H, scale);
+    }
     HS_CHECK_LAUNCH();
     return HS_OK;
 }

@@ -83,6 +83,18 @@ __device__ __forceinline__ bf16x8 cat4(bf16x4 a, bf16x4 b) {
     return r;
 }
 
+// per-kernel-class profiling (prof.hip); ids mirror hs_prof_name()
+enum { HS_PROF_GEMM_NT = 0, HS_PROF_GEMM_NN, HS_PROF_GEMM_TN, HS_PROF_ATTN_FWD, HS_PROF_ATTN_DELTA, HS_PROF_ATTN_DKDV,
+       HS_PROF_ATTN_DQ, HS_PROF_LN_FWD, HS_PROF_LN_BWD, HS_PROF_COLSUM, HS_PROF_CAST, HS_PROF_PATCHIFY, HS_PROF_OTHER,
+       HS_PROF_COUNT };
+int hs_prof_begin(int id, void* stream, double flops, double bytes);
+void hs_prof_end(int token, void* stream);
+struct ProfScope {
+    int tok; void* s;
+    ProfScope(int id, void* stream, double flops = 0, double bytes = 0) : tok(hs_prof_begin(id, stream, flops, bytes)), s(stream) {}
+    ~ProfScope() { hs_prof_end(tok, s); }
+};
+
 #define HS_CHECK_LAUNCH()                                   \
     do {                                                    \
         hipError_t e__ = hipGetLastError();                 \

@@ -301,6 +301,9 @@ extern "C" int hs_gemm(const hs_gemm_args* a, int prec, void* stream) {
     p.aux_out = a->aux_out; p.alpha = a->alpha; p.flags = a->flags; p.split_k = a->split_k;
     hipStream_t s = (hipStream_t)stream;
     const int zdim = a->split_k > 1 ? a->split_k : a->batch;
+    const double mnk = (double)a->M * a->N * a->K * a->batch;
+    ProfScope prof(HS_PROF_GEMM_NT + a->layout, stream, 2.0 * mnk,
+                   ((double)a->M * a->K + (double)a->N * a->K) * a->batch * esz + (double)a->M * a->N * a->batch * (a->out_f32 ? 4 : 2));
     if (prec == HS_PREC_BF16) {
         p.tiles_m = (a->M + 127) / 128;
         dim3 grid(p.tiles_m * ((a->N + 127) / 128), 1, zdim);

@@ -150,6 +150,7 @@ extern "C" int hs_layernorm_fwd(const float* x, const float* resid, const float*
                                 void* y_bf16, float* mean, float* rstd, int rows, int d, float eps, void* stream) {
     if (!x || !gamma || !beta || (!y_f32 && !y_bf16)) return HS_ERR_ARG;
     if (rows < 1 || d < 4 || (d & 3) || d > LN_MAXCH * 256) return HS_ERR_SHAPE;
+    ProfScope prof(HS_PROF_LN_FWD, stream, 0, (double)rows * d * (4 + (resid ? 4 : 0) + (y_f32 ? 4 : 0) + (y_bf16 ? 2 : 0)));
     hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, resid, gamma, beta,
                        y_f32, (bf16_t*)y_bf16, mean, rstd, rows, d, eps);
     HS_CHECK_LAUNCH();
@@ -163,6 +164,7 @@ extern "C" int hs_layernorm_bwd(const float* dy, const float* x, const float* re
     if (rows < 1 || d < 4 || (d & 3) || d > LN_MAXCH * 256) return HS_ERR_SHAPE;
     int blocks = (rows + 3) / 4;
     if (blocks > 1024) blocks = 1024;
+    ProfScope prof(HS_PROF_LN_BWD, stream, 0, (double)rows * d * (8 + (resid ? 4 : 0) + (dx_in ? 4 : 0) + (dx ? 4 : 0) + (dx_bf16 ? 2 : 0)));
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, x, resid, gamma, mean, rstd,
                        dx_in, dx, (bf16_t*)dx_bf16, dgamma, dbeta, rows, d);
     HS_CHECK_LAUNCH();

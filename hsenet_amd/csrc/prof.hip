@@ -1,0 +1,71 @@
+// Optional per-kernel-class timing with HIP events recorded on the SAME stream the kernels are launched on
+// (bench.py's roofline leg).  Off by default: when off, hs_prof_begin/end are a load and a branch.
+// hs_prof_read() is the only entry point in the library that synchronises (hipEventSynchronize), and it is
+// never called from a launch path.
+#include "common.h"
+#include <vector>
+#include <mutex>
+
+namespace {
+struct Rec { int id; hipEvent_t a, b; };
+std::vector<Rec> g_recs;
+std::vector<hipEvent_t> g_pool;
+double g_flops[HS_PROF_COUNT];
+double g_bytes[HS_PROF_COUNT];
+bool g_on = false;
+std::mutex g_mu;
+
+hipEvent_t get_event() {
+    if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+    hipEvent_t e;
+    hipEventCreate(&e);
+    return e;
+}
+}  // namespace
+
+int hs_prof_begin(int id, void* stream, double flops, double bytes) {
+    if (!g_on) return -1;
+    std::lock_guard<std::mutex> lk(g_mu);
+    Rec r;
+    r.id = id; r.a = get_event(); r.b = get_event();
+    hipEventRecord(r.a, (hipStream_t)stream);
+    g_recs.push_back(r);
+    g_flops[id] += flops;
+    g_bytes[id] += bytes;
+    return (int)g_recs.size() - 1;
+}
+void hs_prof_end(int token, void* stream) {
+    if (token < 0) return;
+    std::lock_guard<std::mutex> lk(g_mu);
+    hipEventRecord(g_recs[token].b, (hipStream_t)stream);
+}
+
+extern "C" int hs_prof_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (auto& r : g_recs) { g_pool.push_back(r.a); g_pool.push_back(r.b); }
+    g_recs.clear();
+    for (int i = 0; i < HS_PROF_COUNT; ++i) { g_flops[i] = 0; g_bytes[i] = 0; }
+    g_on = on != 0;
+    return HS_OK;
+}
+extern "C" int hs_prof_read(int id, int* count, double* total_ms, double* flops, double* bytes) {
+    if (id < 0 || id >= HS_PROF_COUNT || !count || !total_ms) return HS_ERR_ARG;
+    std::lock_guard<std::mutex> lk(g_mu);
+    int c = 0;
+    double t = 0;
+    for (auto& r : g_recs) {
+        if (r.id != id) continue;
+        if (hipEventSynchronize(r.b) != hipSuccess) return HS_ERR_LAUNCH;
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) return HS_ERR_LAUNCH;
+        t += ms;
+        ++c;
+    }
+    *count = c; *total_ms = t;
+    if (flops) *flops = g_flops[id];
+    if (bytes) *bytes = g_bytes[id];
+    return HS_OK;
+}
+static const char* kNames[HS_PROF_COUNT] = {"gemm_nt", "gemm_nn", "gemm_tn", "attn_fwd", "attn_bwd_delta", "attn_bwd_dkdv",
+                                            "attn_bwd_dq", "layernorm_fwd", "layernorm_bwd", "colsum", "cast", "patchify", "other"};
+extern "C" const char* hs_prof_name(int id) { return (id >= 0 && id < HS_PROF_COUNT) ? kNames[id] : ""; }

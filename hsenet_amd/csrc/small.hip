@@ -65,6 +65,7 @@ extern "C" int hs_patchify(const float* vol, void* out, int B, int C, int D, int
     if (B < 1 || C < 1 || p1 < 1 || p2 < 1 || p3 < 1 || D % p1 || H % p2 || W % p3) return HS_ERR_SHAPE;
     if (prec != HS_PREC_BF16 && prec != HS_PREC_F32) return HS_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(HS_PROF_PATCHIFY, stream, 0, (double)B * C * D * H * W * (prec == HS_PREC_BF16 ? 6 : 8));
     if (C == 1 && (p3 % 8) == 0 && !(((uintptr_t)vol | (uintptr_t)out) & 15)) {
         const long total = (long)B * D * H * (W / 8);
         dim3 grid((unsigned)((total + 255) / 256));
@@ -570,6 +571,7 @@ extern "C" int hs_colsum(const void* x, int is_bf16, float* out, int M, int N, i
     if (M < 1 || N < V || (N % V) || (ldx % V) || ((uintptr_t)x & 15)) return HS_ERR_SHAPE;
     const int rpb = 512;
     dim3 grid((N + 32 * V - 1) / (32 * V), (M + rpb - 1) / rpb);
+    ProfScope prof(HS_PROF_COLSUM, stream, 0, (double)M * N * (is_bf16 ? 2 : 4));
     if (is_bf16) hipLaunchKernelGGL(colsum_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, out, M, N, (long)ldx, rpb);
     else hipLaunchKernelGGL(colsum_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, out, M, N, (long)ldx, rpb);
     HS_CHECK_LAUNCH();
@@ -605,6 +607,7 @@ __global__ __launch_bounds__(256) void cast_f32_kernel(const bf16_t* __restrict_
 extern "C" int hs_cast_bf16(const float* x, void* y, int64_t n, void* stream) {
     if (!x || !y) return HS_ERR_ARG;
     if (n < 1 || (((uintptr_t)x | (uintptr_t)y) & 15)) return HS_ERR_SHAPE;
+    ProfScope prof(HS_PROF_CAST, stream, 0, (double)n * 6);
     hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)((n + 2047) / 2048)), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)y, (long)n);
     HS_CHECK_LAUNCH();
     return HS_OK;
@@ -705,6 +708,24 @@ extern "C" int hs_adamw(float* p, const float* g, float* m, float* v, int64_t n,
     HS_CHECK_LAUNCH();
     return HS_OK;
 }
+
+__global__ __launch_bounds__(256) void scale_kernel(const float* __restrict__ x, float* __restrict__ y, float alpha, long n) {
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i + 4 <= n) {
+        *(f32x4*)(y + i) = *(const f32x4*)(x + i) * alpha;
+    } else {
+        for (long j = i; j < n; ++j) y[j] = x[j] * alpha;
+    }
+}
+extern "C" int hs_scale(const float* x, float* y, float alpha, int64_t n, void* stream) {
+    if (!x || !y) return HS_ERR_ARG;
+    if (n < 1 || (((uintptr_t)x | (uintptr_t)y) & 15)) return HS_ERR_SHAPE;
+    ProfScope prof(HS_PROF_OTHER, stream, 0, (double)n * 8);
+    hipLaunchKernelGGL(scale_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, x, y, alpha, (long)n);
+    HS_CHECK_LAUNCH();
+    return HS_OK;
+}
+extern "C" int hs_prof_count(void) { return HS_PROF_COUNT; }
 
 extern "C" int hs_version(void) { return 1; }
 extern "C" int hs_device_check(int dev) {

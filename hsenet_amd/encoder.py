@@ -164,7 +164,8 @@ class _ViTBase(nn.Module):
 
     def _stack(self, tokens, prec):
         params = [p for blk in self.blocks for p in blk.ordered_params()] + [self.norm.weight, self.norm.bias]
-        y, hidden = Fn.BlocksFn.apply(tokens, self.num_heads, self.mlp_dim, prec, *params)
+        need_grad = torch.is_grad_enabled() and (tokens.requires_grad or any(p.requires_grad for p in params))
+        y, hidden = Fn.BlocksFn.apply(tokens, self.num_heads, self.mlp_dim, prec, need_grad, *params)
         return y, [hidden[i] for i in range(hidden.shape[0])]
 
 

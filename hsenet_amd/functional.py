@@ -453,14 +453,14 @@ class BlocksFn(torch.autograd.Function):
     differentiate the hidden-state list)."""
 
     @staticmethod
-    def forward(ctx, x0, H, mlp, prec, *params):
+    def forward(ctx, x0, H, mlp, prec, need_grad, *params):
         x0 = _f32(x0).contiguous()
         params = tuple(p.contiguous() for p in params)
         _need(x0, *params)
         B, N, d = x0.shape
         Ln = (len(params) - 2) // 11
-        # (autograd.Function.forward runs with grad mode off: ask ctx which inputs need gradients)
-        need_grad = any(ctx.needs_input_grad)
+        # need_grad is decided by the caller (grad mode is off inside Function.forward, and
+        # ctx.needs_input_grad ignores torch.no_grad())
         if need_grad and prec != L.PREC_BF16:
             raise L.HsError("the fused block stack differentiates in bf16 mode only (f32 is the forward parity mode)")
         desc = L.VitDesc(B, N, d, H, mlp, Ln, prec, int(need_grad))
@@ -491,4 +491,4 @@ class BlocksFn(torch.autograd.Function):
         lg, ng = _ptr_array(grads[:-2]), _ptr_array(grads[-2:])
         L.call("hs_vit_blocks_bwd", C.byref(desc), x0.data_ptr(), lp, npar, dy.data_ptr(), dx0.data_ptr(), lg, ng, hidden.data_ptr(),
                ws.data_ptr() + ctx.ws_off, ctx.nbytes, desc.L, 0, _s())
-        return (dx0, None, None, None, *grads)
+        return (dx0, None, None, None, None, *grads)

@@ -154,6 +154,18 @@ int hs_l2norm_bwd(const float* x, const float* dy, float* dx, int rows, int d, f
 int hs_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
              float weight_decay, float grad_scale, int step, void* stream);
 
+/* y = alpha * x (fp32): the synthetic bench loss gradient dL/dy = y * 2/numel of L = mean(y^2) */
+int hs_scale(const float* x, float* y, float alpha, int64_t n, void* stream);
+
+/* ---- measurement: per-kernel-class timing with HIP events on the launch stream (bench.py roofline leg).
+ * hs_prof_enable(1) clears and starts recording, (0) stops.  hs_prof_read synchronises on the recorded events
+ * (the only synchronising call in the library) and returns launches, summed duration, and the algorithmic
+ * FLOPs / bytes the launches accounted for.  Class ids 0..hs_prof_count()-1, names from hs_prof_name(). */
+int hs_prof_enable(int on);
+int hs_prof_read(int id, int* count, double* total_ms, double* flops, double* bytes);
+const char* hs_prof_name(int id);
+int hs_prof_count(void);
+
 /* ---- fused encoder driver: the hot loops vit.py:464-467 / 352-355 (12 x MONAI TransformerBlock + final norm) as
  * one enqueue.  All pointers are device pointers.
  * layer_params: L*11 fp32 tensors in MONAI state-dict order per block:
