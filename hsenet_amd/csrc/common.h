@@ -55,9 +55,14 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // Buffer descriptor with hardware range checking: loads past `bytes` return 0.
+// The descriptor inputs go through readfirstlane so the compiler can PROVE it wave-uniform; otherwise it wraps every
+// buffer op in a serialising "waterfall" loop (cdna guide T20).  All callers pass block-uniform bases.
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, size_t bytes) {
     unsigned n = bytes > (size_t)HS_MAX_RECORDS ? HS_MAX_RECORDS : (unsigned)bytes;
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, n, 0x00020000);
+    const unsigned long long a = (unsigned long long)base;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    n = __builtin_amdgcn_readfirstlane(n);
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, n, 0x00020000);
 }
 __device__ __forceinline__ u32x4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned off) {
     return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);

@@ -1,8 +1,7 @@
 // K3: GEMM family  C[M,N] = sum_k A(m,k) B(n,k)  with fused epilogues (see include/hsenet_hip.h).
 //
-// bf16 kernel: 128x128x64 block tile, 4 waves (2x2), each wave 64x64 = 2x2 v_mfma_f32_32x32x16_bf16 blocks.
-// Operands are staged global -> registers (range-checked buffer loads: every M/N/K tail reads as 0)
-// -> LDS (write AFTER the MFMA phase of the current tile, one barrier per K-tile; cdna guide T14).
+// bf16 kernel: 256x128x64 block tile, 8 waves, each wave 64x64 = 2x2 v_mfma_f32_32x32x16_bf16 blocks; operand
+// tiles arrive by LDS-DMA into a 3-stage ring (details at the kernel).
 // An operand whose k index is contiguous in memory lives in LDS image R (ds_read_b128 row reads); an
 // operand stored [K][dim] lives in image T and is read with ds_read_b64_tr_b16 (hardware transpose),
 // so NT / NN / TN all feed the same MFMA loop and no transposed copies of weights or activations exist.
@@ -44,56 +43,169 @@ __device__ __forceinline__ void epilogue_store(const GemmP& p, long cz, int m, i
 }
 
 // ------------------------------------------------------------------------------------------------------
-// bf16
+// bf16: 256x128x64 tile, 8 waves (4 along M x 2 along N), wave tile 64x64.
+// Operand tiles go global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds: no VGPR staging, no ds_write), with
+// the buffer descriptor's range check zero-filling every M/N/K tail.  LDS-DMA writes lane-linearly, so the
+// bank swizzle of images R/T is applied to the per-lane SOURCE address (cdna guide rule 21) and again on the
+// fragment reads.  3-stage ring: tile t+2 is issued right after the barrier of step t, so two tiles are in flight
+// while one is consumed; waits are counted (s_waitcnt vmcnt(6) = "all but the newest tile's 6 loads"), barriers raw.
+// The epilogue is staged through LDS (see the kernel's tail) so that stores/atomics are whole row segments.
 // ------------------------------------------------------------------------------------------------------
+#define G_STAGE 49152   // A 32 KiB + B 16 KiB
+#define G_NSTAGE 3
+
+// fast erf (Abramowitz-Stegun 7.1.26, |err| <= 1.5e-7) sharing exp(-x^2/2) between GELU and its derivative
+__device__ __forceinline__ void gelu_parts(float x, float& cdf, float& pdf_x) {
+    const float u = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * u);
+    const float e = __expf(-u * u);
+    const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
+    const float erf_abs = 1.0f - poly * e;
+    cdf = 0.5f * (1.0f + copysignf(erf_abs, x));
+    pdf_x = x * 0.3989422804014327f * e;
+}
+
+// LDS-DMA of one operand tile.  One wave-instruction = 1 KiB of LDS (R image: 8 rows x 128 B; T image: 4 rows x
+// 256 B).  Piece j of this wave (j < NP) is piece index j*8 + wave of the operand's stage area.
+// dma_voff(): the per-lane byte offset of piece j at k0 = 0, HS_OOB_OFF for rows/cols outside the matrix.  Full
+// K-tiles then only add a wave-uniform scalar offset (kt * kstep bytes); a partial last K-tile recomputes the
+// offsets with the k bound (dma_voff with K) so the descriptor's range check zero-fills the k tail.
 template <bool TR>
-__device__ __forceinline__ void bf_gload(u32x4 (&reg)[4], __amdgpu_buffer_rsrc_t rs, int dim0, int DIM, int k0,
-                                         int K, long ld, int tid) {
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int idx = it * 256 + tid;
-        unsigned off;
-        if (!TR) {
-            const int gi = dim0 + (idx >> 3), gk = k0 + (idx & 7) * 8;
-            off = (gi < DIM && gk < K) ? (unsigned)(((long)gi * ld + gk) * 2) : HS_OOB_OFF;
-        } else {
-            const int gk = k0 + (idx >> 4), gi = dim0 + (idx & 15) * 8;
-            off = (gk < K && gi < DIM) ? (unsigned)(((long)gk * ld + gi) * 2) : HS_OOB_OFF;
-        }
-        reg[it] = buf_load16(rs, off);
+__device__ __forceinline__ unsigned dma_voff(int j, int dim0, int DIM, int k0, int K, long ld, int wave, int lane) {
+    const int piece = j * 8 + wave;
+    if (!TR) {
+        const int row = piece * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ swzR(row);
+        const int gi = dim0 + row, gk = k0 + c * 8;
+        return (gi < DIM && gk < K) ? (unsigned)(((long)gi * ld + gk) * 2) : HS_OOB_OFF;
+    } else {
+        const int sub = piece >> 4;                 // 128-wide sub-image (16 pieces each)
+        const int row = (piece & 15) * 4 + (lane >> 4);
+        const int c = (lane & 15) ^ (((row & 3) << 2) | ((row >> 2) & 3));
+        const int gk = k0 + row, gi = dim0 + sub * 128 + c * 8;
+        return (gk < K && gi < DIM) ? (unsigned)(((long)gk * ld + gi) * 2) : HS_OOB_OFF;
     }
 }
-template <bool TR>
-__device__ __forceinline__ void bf_swrite(const u32x4 (&reg)[4], char* lds, int tid) {
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int idx = it * 256 + tid;
-        const int o = TR ? offT(idx >> 4, idx & 15) : offR(idx >> 3, idx & 7);
-        *(u32x4*)(lds + o) = reg[it];
-    }
+__device__ __forceinline__ void dma_piece(__amdgpu_buffer_rsrc_t rs, char* lds_area, int j, int wave, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (LDS_PTR(void))(lds_area + (j * 8 + wave) * 1024), 16, voff, soff, 0, 0);
 }
-// MFMA 32x32x16 operand fragment for the 32-wide block starting at `sub` of the 128-wide tile, k-step ks.
+// fragment of the 32-wide block starting at `sub` (0..255) of an operand image, k-step ks
 template <bool TR>
-__device__ __forceinline__ bf16x8 bf_frag(const char* lds, int sub, int ks, int lane) {
+__device__ __forceinline__ bf16x8 g_frag(const char* lds, int sub, int ks, int lane) {
     if (!TR) {
         return *(const bf16x8*)(lds + offR(sub + (lane & 31), 2 * ks + (lane >> 5)));
     } else {
+        const char* img = lds + (sub >> 7) * 16384;
         const int g = lane >> 4, h = g >> 1, p = lane & 3, q = (lane >> 2) & 3;
-        const int col = sub + 16 * (g & 1) + 4 * p;
+        const int col = (sub & 127) + 16 * (g & 1) + 4 * p;
         const int r1 = ks * 16 + 8 * h + q;
-        const bf16x4 a = lds_tr16(lds + offT(r1, col >> 3) + 8 * (p & 1));
-        const bf16x4 b = lds_tr16(lds + offT(r1 + 4, col >> 3) + 8 * (p & 1));
+        const bf16x4 a = lds_tr16(img + offT(r1, col >> 3) + 8 * (p & 1));
+        const bf16x4 b = lds_tr16(img + offT(r1 + 4, col >> 3) + 8 * (p & 1));
         return cat4(a, b);
     }
 }
 
+// 4 consecutive n of one output row m
+__device__ __forceinline__ void epilogue_vec4(const GemmP& p, long cz, int m, int n, f32x4 v, bool vec_ok) {
+    if (m >= p.M || n >= p.N) return;
+    if (!vec_ok || n + 3 >= p.N) {   // rare path (N or ldc not a multiple of 4): element-wise, kept rolled
+#pragma unroll 1
+        for (int e = 0; e < 4; ++e) epilogue_store<false>(p, cz, m, n + e, v[e]);
+        return;
+    }
+    v *= p.alpha;
+    if (p.flags & HS_EPI_BIAS) {
+        if (p.flags & HS_EPI_BIAS_M) v += p.bias[m]; else v += *(const f32x4*)(p.bias + n);
+    }
+    const long idx = cz + (long)m * p.ldc + n;
+    if (p.flags & HS_EPI_GELU) {
+        u32x2 zb;
+        zb[0] = pack2bf(v[0], v[1]); zb[1] = pack2bf(v[2], v[3]);       // autocast: linear1 emits bf16
+        if (p.aux_out) *(u32x2*)((bf16_t*)p.aux_out + idx) = zb;
+        v[0] = __uint_as_float(zb[0] << 16); v[1] = __uint_as_float(zb[0] & 0xffff0000u);
+        v[2] = __uint_as_float(zb[1] << 16); v[3] = __uint_as_float(zb[1] & 0xffff0000u);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { float c, px; gelu_parts(v[e], c, px); v[e] *= c; }
+    }
+    if (p.flags & HS_EPI_GELU_BWD) {
+        const u32x2 zb = *(const u32x2*)((const bf16_t*)p.aux + idx);
+        const float z[4] = {__uint_as_float(zb[0] << 16), __uint_as_float(zb[0] & 0xffff0000u),
+                            __uint_as_float(zb[1] << 16), __uint_as_float(zb[1] & 0xffff0000u)};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { float c, px; gelu_parts(z[e], c, px); v[e] *= (c + px); }
+    }
+    if (p.flags & HS_EPI_RESID) v += *(const f32x4*)(p.resid + idx);
+    if (p.out_f32) {
+        if (p.flags & HS_EPI_ATOMIC) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) atomicAdd(&p.out_f32[idx + e], v[e]);
+        } else {
+            *(f32x4*)(p.out_f32 + idx) = v;
+        }
+    }
+    if (p.out_bf16) {
+        u32x2 o;
+        o[0] = pack2bf(v[0], v[1]); o[1] = pack2bf(v[2], v[3]);
+        *(u32x2*)((bf16_t*)p.out_bf16 + idx) = o;
+    }
+}
+
+// one K-tile of MFMA work for a wave (4 k-steps x 2x2 blocks), with the DMA pieces of K-tile `ktn` issued behind
+// the MFMA groups.  MODE 0: no prefetch; 1: full K-tile (hoisted offsets + scalar advance); 2: partial last K-tile.
+template <bool ATR, bool BTR, int MODE>
+__device__ __forceinline__ void ktile_step(f32x16 (&acc)[2][2], const char* a_l, const char* b_l, char* nxt, int wm, int wn, int wave,
+                                           int lane, __amdgpu_buffer_rsrc_t rsA, __amdgpu_buffer_rsrc_t rsB, const unsigned (&va)[4],
+                                           const unsigned (&vb)[2], unsigned sa, unsigned sb, const GemmP& p, int m0, int n0, int ktn) {
+    auto piece = [&](int q) {
+        if (MODE == 1) {
+            if (q < 4) dma_piece(rsA, nxt, q, wave, va[q], sa); else dma_piece(rsB, nxt + 32768, q - 4, wave, vb[q - 4], sb);
+        } else if (MODE == 2) {
+            if (q < 4) dma_piece(rsA, nxt, q, wave, dma_voff<ATR>(q, m0, p.M, ktn * 64, p.K, p.lda, wave, lane), 0);
+            else dma_piece(rsB, nxt + 32768, q - 4, wave, dma_voff<BTR>(q - 4, n0, p.N, ktn * 64, p.K, p.ldb, wave, lane), 0);
+        }
+    };
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 a0 = g_frag<ATR>(a_l, wm * 64, ks, lane);
+        const bf16x8 a1 = g_frag<ATR>(a_l, wm * 64 + 32, ks, lane);
+        const bf16x8 b0 = g_frag<BTR>(b_l, wn * 64, ks, lane);
+        const bf16x8 b1 = g_frag<BTR>(b_l, wn * 64 + 32, ks, lane);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+        if (MODE != 0) {   // pieces (0,1) (2,3) (4) (5): their issue cost sits behind an MFMA group, not in front of one
+            if (ks < 2) { piece(2 * ks); piece(2 * ks + 1); } else piece(ks + 2);
+        }
+    }
+}
+
+#define G_EPI_LD 68   // floats per staged row (64 + 4 pad)
+
 template <bool ATR, bool BTR>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p) {
-    __shared__ __attribute__((aligned(16))) char smem[65536];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+__global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmP p) {
+    __shared__ __attribute__((aligned(16))) char smem[G_STAGE * G_NSTAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const int tm = blockIdx.x % p.tiles_m, tn = blockIdx.x / p.tiles_m;
-    const int m0 = tm * 128, n0 = tn * 128;
+    // XCD-aware tile order.  Blocks are dealt round-robin over the 8 XCDs (b % 8 labels the blocks sharing an L2), so
+    // first give each XCD a CONTIGUOUS range of a virtual order v (bijective form, cdna guide section 5), then walk v
+    // in groups of 4 row tiles x all column tiles (column-major inside a group): the ~32 blocks an XCD runs at once
+    // form a 4 x 8 patch of output tiles that re-use each other's A rows and B columns out of that XCD's L2.
+    // Placement only affects speed, never results.
+    int tm, tn;
+    {
+        const int nb = gridDim.x, b = blockIdx.x;
+        const int q = nb >> 3, r = nb & 7, x = b & 7;
+        const int v = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+        const int tiles_n = nb / p.tiles_m;
+        const int per_group = 4 * tiles_n;
+        const int g = v / per_group, w = v - g * per_group;
+        const int gm = min(4, p.tiles_m - g * 4);
+        tm = g * 4 + w % gm;
+        tn = w / gm;
+    }
+    const int m0 = tm * 256, n0 = tn * 128;
     const int z = blockIdx.z;
     const int bz = p.split_k > 1 ? 0 : z;
     const bf16_t* A = (const bf16_t*)p.A + bz * p.sA;
@@ -108,10 +220,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p) {
         const int per = (kt_total + p.split_k - 1) / p.split_k;
         kt0 = z * per;
         kt1 = min(kt_total, kt0 + per);
+        if (kt0 >= kt1) return;
     }
-    // double buffer: stage `cur` = [A 16 KiB | B 16 KiB] at smem + cur*32 KiB
-#define AS(c) (smem + (c) * 32768)
-#define BS(c) (smem + (c) * 32768 + 16384)
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -120,54 +230,83 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    if (kt0 < kt1) {
-        u32x4 ra[4], rb[4];
-        bf_gload<ATR>(ra, rsA, m0, p.M, kt0 * 64, p.K, p.lda, tid);
-        bf_gload<BTR>(rb, rsB, n0, p.N, kt0 * 64, p.K, p.ldb, tid);
-        bf_swrite<ATR>(ra, AS(0), tid);
-        bf_swrite<BTR>(rb, BS(0), tid);
-        __syncthreads();
-        int cur = 0;
-        for (int kt = kt0; kt < kt1; ++kt) {
-            const bool more = kt + 1 < kt1;
-            if (more) {
-                bf_gload<ATR>(ra, rsA, m0, p.M, (kt + 1) * 64, p.K, p.lda, tid);
-                bf_gload<BTR>(rb, rsB, n0, p.N, (kt + 1) * 64, p.K, p.ldb, tid);
-            }
-            const char* a_l = AS(cur);
-            const char* b_l = BS(cur);
+    // per-lane DMA offsets at k0 = 0 (rows/cols outside the matrix -> out-of-range offset -> zeros)
+    unsigned va[4], vb[2];
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const bf16x8 a0 = bf_frag<ATR>(a_l, wm * 64, ks, lane);
-                const bf16x8 a1 = bf_frag<ATR>(a_l, wm * 64 + 32, ks, lane);
-                const bf16x8 b0 = bf_frag<BTR>(b_l, wn * 64, ks, lane);
-                const bf16x8 b1 = bf_frag<BTR>(b_l, wn * 64 + 32, ks, lane);
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+    for (int j = 0; j < 4; ++j) va[j] = dma_voff<ATR>(j, m0, p.M, 0, 64, p.lda, wave, lane);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) vb[j] = dma_voff<BTR>(j, n0, p.N, 0, 64, p.ldb, wave, lane);
+    const unsigned ka = ATR ? (unsigned)(p.lda * 128) : 128u;   // bytes per K-tile step
+    const unsigned kb = BTR ? (unsigned)(p.ldb * 128) : 128u;
+    const int kt_full = p.K >> 6;                                 // K-tiles [0, kt_full) are complete
+
+    auto issue_tile = [&](int kt, int st) {
+        char* sa = smem + st * G_STAGE;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            if (kt < kt_full) {
+                if (q < 4) dma_piece(rsA, sa, q, wave, va[q], (unsigned)kt * ka);
+                else dma_piece(rsB, sa + 32768, q - 4, wave, vb[q - 4], (unsigned)kt * kb);
+            } else {
+                if (q < 4) dma_piece(rsA, sa, q, wave, dma_voff<ATR>(q, m0, p.M, kt * 64, p.K, p.lda, wave, lane), 0);
+                else dma_piece(rsB, sa + 32768, q - 4, wave, dma_voff<BTR>(q - 4, n0, p.N, kt * 64, p.K, p.ldb, wave, lane), 0);
             }
-            if (more) {
-                bf_swrite<ATR>(ra, AS(cur ^ 1), tid);
-                bf_swrite<BTR>(rb, BS(cur ^ 1), tid);
-            }
-            __syncthreads();
-            cur ^= 1;
         }
-    } else if (p.split_k > 1) {
-        return;  // empty K slice: nothing to add
+    };
+    issue_tile(kt0, 0);
+    if (kt0 + 1 < kt1) issue_tile(kt0 + 1, 1);
+    int st = 0;
+    for (int kt = kt0; kt < kt1; ++kt) {
+        // tile kt landed (this wave's loads), then everyone's; tile kt+1 may stay in flight
+        if (kt + 1 < kt1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const int st2 = st >= 1 ? st - 1 : 2;    // (st + 2) % 3: the stage every wave finished reading before this barrier
+        const char* a_l = smem + st * G_STAGE;
+        const char* b_l = a_l + 32768;
+        char* nxt = smem + st2 * G_STAGE;
+        const int ktn = kt + 2;
+        if (ktn < kt1 && ktn < kt_full)
+            ktile_step<ATR, BTR, 1>(acc, a_l, b_l, nxt, wm, wn, wave, lane, rsA, rsB, va, vb, (unsigned)ktn * ka, (unsigned)ktn * kb, p, m0, n0, ktn);
+        else if (ktn < kt1)
+            ktile_step<ATR, BTR, 2>(acc, a_l, b_l, nxt, wm, wn, wave, lane, rsA, rsB, va, vb, 0, 0, p, m0, n0, ktn);
+        else
+            ktile_step<ATR, BTR, 0>(acc, a_l, b_l, nxt, wm, wn, wave, lane, rsA, rsB, va, vb, 0, 0, p, m0, n0, ktn);
+        st = st == 2 ? 0 : st + 1;
     }
-#undef AS
-#undef BS
+    // ---- epilogue through LDS: each wave parks its 64x64 fp32 tile in its own 17 KiB slice of the (now idle) ring
+    // and reads it back row-wise, so global stores/atomics and the bias/resid/aux loads are 128-256-B row segments
+    // instead of one 4-8-B piece per row (which cost more than the K=768 main loop).
+    __builtin_amdgcn_s_barrier();     // every wave is done reading the operand stages
+    float* my = (float*)(smem + wave * (64 * G_EPI_LD * 4));
     const int h = lane >> 5, c = lane & 31;
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                epilogue_store<false>(p, cz, m0 + wm * 64 + mb * 32 + acc_row(r, h), n0 + wn * 64 + nb * 32 + c,
-                                      acc[mb][nb][r]);
+            for (int r = 0; r < 16; ++r) my[(mb * 32 + acc_row(r, h)) * G_EPI_LD + nb * 32 + c] = acc[mb][nb][r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int mw = m0 + wm * 64, nw = n0 + wn * 64;
+    if (p.flags & HS_EPI_ATOMIC) {
+        // one float per lane: every atomic wave-instruction is 256 contiguous bytes of one row
+        const int n = nw + lane;
+        for (int row = 0; row < 64; ++row) {
+            const int m = mw + row;
+            if (m < p.M && n < p.N) atomicAdd(p.out_f32 + cz + (long)m * p.ldc + n, my[row * G_EPI_LD + lane] * p.alpha);
+        }
+    } else {
+        const bool vec_ok = !(p.N & 3) && !(p.ldc & 3);
+        const int rr = lane >> 4, cc = (lane & 15) * 4;
+#pragma unroll 2
+        for (int step = 0; step < 16; ++step) {
+            const int row = step * 4 + rr;
+            const f32x4 v = *(const f32x4*)(my + row * G_EPI_LD + cc);
+            epilogue_vec4(p, cz, mw + row, nw + cc, v, vec_ok);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -305,11 +444,11 @@ extern "C" int hs_gemm(const hs_gemm_args* a, int prec, void* stream) {
     ProfScope prof(HS_PROF_GEMM_NT + a->layout, stream, 2.0 * mnk,
                    ((double)a->M * a->K + (double)a->N * a->K) * a->batch * esz + (double)a->M * a->N * a->batch * (a->out_f32 ? 4 : 2));
     if (prec == HS_PREC_BF16) {
-        p.tiles_m = (a->M + 127) / 128;
+        p.tiles_m = (a->M + 255) / 256;
         dim3 grid(p.tiles_m * ((a->N + 127) / 128), 1, zdim);
-        if (a->layout == HS_GEMM_NT) hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), grid, dim3(256), 0, s, p);
-        else if (a->layout == HS_GEMM_NN) hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), grid, dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, dim3(256), 0, s, p);
+        if (a->layout == HS_GEMM_NT) hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), grid, dim3(512), 0, s, p);
+        else if (a->layout == HS_GEMM_NN) hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), grid, dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, dim3(512), 0, s, p);
     } else {
         p.tiles_m = (a->M + 63) / 64;
         dim3 grid(p.tiles_m * ((a->N + 63) / 64), 1, zdim);
