@@ -74,14 +74,19 @@ int gemm(int prec, int layout, const void* A, const void* Bm, int M, int N, int 
     return hs_gemm(&g, prec, s);
 }
 
-// split-K factor for a wgrad whose output has `tiles` 128x128 tiles and `K` reduction rows
+// split-K factor for a wgrad whose output has ceil(Mo/256)*ceil(No/128) tiles and K reduction rows: pick the split
+// that minimises (rounds over 256 CUs) x (K-tiles per block + a fixed per-block cost ~ the atomic epilogue).
 int wgrad_split(int Mo, int No, int K) {
-    const int tiles = ((Mo + 127) / 128) * ((No + 127) / 128);
+    const int tiles = ((Mo + 255) / 256) * ((No + 127) / 128);
     const int kt = (K + 63) / 64;
-    int s = (768 + tiles - 1) / tiles;
-    if (s > kt / 2) s = kt / 2;
-    if (s < 1) s = 1;
-    return s;
+    int best = 1;
+    long best_cost = -1;
+    for (int s = 1; s <= 32 && s <= kt; ++s) {
+        const long rounds = ((long)tiles * s + 255) / 256;
+        const long cost = rounds * ((kt + s - 1) / s + 16);
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = s; }
+    }
+    return best;
 }
 
 #define RC(x) do { int rc__ = (x); if (rc__ != HS_OK) return rc__; } while (0)

@@ -22,6 +22,26 @@ def _al(n: int, a: int = 64) -> int:
     return (n + a - 1) // a * a
 
 
+def bucket_plan(names, offsets, total: int, n_layers: int, n_buckets: int):
+    """Backward-completion-ordered layer chunks [(l_hi, l_lo)] and the flat-gradient element range each one
+    finishes.  Parameters sit in state-dict order (cls, pos, patch-embed, blocks.0 .. blocks.L-1, norm), backward
+    completes blocks from L-1 down, so chunk i covers [offset(blocks.l_lo), previous start); the first chunk also
+    carries the final norm (it sits behind blocks.L-1), the last one cls/pos/patch-embed (in front of blocks.0)."""
+    per = max(1, (n_layers + n_buckets - 1) // n_buckets)
+    chunks, hi = [], n_layers
+    while hi > 0:
+        lo = max(0, hi - per)
+        chunks.append((hi, lo))
+        hi = lo
+    name_off = dict(zip(names, offsets))
+    bounds, end = [], total
+    for (hi, lo) in chunks:
+        start = name_off[f"blocks.{lo}.mlp.linear1.weight"] if lo > 0 else 0
+        bounds.append((start, end))
+        end = start
+    return chunks, bounds
+
+
 class FlatEncoder:
     """ViT_stage1 with flat parameter / gradient / moment buffers and an explicit fused train step."""
 
@@ -77,20 +97,7 @@ class FlatEncoder:
         self._np = Fn._ptr_array([model.norm.weight, model.norm.bias])
         self._lg = Fn._ptr_array([p.grad for p in blocks])
         self._ng = Fn._ptr_array([model.norm.weight.grad, model.norm.bias.grad])
-        # gradient buckets in backward-completion order: [blocks hi..lo (+ final norm with the first)], last one also
-        # carries cls / pos / patch-embed, which sit in front of blocks.0 in state-dict order.
-        per = max(1, (self.Ln + n_buckets - 1) // n_buckets)
-        self.layer_chunks, hi = [], self.Ln
-        while hi > 0:
-            lo = max(0, hi - per)
-            self.layer_chunks.append((hi, lo))
-            hi = lo
-        name_off = dict(zip(self.names, offs))
-        bounds, end = [], self.total
-        for (hi, lo) in self.layer_chunks:
-            start = name_off[f"blocks.{lo}.mlp.linear1.weight"] if lo > 0 else 0
-            bounds.append((start, end))
-            end = start
+        self.layer_chunks, bounds = bucket_plan(self.names, offs, self.total, self.Ln, n_buckets)
         self.buckets = GradBuckets(self.grad, bounds, group)
 
     # -- pieces --------------------------------------------------------------------------------------------

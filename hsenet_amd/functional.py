@@ -107,9 +107,16 @@ def colsum(x: torch.Tensor, out: torch.Tensor) -> None:
     L.call("hs_colsum", x.data_ptr(), int(x.dtype == torch.bfloat16), out.data_ptr(), x.shape[0], x.shape[1], x.shape[1], _s())
 
 
-def _wgrad_split(Mo: int, No: int, K: int, tile: int = 128, kt: int = 64) -> int:
-    tiles = ((Mo + tile - 1) // tile) * ((No + tile - 1) // tile)
-    return max(1, min((K + kt - 1) // kt // 2, (768 + tiles - 1) // tiles))
+def _wgrad_split(Mo: int, No: int, K: int, tile=(256, 128), kt: int = 64) -> int:
+    """split-K for a wgrad: minimise (rounds over 256 CUs) x (K-tiles per block + fixed per-block cost)."""
+    tiles = ((Mo + tile[0] - 1) // tile[0]) * ((No + tile[1] - 1) // tile[1])
+    nkt = (K + kt - 1) // kt
+    best, best_cost = 1, None
+    for s in range(1, min(32, nkt) + 1):
+        cost = ((tiles * s + 255) // 256) * ((nkt + s - 1) // s + 16)
+        if best_cost is None or cost < best_cost:
+            best, best_cost = s, cost
+    return best
 
 
 def attn_fwd(qkv: torch.Tensor, H: int, prec: int):
@@ -186,7 +193,7 @@ class LinearFn(torch.autograd.Function):
             dx = dx.view(ctx.xshape)
         if ctx.needs_input_grad[1]:
             dw = torch.zeros(N, K, dtype=torch.float32, device=dy.device)
-            tile, kt = (128, 64) if prec == L.PREC_BF16 else (64, 32)
+            tile, kt = ((256, 128), 64) if prec == L.PREC_BF16 else ((64, 64), 32)
             gemm(dya, xa, L.GEMM_TN, prec=prec, out_f32=dw, flags=L.EPI_ATOMIC, split_k=_wgrad_split(N, K, M, tile, kt))
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = torch.zeros(N, dtype=torch.float32, device=dy.device)
@@ -292,7 +299,7 @@ class PatchEmbedFn(torch.autograd.Function):
         dy2 = _f32(dy).contiguous().view(-1, N)
         dya = cast_bf16(dy2) if prec == L.PREC_BF16 else dy2
         dw = torch.zeros(N, K, dtype=torch.float32, device=dy.device)
-        tile, kt = (128, 64) if prec == L.PREC_BF16 else (64, 32)
+        tile, kt = ((256, 128), 64) if prec == L.PREC_BF16 else ((64, 64), 32)
         gemm(dya, patches, L.GEMM_TN, prec=prec, out_f32=dw, flags=L.EPI_ATOMIC,
              split_k=_wgrad_split(N, K, patches.shape[0], tile, kt))
         db = torch.zeros(N, dtype=torch.float32, device=dy.device)

@@ -1,0 +1,178 @@
+"""CPU tests of the oracle (oracle/ref_cpu.py): against the committed golden vectors that
+oracle/make_goldens.py produced by running the REFERENCE modules, and against two independent implementations
+of the transformer-block arithmetic (torch.nn.MultiheadAttention, HuggingFace ViTLayer) for the MONAI blocks
+the reference imports but does not ship."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_cpu as R
+
+
+def rel(a, b):
+    return R.rel_err(torch.as_tensor(a), torch.as_tensor(b))
+
+
+@torch.no_grad()
+def test_tiny_encoders_vs_golden(golden):
+    g = golden("tiny_encoders.npz")
+    img, patch, L, B = tuple(g["img"]), tuple(g["patch"]), int(g["layers"]), int(g["batch"])
+    kw = dict(in_channels=1, img_size=img, patch_size=patch, num_layers=L, pos_embed="perceptron", classification=True)
+    x, s = R.synthetic_volume((B, 1) + img, int(g["seed_x"])), R.synthetic_slices(B, int(g["seed_s"]))
+    m1 = R.ViT_stage1(**kw).eval()
+    assert list(m1.state_dict().keys()) == list(g["s1_keys"])
+    m1.load_state_dict(R.seeded_state_dict(m1, int(g["seed_w1"])))
+    y, h = m1(x)
+    assert rel(y, g["s1_out"]) < 1e-6 and rel(torch.stack(h), g["s1_hidden"]) < 1e-6
+    m2 = R.ViT_stage2(**kw).eval()
+    assert list(m2.state_dict().keys()) == list(g["s2_keys"])
+    m2.load_state_dict(R.seeded_state_dict(m2, int(g["seed_w2"])))
+    y, h = m2(x, s)
+    assert rel(y, g["s2_out"]) < 1e-6 and rel(torch.stack(h), g["s2_hidden"]) < 1e-6
+    ra = R.regular_attention().eval()
+    ra.load_state_dict(R.seeded_state_dict(ra, int(g["seed_ra"])))
+    q = torch.from_numpy(np.random.default_rng(int(g["seed_raq"])).standard_normal((B, 8, 768), dtype=np.float32))
+    yo, am = ra(q, s, s)
+    assert rel(yo, g["ra_out"]) < 1e-6 and rel(am, g["ra_map"]) < 1e-6
+
+
+@torch.no_grad()
+def test_packer_vs_golden(golden):
+    g = golden("packer.npz")
+    ra = R.resolution_attention_v3().eval()
+    ra.load_state_dict(R.seeded_state_dict(ra, int(g["seed_ra"])))
+    for tag, grid, ks in (("g288_k144", (2, 8, 8), (1, 4, 4)), ("g444_k222", (4, 4, 4), (2, 2, 2)), ("g488_k244", (4, 8, 8), (2, 4, 4))):
+        hr = torch.from_numpy(np.random.default_rng(int(g["seed_hr"])).standard_normal((2,) + grid + (768,), dtype=np.float32))
+        lr = torch.nn.functional.avg_pool3d(hr.permute(0, 4, 1, 2, 3), kernel_size=ks).permute(0, 2, 3, 4, 1)
+        assert rel(ra(lr, hr, ks), g[f"ra_{tag}"]) < 1e-6
+    args = ((32, 256, 256), (4, 16, 16), 768, 3072, "mlp", 2)
+    pk = R.VisualPacker_3d_phi_v3(*args).eval()
+    assert list(pk.state_dict().keys()) == list(g["packer_keys"]) and pk.proj_out_num == 128
+    assert sum(p.numel() for p in pk.parameters()) == 14166528          # SURVEY.md section 8c known answer
+    pk.load_state_dict(R.seeded_state_dict(pk, int(g["seed_pw"])))
+    x = torch.from_numpy(np.random.default_rng(int(g["seed_px"])).standard_normal((2, 2048, 768), dtype=np.float32))
+    y = pk(x)
+    assert rel(y[:, list(g["packer_rows"])], g["packer_out_rows"]) < 1e-6
+    assert rel(y.norm(dim=-1), g["packer_row_norms"]) < 1e-6
+
+
+@torch.no_grad()
+def test_plumbing_vit_small_vs_golden(golden):
+    g = golden("plumbing_vit_small.npz")
+    m = R.ViT_stage1(in_channels=1, img_size=(128,) * 3, patch_size=(16,) * 3, hidden_size=384, mlp_dim=1536, num_layers=6,
+                     num_heads=6, pos_embed="perceptron", classification=True).eval()
+    m.load_state_dict(R.seeded_state_dict(m, int(g["seed_w"])))
+    y, _ = m(R.synthetic_volume((1, 1, 128, 128, 128), int(g["seed_x"])))
+    assert rel(y, g["out"]) < 1e-6
+
+
+@torch.no_grad()
+def test_native_stage1_vs_golden(golden):
+    """reference-native 32x256x256 geometry, L=12 (the dual tower's stage-1 half; ~3 s on 8 cores)."""
+    g = golden("native_dual.npz")
+
+    class Cfg:
+        vision_select_layer, vision_select_feature, image_channel = -1, "patch", 1
+        image_size, patch_size, remain_2d3d_ViT_type = (32, 256, 256), (4, 16, 16), "3d_vit"
+    tower = R.ViT3DTower_dual_encoders(Cfg()).eval()
+    assert len(tower.state_dict()) == int(g["n_tower_keys"]) == 138 + 150
+    tower.load_state_dict(R.seeded_state_dict(tower, int(g["seed_tower"])))
+    f1 = tower(R.synthetic_volume((1, 1, 32, 256, 256), int(g["seed_x"])), R.synthetic_slices(1, int(g["seed_s"])))
+    assert rel(f1[:, list(g["native_rows"])], g["native_s1_rows"]) < 1e-5
+    assert rel(f1.norm(dim=-1), g["native_s1_norms"]) < 1e-5
+
+
+def test_param_counts_and_errors():
+    kw = dict(in_channels=1, img_size=(32, 256, 256), patch_size=(4, 16, 16), pos_embed="perceptron", classification=True)
+    assert sum(p.numel() for p in R.ViT_stage1(**kw).parameters()) == 87389184
+    assert sum(p.numel() for p in R.ViT_stage2(**kw).parameters()) == 89753857
+    with pytest.raises(ValueError):
+        R.ViT_stage1(1, (32, 256, 256), (4, 16, 16), dropout_rate=1.5, pos_embed="perceptron")
+    with pytest.raises(ValueError):
+        R.ViT_stage1(1, (32, 256, 256), (4, 16, 16), hidden_size=770, pos_embed="perceptron")
+
+
+@torch.no_grad()
+def test_sablock_vs_torch_multihead_attention():
+    """independent check of the recalled MONAI SABlock arithmetic + its [q|k|v][head][dh] weight layout."""
+    torch.manual_seed(0)
+    d, H = 384, 6
+    sa = R.SABlock(d, H).eval()
+    mha = torch.nn.MultiheadAttention(d, H, bias=True, batch_first=True).eval()
+    mha.in_proj_weight.copy_(sa.qkv.weight)           # torch packs [q; k; v] rows, heads contiguous inside each
+    mha.in_proj_bias.zero_()
+    mha.out_proj.weight.copy_(sa.out_proj.weight)
+    mha.out_proj.bias.copy_(sa.out_proj.bias)
+    x = torch.randn(2, 37, d)
+    ref, _ = mha(x, x, x, need_weights=False)
+    assert rel(sa(x), ref) < 1e-5
+
+
+@torch.no_grad()
+def test_transformer_block_vs_hf_vit_layer():
+    """independent check of the pre-LN block (x + attn(LN1 x); x + mlp(LN2 x), exact GELU, eps 1e-5... HF uses its
+    config eps) against HuggingFace's ViTLayer with the weights mapped across."""
+    tv = pytest.importorskip("transformers.models.vit.modeling_vit")
+    from transformers import ViTConfig
+    torch.manual_seed(1)
+    d, H, mlp = 384, 6, 1536
+    cfg = ViTConfig(hidden_size=d, num_attention_heads=H, intermediate_size=mlp, hidden_act="gelu", layer_norm_eps=1e-5,
+                    hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, qkv_bias=True)
+    cfg._attn_implementation = "eager"
+    hf = tv.ViTLayer(cfg).eval()
+    blk = R.TransformerBlock(d, mlp, H).eval()
+    sd = R.seeded_state_dict(blk, 7)
+    blk.load_state_dict(sd)
+    wq, wk, wv = blk.attn.qkv.weight.split(d, dim=0)
+    named = dict(hf.named_parameters())
+
+    def put(names, value):          # transformers renamed these sub-modules across versions: accept either spelling
+        for n in names:
+            if n in named:
+                named[n].copy_(value)
+                return
+        raise KeyError(names)
+    put(["attention.q_proj.weight", "attention.attention.query.weight"], wq)
+    put(["attention.k_proj.weight", "attention.attention.key.weight"], wk)
+    put(["attention.v_proj.weight", "attention.attention.value.weight"], wv)
+    for n in ("q_proj", "k_proj", "v_proj"):
+        for cand in (f"attention.{n}.bias", f"attention.attention.{ {'q_proj': 'query', 'k_proj': 'key', 'v_proj': 'value'}[n] }.bias"):
+            if cand in named:
+                named[cand].zero_()
+    put(["attention.o_proj.weight", "attention.output.dense.weight"], blk.attn.out_proj.weight)
+    put(["attention.o_proj.bias", "attention.output.dense.bias"], blk.attn.out_proj.bias)
+    put(["layernorm_before.weight"], blk.norm1.weight); put(["layernorm_before.bias"], blk.norm1.bias)
+    put(["layernorm_after.weight"], blk.norm2.weight); put(["layernorm_after.bias"], blk.norm2.bias)
+    put(["mlp.fc1.weight", "intermediate.dense.weight"], blk.mlp.linear1.weight)
+    put(["mlp.fc1.bias", "intermediate.dense.bias"], blk.mlp.linear1.bias)
+    put(["mlp.fc2.weight", "output.dense.weight"], blk.mlp.linear2.weight)
+    put(["mlp.fc2.bias", "output.dense.bias"], blk.mlp.linear2.bias)
+    x = torch.randn(2, 29, d)
+    out = hf(x)
+    out = out[0] if isinstance(out, (tuple, list)) else out
+    assert rel(blk(x), out) < 1e-5
+
+
+def test_patch_embedding_matches_conv3d():
+    """the 'perceptron' rearrange + Linear equals a strided Conv3d with the weight reshaped (p1,p2,p3,c) -> (c,p1,p2,p3):
+    pins the token order (row-major over D/p1,H/p2,W/p3) and in-patch feature order."""
+    torch.manual_seed(2)
+    pe = R.PatchEmbeddingBlock(2, (8, 32, 32), (4, 16, 16), 96, 4).eval()
+    x = torch.randn(2, 2, 8, 32, 32)
+    lin = pe.patch_embeddings[1]
+    w = lin.weight.view(96, 4, 16, 16, 2).permute(0, 4, 1, 2, 3)
+    ref = torch.nn.functional.conv3d(x, w, lin.bias, stride=(4, 16, 16)).flatten(2).transpose(1, 2) + pe.position_embeddings
+    with torch.no_grad():
+        assert rel(pe(x), ref) < 1e-5
+
+
+def test_clip_loss_head():
+    torch.manual_seed(3)
+    img = torch.nn.functional.normalize(torch.randn(4, 768), dim=-1)
+    txt = torch.nn.functional.normalize(torch.randn(4, 768), dim=-1)
+    scale = torch.tensor(float(np.log(1 / 0.07)))
+    loss = R.clip_contrastive_loss(img, txt, scale)
+    logits = scale * img @ txt.t()
+    lab = torch.arange(4)
+    ref = 0.5 * (torch.nn.functional.cross_entropy(logits, lab) + torch.nn.functional.cross_entropy(logits.t(), lab))
+    assert abs(float(loss - ref)) < 1e-6
