@@ -8,6 +8,7 @@
 //
 // f32 kernel (parity mode): 64x64x32 tile, v_mfma_f32_32x32x2_f32 (exact f32 fma chain).
 #include "common.h"
+#include <stdlib.h>
 
 struct GemmP {
     const void* A; const void* B;
@@ -43,16 +44,14 @@ __device__ __forceinline__ void epilogue_store(const GemmP& p, long cz, int m, i
 }
 
 // ------------------------------------------------------------------------------------------------------
-// bf16: 256x128x64 tile, 8 waves (4 along M x 2 along N), wave tile 64x64.
+// bf16: 256x256x64 (wave tile 128x64) or 256x128x64 (wave tile 64x64) block tiles, 8 waves (GCfg below).
 // Operand tiles go global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds: no VGPR staging, no ds_write), with
 // the buffer descriptor's range check zero-filling every M/N/K tail.  LDS-DMA writes lane-linearly, so the
 // bank swizzle of images R/T is applied to the per-lane SOURCE address (cdna guide rule 21) and again on the
-// fragment reads.  3-stage ring: tile t+2 is issued right after the barrier of step t, so two tiles are in flight
-// while one is consumed; waits are counted (s_waitcnt vmcnt(6) = "all but the newest tile's 6 loads"), barriers raw.
+// fragment reads.  Stage ring (2 or 3 deep): the prefetched tile is issued right after the barrier of step t, behind
+// the MFMA groups; waits are counted (s_waitcnt vmcnt(6) = "all but the newest tile's 6 loads"), barriers raw.
 // The epilogue is staged through LDS (see the kernel's tail) so that stores/atomics are whole row segments.
 // ------------------------------------------------------------------------------------------------------
-#define G_STAGE 49152   // A 32 KiB + B 16 KiB
-#define G_NSTAGE 3
 
 // fast erf (Abramowitz-Stegun 7.1.26, |err| <= 1.5e-7) sharing exp(-x^2/2) between GELU and its derivative
 __device__ __forceinline__ void gelu_parts(float x, float& cdf, float& pdf_x) {
@@ -150,48 +149,91 @@ __device__ __forceinline__ void epilogue_vec4(const GemmP& p, long cz, int m, in
     }
 }
 
-// one K-tile of MFMA work for a wave (4 k-steps x 2x2 blocks), with the DMA pieces of K-tile `ktn` issued behind
-// the MFMA groups.  MODE 0: no prefetch; 1: full K-tile (hoisted offsets + scalar advance); 2: partial last K-tile.
-template <bool ATR, bool BTR, int MODE>
-__device__ __forceinline__ void ktile_step(f32x16 (&acc)[2][2], const char* a_l, const char* b_l, char* nxt, int wm, int wn, int wave,
-                                           int lane, __amdgpu_buffer_rsrc_t rsA, __amdgpu_buffer_rsrc_t rsB, const unsigned (&va)[4],
-                                           const unsigned (&vb)[2], unsigned sa, unsigned sb, const GemmP& p, int m0, int n0, int ktn) {
+// Tile configurations.  BIG: 256x256 block, 8 waves as 2(M) x 4(N), wave tile 128x64 (4x2 MFMA blocks, 32 MFMAs per
+// K-tile per wave), 2 stages x 64 KiB.  !BIG: 256x128 block, waves 4 x 2, wave tile 64x64, 3 stages x 48 KiB.
+template <bool BIG> struct GCfg {
+    static constexpr int MB = BIG ? 4 : 2;            // 32-row MFMA blocks per wave along M
+    static constexpr int WAVES_N = BIG ? 4 : 2;
+    static constexpr int BN = WAVES_N * 64;
+    static constexpr int NSTAGE = BIG ? 2 : 3;
+    static constexpr int PB = BIG ? 4 : 2;            // B-operand DMA pieces per wave per K-tile (A: always 4)
+    static constexpr int PIECES = 4 + PB;
+    static constexpr int STAGE = 32768 + BN * 128;
+    static constexpr int EPI = 8 * 64 * 68 * 4;       // per-wave 64x64 fp32 staging slices (68-float rows)
+    static constexpr int SMEM = STAGE * NSTAGE > EPI ? STAGE * NSTAGE : EPI;
+};
+#define G_EPI_LD 68   // floats per staged row (64 + 4 pad)
+
+// one K-tile of MFMA work for a wave, with the DMA pieces of the prefetched K-tile (if any: `issue`, wave-uniform)
+// issued behind the MFMA groups.  A single code path keeps the 64-128 accumulator registers out of phi copies.
+template <bool ATR, bool BTR, bool BIG>
+__device__ __forceinline__ void ktile_step(f32x16 (&acc)[GCfg<BIG>::MB][2], const char* a_l, const char* b_l, char* nxt, int row0, int col0,
+                                           int wave, int lane, __amdgpu_buffer_rsrc_t rsA, __amdgpu_buffer_rsrc_t rsB,
+                                           const unsigned (&va)[4], const unsigned (&vb)[GCfg<BIG>::PB], unsigned sa, unsigned sb, bool issue) {
+    typedef GCfg<BIG> C;
+    constexpr int MODE = 1;
     auto piece = [&](int q) {
-        if (MODE == 1) {
+        if (issue) {
             if (q < 4) dma_piece(rsA, nxt, q, wave, va[q], sa); else dma_piece(rsB, nxt + 32768, q - 4, wave, vb[q - 4], sb);
-        } else if (MODE == 2) {
-            if (q < 4) dma_piece(rsA, nxt, q, wave, dma_voff<ATR>(q, m0, p.M, ktn * 64, p.K, p.lda, wave, lane), 0);
-            else dma_piece(rsB, nxt + 32768, q - 4, wave, dma_voff<BTR>(q - 4, n0, p.N, ktn * 64, p.K, p.ldb, wave, lane), 0);
         }
     };
+    // Software pipeline inside the K-tile: the fragments of k-step ks+1 are read BEFORE the MFMAs of k-step ks are
+    // issued and the DMA pieces go after those MFMAs, so LDS read latency (~200 cycles) and DMA issue cost (~65
+    // cycles per piece) elapse under the matrix pipe.
+    if (BIG) {
+        // 128x64 wave tile: the accumulator already takes 128 of the 256 registers available at 2 waves/SIMD, so the
+        // A fragments stream one 32-row block at a time (2 MFMAs each) instead of being double-buffered.
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        const bf16x8 a0 = g_frag<ATR>(a_l, wm * 64, ks, lane);
-        const bf16x8 a1 = g_frag<ATR>(a_l, wm * 64 + 32, ks, lane);
-        const bf16x8 b0 = g_frag<BTR>(b_l, wn * 64, ks, lane);
-        const bf16x8 b1 = g_frag<BTR>(b_l, wn * 64 + 32, ks, lane);
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
-        if (MODE != 0) {   // pieces (0,1) (2,3) (4) (5): their issue cost sits behind an MFMA group, not in front of one
-            if (ks < 2) { piece(2 * ks); piece(2 * ks + 1); } else piece(ks + 2);
+        for (int ks = 0; ks < 4; ++ks) {
+            const bf16x8 b0 = g_frag<BTR>(b_l, col0, ks, lane);
+            const bf16x8 b1 = g_frag<BTR>(b_l, col0 + 32, ks, lane);
+#pragma unroll
+            for (int i = 0; i < C::MB; ++i) {
+                const bf16x8 a = g_frag<ATR>(a_l, row0 + 32 * i, ks, lane);
+                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b0, acc[i][0], 0, 0, 0);
+                acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1, acc[i][1], 0, 0, 0);
+            }
+            if (MODE != 0) { piece(2 * ks); piece(2 * ks + 1); }     // 8 pieces: 2 per k-step
+        }
+    } else {
+        bf16x8 fa[2][C::MB], fb[2][2];
+#pragma unroll
+        for (int i = 0; i < C::MB; ++i) fa[0][i] = g_frag<ATR>(a_l, row0 + 32 * i, 0, lane);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fb[0][j] = g_frag<BTR>(b_l, col0 + 32 * j, 0, lane);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int cur = ks & 1, nx = cur ^ 1;
+            if (ks < 3) {
+#pragma unroll
+                for (int i = 0; i < C::MB; ++i) fa[nx][i] = g_frag<ATR>(a_l, row0 + 32 * i, ks + 1, lane);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) fb[nx][j] = g_frag<BTR>(b_l, col0 + 32 * j, ks + 1, lane);
+            }
+#pragma unroll
+            for (int i = 0; i < C::MB; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
+            if (MODE != 0) {
+                if (ks < 2) { piece(2 * ks); piece(2 * ks + 1); } else piece(ks + 2);   // 6 pieces: (0,1)(2,3)(4)(5)
+            }
         }
     }
 }
 
-#define G_EPI_LD 68   // floats per staged row (64 + 4 pad)
-
-template <bool ATR, bool BTR>
+template <bool ATR, bool BTR, bool BIG>
 __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmP p) {
-    __shared__ __attribute__((aligned(16))) char smem[G_STAGE * G_NSTAGE];
+    typedef GCfg<BIG> C;
+    __shared__ __attribute__((aligned(16))) char smem[C::SMEM];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = BIG ? wave >> 2 : wave >> 1, wn = BIG ? wave & 3 : wave & 1;
+    const int row0 = wm * (C::MB * 32), col0 = wn * 64;        // this wave's tile inside the block tile
     // XCD-aware tile order.  Blocks are dealt round-robin over the 8 XCDs (b % 8 labels the blocks sharing an L2), so
     // first give each XCD a CONTIGUOUS range of a virtual order v (bijective form, cdna guide section 5), then walk v
     // in groups of 4 row tiles x all column tiles (column-major inside a group): the ~32 blocks an XCD runs at once
-    // form a 4 x 8 patch of output tiles that re-use each other's A rows and B columns out of that XCD's L2.
+    // form a patch of output tiles that re-use each other's A rows and B columns out of that XCD's L2.
     // Placement only affects speed, never results.
     int tm, tn;
     {
@@ -205,7 +247,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmP p) {
         tm = g * 4 + w % gm;
         tn = w / gm;
     }
-    const int m0 = tm * 256, n0 = tn * 128;
+    const int m0 = tm * 256, n0 = tn * C::BN;
     const int z = blockIdx.z;
     const int bz = p.split_k > 1 ? 0 : z;
     const bf16_t* A = (const bf16_t*)p.A + bz * p.sA;
@@ -222,28 +264,28 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmP p) {
         kt1 = min(kt_total, kt0 + per);
         if (kt0 >= kt1) return;
     }
-    f32x16 acc[2][2];
+    f32x16 acc[C::MB][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < C::MB; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     // per-lane DMA offsets at k0 = 0 (rows/cols outside the matrix -> out-of-range offset -> zeros)
-    unsigned va[4], vb[2];
+    unsigned va[4], vb[C::PB];
 #pragma unroll
     for (int j = 0; j < 4; ++j) va[j] = dma_voff<ATR>(j, m0, p.M, 0, 64, p.lda, wave, lane);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) vb[j] = dma_voff<BTR>(j, n0, p.N, 0, 64, p.ldb, wave, lane);
+    for (int j = 0; j < C::PB; ++j) vb[j] = dma_voff<BTR>(j, n0, p.N, 0, 64, p.ldb, wave, lane);
     const unsigned ka = ATR ? (unsigned)(p.lda * 128) : 128u;   // bytes per K-tile step
     const unsigned kb = BTR ? (unsigned)(p.ldb * 128) : 128u;
     const int kt_full = p.K >> 6;                                 // K-tiles [0, kt_full) are complete
 
     auto issue_tile = [&](int kt, int st) {
-        char* sa = smem + st * G_STAGE;
+        char* sa = smem + st * C::STAGE;
 #pragma unroll
-        for (int q = 0; q < 6; ++q) {
+        for (int q = 0; q < C::PIECES; ++q) {
             if (kt < kt_full) {
                 if (q < 4) dma_piece(rsA, sa, q, wave, va[q], (unsigned)kt * ka);
                 else dma_piece(rsB, sa + 32768, q - 4, wave, vb[q - 4], (unsigned)kt * kb);
@@ -253,58 +295,75 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmP p) {
             }
         }
     };
+    // ring: prefetch distance D = NSTAGE-1 tiles.  At step kt: wait until tile kt has landed (D-1 newer tiles may stay
+    // in flight: counted vmcnt), barrier, then issue tile kt+D into the stage every wave finished reading before
+    // that barrier (the one consumed at step kt-1).
+    constexpr int D = C::NSTAGE - 1;
     issue_tile(kt0, 0);
-    if (kt0 + 1 < kt1) issue_tile(kt0 + 1, 1);
+    if (D == 2 && kt0 + 1 < kt1) issue_tile(kt0 + 1, 1);
     int st = 0;
     for (int kt = kt0; kt < kt1; ++kt) {
-        // tile kt landed (this wave's loads), then everyone's; tile kt+1 may stay in flight
-        if (kt + 1 < kt1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        if (D == 2 && kt + 1 < kt1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        const int st2 = st >= 1 ? st - 1 : 2;    // (st + 2) % 3: the stage every wave finished reading before this barrier
-        const char* a_l = smem + st * G_STAGE;
+        const int stn = (D == 2) ? (st >= 1 ? st - 1 : 2) : (st ^ 1);
+        const char* a_l = smem + st * C::STAGE;
         const char* b_l = a_l + 32768;
-        char* nxt = smem + st2 * G_STAGE;
-        const int ktn = kt + 2;
-        if (ktn < kt1 && ktn < kt_full)
-            ktile_step<ATR, BTR, 1>(acc, a_l, b_l, nxt, wm, wn, wave, lane, rsA, rsB, va, vb, (unsigned)ktn * ka, (unsigned)ktn * kb, p, m0, n0, ktn);
-        else if (ktn < kt1)
-            ktile_step<ATR, BTR, 2>(acc, a_l, b_l, nxt, wm, wn, wave, lane, rsA, rsB, va, vb, 0, 0, p, m0, n0, ktn);
-        else
-            ktile_step<ATR, BTR, 0>(acc, a_l, b_l, nxt, wm, wn, wave, lane, rsA, rsB, va, vb, 0, 0, p, m0, n0, ktn);
-        st = st == 2 ? 0 : st + 1;
+        char* nxt = smem + stn * C::STAGE;
+        const int ktn = kt + D;
+        const bool issue = ktn < kt1;
+        unsigned sa = (unsigned)ktn * ka, sb = (unsigned)ktn * kb;
+        if (issue && ktn >= kt_full) {
+            // partial last K-tile: bound k per lane.  It is the last tile ever issued, so the hoisted offsets are dead
+            // and can be overwritten in place.
+#pragma unroll
+            for (int j = 0; j < 4; ++j) va[j] = dma_voff<ATR>(j, m0, p.M, ktn * 64, p.K, p.lda, wave, lane);
+#pragma unroll
+            for (int j = 0; j < C::PB; ++j) vb[j] = dma_voff<BTR>(j, n0, p.N, ktn * 64, p.K, p.ldb, wave, lane);
+            sa = sb = 0;
+        }
+        ktile_step<ATR, BTR, BIG>(acc, a_l, b_l, nxt, row0, col0, wave, lane, rsA, rsB, va, vb, sa, sb, issue);
+        st = (D == 2) ? (st == 2 ? 0 : st + 1) : (st ^ 1);
     }
-    // ---- epilogue through LDS: each wave parks its 64x64 fp32 tile in its own 17 KiB slice of the (now idle) ring
-    // and reads it back row-wise, so global stores/atomics and the bias/resid/aux loads are 128-256-B row segments
-    // instead of one 4-8-B piece per row (which cost more than the K=768 main loop).
+    // ---- epilogue through LDS: each wave parks a 64x64 fp32 piece of its tile in its own 17 KiB slice of the (now
+    // idle) ring and reads it back row-wise, so global stores/atomics and the bias/resid/aux loads are 128-256-B row
+    // segments instead of one 4-8-B piece per row (which cost more than the K=768 main loop).
     __builtin_amdgcn_s_barrier();     // every wave is done reading the operand stages
     float* my = (float*)(smem + wave * (64 * G_EPI_LD * 4));
     const int h = lane >> 5, c = lane & 31;
+    const bool vec_ok = !(p.N & 3) && !(p.ldc & 3);
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb)
+    for (int half = 0; half < C::MB / 2; ++half) {
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
+        for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) my[(mb * 32 + acc_row(r, h)) * G_EPI_LD + nb * 32 + c] = acc[mb][nb][r];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int mw = m0 + wm * 64, nw = n0 + wn * 64;
-    if (p.flags & HS_EPI_ATOMIC) {
-        // one float per lane: every atomic wave-instruction is 256 contiguous bytes of one row
-        const int n = nw + lane;
-        for (int row = 0; row < 64; ++row) {
-            const int m = mw + row;
-            if (m < p.M && n < p.N) atomicAdd(p.out_f32 + cz + (long)m * p.ldc + n, my[row * G_EPI_LD + lane] * p.alpha);
-        }
-    } else {
-        const bool vec_ok = !(p.N & 3) && !(p.ldc & 3);
-        const int rr = lane >> 4, cc = (lane & 15) * 4;
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) my[(mb * 32 + acc_row(r, h)) * G_EPI_LD + nb * 32 + c] = acc[half * 2 + mb][nb][r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int mw = m0 + row0 + half * 64, nw = n0 + col0;
+        if (p.flags & HS_EPI_ATOMIC) {
+            // one float per lane: every atomic wave-instruction is 256 contiguous bytes of one row
+            const int n = nw + lane;
+            for (int row = 0; row < 64; ++row) {
+                const int m = mw + row;
+                if (m < p.M && n < p.N) atomicAdd(p.out_f32 + cz + (long)m * p.ldc + n, my[row * G_EPI_LD + lane] * p.alpha);
+            }
+        } else {
+            const int rr = lane >> 4, cc = (lane & 15) * 4;
 #pragma unroll 2
-        for (int step = 0; step < 16; ++step) {
-            const int row = step * 4 + rr;
-            const f32x4 v = *(const f32x4*)(my + row * G_EPI_LD + cc);
-            epilogue_vec4(p, cz, mw + row, nw + cc, v, vec_ok);
+            for (int step = 0; step < 16; ++step) {
+                const int row = step * 4 + rr;
+                const f32x4 v = *(const f32x4*)(my + row * G_EPI_LD + cc);
+                epilogue_vec4(p, cz, mw + row, nw + cc, v, vec_ok);
+            }
+        }
+        if (half + 1 < C::MB / 2) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
     }
 }
@@ -444,11 +503,22 @@ extern "C" int hs_gemm(const hs_gemm_args* a, int prec, void* stream) {
     ProfScope prof(HS_PROF_GEMM_NT + a->layout, stream, 2.0 * mnk,
                    ((double)a->M * a->K + (double)a->N * a->K) * a->batch * esz + (double)a->M * a->N * a->batch * (a->out_f32 ? 4 : 2));
     if (prec == HS_PREC_BF16) {
+        // tile choice: the 256x256 tile does twice the MFMA work per barrier / DMA piece / LDS read; use it when the
+        // grid still fills the chip (>= ~0.9 round of 256 CUs), else the 256x128 tile
         p.tiles_m = (a->M + 255) / 256;
-        dim3 grid(p.tiles_m * ((a->N + 127) / 128), 1, zdim);
-        if (a->layout == HS_GEMM_NT) hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), grid, dim3(512), 0, s, p);
-        else if (a->layout == HS_GEMM_NN) hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), grid, dim3(512), 0, s, p);
-        else hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, dim3(512), 0, s, p);
+        const long big_blocks = (long)p.tiles_m * ((a->N + 255) / 256) * zdim;
+        const char* force = getenv("HS_GEMM_TILE");   // "big" / "small": tools/bench_gemm.py A/B runs
+        const bool big = force ? (force[0] == 'b') : (a->layout != HS_GEMM_TN && big_blocks >= 230);
+        dim3 grid(p.tiles_m * ((a->N + (big ? 255 : 127)) / (big ? 256 : 128)), 1, zdim);
+#define HS_LAUNCH(ATR, BTR)                                                                                          \
+    do {                                                                                                             \
+        if (big) hipLaunchKernelGGL((gemm_bf16_kernel<ATR, BTR, true>), grid, dim3(512), 0, s, p);                    \
+        else hipLaunchKernelGGL((gemm_bf16_kernel<ATR, BTR, false>), grid, dim3(512), 0, s, p);                       \
+    } while (0)
+        if (a->layout == HS_GEMM_NT) HS_LAUNCH(false, false);
+        else if (a->layout == HS_GEMM_NN) HS_LAUNCH(false, true);
+        else HS_LAUNCH(true, true);
+#undef HS_LAUNCH
     } else {
         p.tiles_m = (a->M + 63) / 64;
         dim3 grid(p.tiles_m * ((a->N + 63) / 64), 1, zdim);
