@@ -57,7 +57,7 @@ __device__ __forceinline__ void store_dT(bf16_t* rowptr, const f32x16 (&acc)[2],
 // ------------------------------------------------------------------------------------------------------
 // forward, bf16.  grid (ceil(N/128), H, B), 4 waves x 32 queries, 64-key tiles.
 // ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
+__global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
                                                             float* __restrict__ lse, int N, int H, float scale) {
     __shared__ __attribute__((aligned(16))) char smem[32768];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, c = lane & 31;
@@ -111,6 +111,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16_t* __rest
             for (int ks = 0; ks < 4; ++ks)
                 s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Kl, kb * 32 + c, ks, h), qf[ks], s[kb], 0, 0, 0);
         if (t == nt - 1 && (N & 63)) {
+            asm volatile("" ::: "memory");   // keep this a wave-uniform BRANCH: if-converted it is 33 v_cndmask on every tile
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -320,7 +321,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
 }
 
 // dK, dV: grid (ceil(N/128), H, B); each wave owns 32 keys, sweeps all queries in 64-row tiles.
-__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
                                                             const float* __restrict__ lse, const float* __restrict__ delta,
                                                             bf16_t* __restrict__ dqkv, int N, int H, float scale) {
     // stage: Q image 8 KiB | dO image 8 KiB | -lse/scale [64] f32 | -delta [64] f32
@@ -343,21 +344,24 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16_t* __rest
         vf[ks] = __builtin_bit_cast(bf16x8, buf_load16(rs, key < N ? off + Dm * 2 : HS_OOB_OFF));
     }
     u32x4 rq[2], rd[2];
-    float rstat = 0.f;
+    unsigned rstat = 0;
+    // waves 0/1 also fetch the tile's 64 lse / delta values.  Raw range-checked loads only: any arithmetic on a freshly
+    // loaded value here would force s_waitcnt vmcnt(0) and drain the whole next-tile prefetch before the MFMAs start.
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const __amdgpu_buffer_rsrc_t rsl = make_rsrc(wave_u == 0 ? lse_b : del_b, (size_t)N * 4);
     auto gload = [&](int t) {
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
             const int idx = it * 256 + tid, q = t * 64 + (idx >> 3);
-            rq[it] = buf_load16(rs, q < N ? (unsigned)(((long)q * D3 + head * 64 + (idx & 7) * 8) * 2) : HS_OOB_OFF);
-            rd[it] = buf_load16(rsd, q < N ? (unsigned)(((long)q * Dm + head * 64 + (idx & 7) * 8) * 2) : HS_OOB_OFF);
+            const bool ok = q < N;
+            const unsigned oq = (unsigned)(((long)q * D3 + head * 64 + (idx & 7) * 8) * 2);
+            const unsigned od = (unsigned)(((long)q * Dm + head * 64 + (idx & 7) * 8) * 2);
+            rq[it] = buf_load16(rs, ok ? oq : HS_OOB_OFF);
+            rd[it] = buf_load16(rsd, ok ? od : HS_OOB_OFF);
         }
-        if (tid < 128) {
-            const int q = t * 64 + (tid & 63);
-            if (tid < 64) rstat = q < N ? -lse_b[q] * inv_scale : NEG_INF;
-            else rstat = q < N ? -del_b[q] : 0.f;
-        }
+        if (wave_u < 2) rstat = __builtin_amdgcn_raw_buffer_load_b32(rsl, (unsigned)(t * 64 + lane) * 4u, 0, 0);   // OOB -> 0
     };
-    auto swrite = [&](int st) {
+    auto swrite = [&](int st, int t) {
         char* sb = smem + st * 16896;
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
@@ -365,12 +369,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16_t* __rest
             *(u32x4*)(sb + o_) = rq[it];
             *(u32x4*)(sb + 8192 + o_) = rd[it];
         }
-        if (tid < 128) *(float*)(sb + 16384 + tid * 4) = rstat;
+        if (wave_u < 2) {
+            const float v = __uint_as_float(rstat);
+            const bool ok = t * 64 + lane < N;
+            // wave 0: -lse/scale (queries past N: -inf, so that P = exp2(-inf) = 0); wave 1: -delta
+            const float w = wave_u == 0 ? (ok ? -v * inv_scale : NEG_INF) : -v;
+            *(float*)(sb + 16384 + tid * 4) = w;
+        }
     };
     f32x16 dk[2] = {zero16(), zero16()}, dv[2] = {zero16(), zero16()};
     const int nt = (N + 63) >> 6;
     gload(0);
-    swrite(0);
+    swrite(0, 0);
     __syncthreads();
     int cur = 0;
     for (int t = 0; t < nt; ++t) {
@@ -414,7 +424,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16_t* __rest
                 }
             }
         }
-        if (more) swrite(cur ^ 1);
+        if (more) swrite(cur ^ 1, t + 1);
         __syncthreads();
         cur ^= 1;
     }
@@ -426,7 +436,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16_t* __rest
 }
 
 // dQ: grid (ceil(N/128), H, B); each wave owns 32 queries, sweeps all keys in 64-row tiles.
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
                                                           const float* __restrict__ lse, const float* __restrict__ delta,
                                                           bf16_t* __restrict__ dqkv, int N, int H, float scale) {
     __shared__ __attribute__((aligned(16))) char smem[32768];
@@ -482,13 +492,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
                 st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Kl, kb * 32 + c, ks, h), qf[ks], st, 0, 0, 0);
                 dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Vl, kb * 32 + c, ks, h), dof[ks], dpt, 0, 0, 0);
             }
-            const bool tail = (t == nt - 1) && (N & 63);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float p = __builtin_amdgcn_exp2f(st[r] * c2 - lq);
-                if (tail && t * 64 + kb * 32 + acc_row(r, h) >= N) p = 0.f;
-                dpt[r] = p * (dpt[r] - dq_);
+            for (int r = 0; r < 16; ++r) st[r] = __builtin_amdgcn_exp2f(st[r] * c2 - lq);
+            if ((t == nt - 1) && (N & 63)) {
+                asm volatile("" ::: "memory");   // wave-uniform branch, not 16 v_cndmask per key block on every tile
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (t * 64 + kb * 32 + acc_row(r, h) >= N) st[r] = 0.f;
             }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dpt[r] = st[r] * (dpt[r] - dq_);
 #pragma unroll
             for (int sp = 0; sp < 2; ++sp) {
                 const bf16x8 dsf = pack8(dpt, sp);
