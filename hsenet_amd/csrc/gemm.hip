@@ -15,7 +15,7 @@ struct GemmP {
     int M, N, K;
     long lda, ldb, sA, sB, sC, ldc;
     float* out_f32; void* out_bf16;
-    const float* bias; const float* resid; const void* aux; void* aux_out;
+    const float* bias; const float* resid; const void* aux; void* aux_out; float* colsum;
     float alpha; int flags; int split_k; int tiles_m;
 };
 
@@ -28,13 +28,14 @@ __device__ __forceinline__ void epilogue_store(const GemmP& p, long cz, int m, i
     if (p.flags & HS_EPI_GELU) {
         if (!F32AUX) v = bf2f(f2bf(v));  // autocast: linear1 emits bf16, GELU runs on that
         if (p.aux_out) {
-            if (F32AUX) ((float*)p.aux_out)[idx] = v; else ((bf16_t*)p.aux_out)[idx] = f2bf(v);
+            const float keep = (p.flags & HS_EPI_SAVE_DGELU) ? gelu_grad_f(v) : v;
+            if (F32AUX) ((float*)p.aux_out)[idx] = keep; else ((bf16_t*)p.aux_out)[idx] = f2bf(keep);
         }
         v = gelu_f(v);
     }
     if (p.flags & HS_EPI_GELU_BWD) {
         const float z = F32AUX ? ((const float*)p.aux)[idx] : bf2f(((const bf16_t*)p.aux)[idx]);
-        v *= gelu_grad_f(z);
+        v *= (p.flags & HS_EPI_SAVE_DGELU) ? z : gelu_grad_f(z);
     }
     if (p.flags & HS_EPI_RESID) v += p.resid[idx];
     if (p.out_f32) {
@@ -105,43 +106,46 @@ __device__ __forceinline__ bf16x8 g_frag(const char* lds, int sub, int ks, int l
 }
 
 // 4 consecutive n of one output row m
-__device__ __forceinline__ void epilogue_vec4(const GemmP& p, long cz, int m, int n, f32x4 v, bool vec_ok) {
-    if (m >= p.M || n >= p.N) return;
-    if (!vec_ok || n + 3 >= p.N) {   // rare path (N or ldc not a multiple of 4): element-wise, kept rolled
-#pragma unroll 1
-        for (int e = 0; e < 4; ++e) epilogue_store<false>(p, cz, m, n + e, v[e]);
-        return;
-    }
+// Vector epilogue for 4 consecutive n of one output row, split in two so that a group of steps can do ALL its math
+// first and ALL its stores afterwards: vmcnt is an in-order counter and these steps sit in divergent control flow, so
+// hipcc waits vmcnt(0) before every use of a loaded value — with a store between two uses that is one store round trip
+// per step (~32 per block), which cost more than the K=768 main loop.
+// epi_math: v -> final value (bias, GELU(+value to save), GELU', residual); *keep = bf16x4 to store to aux_out.
+__device__ __forceinline__ f32x4 epi_math(const GemmP& p, int m, f32x4 v, f32x4 res, u32x2 zb_in, f32x4 bias_n, u32x2* keep) {
     v *= p.alpha;
     if (p.flags & HS_EPI_BIAS) {
-        if (p.flags & HS_EPI_BIAS_M) v += p.bias[m]; else v += *(const f32x4*)(p.bias + n);
+        if (p.flags & HS_EPI_BIAS_M) v += p.bias[m]; else v += bias_n;      // column bias: hoisted by the caller
     }
-    const long idx = cz + (long)m * p.ldc + n;
     if (p.flags & HS_EPI_GELU) {
         u32x2 zb;
         zb[0] = pack2bf(v[0], v[1]); zb[1] = pack2bf(v[2], v[3]);       // autocast: linear1 emits bf16
-        if (p.aux_out) *(u32x2*)((bf16_t*)p.aux_out + idx) = zb;
         v[0] = __uint_as_float(zb[0] << 16); v[1] = __uint_as_float(zb[0] & 0xffff0000u);
         v[2] = __uint_as_float(zb[1] << 16); v[3] = __uint_as_float(zb[1] & 0xffff0000u);
+        f32x4 dg;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { float c, px; gelu_parts(v[e], c, px); v[e] *= c; }
+        for (int e = 0; e < 4; ++e) { float c, px; gelu_parts(v[e], c, px); v[e] *= c; dg[e] = c + px; }
+        // HS_EPI_SAVE_DGELU: keep gelu'(z) (it shares exp(-z^2/2) with gelu) instead of z, so the backward epilogue is
+        // one multiply instead of an erf + exp per element
+        if (p.flags & HS_EPI_SAVE_DGELU) { zb[0] = pack2bf(dg[0], dg[1]); zb[1] = pack2bf(dg[2], dg[3]); }
+        *keep = zb;
     }
     if (p.flags & HS_EPI_GELU_BWD) {
-        const u32x2 zb = *(const u32x2*)((const bf16_t*)p.aux + idx);
-        const float z[4] = {__uint_as_float(zb[0] << 16), __uint_as_float(zb[0] & 0xffff0000u),
-                            __uint_as_float(zb[1] << 16), __uint_as_float(zb[1] & 0xffff0000u)};
+        const float z[4] = {__uint_as_float(zb_in[0] << 16), __uint_as_float(zb_in[0] & 0xffff0000u),
+                            __uint_as_float(zb_in[1] << 16), __uint_as_float(zb_in[1] & 0xffff0000u)};
+        if (p.flags & HS_EPI_SAVE_DGELU) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { float c, px; gelu_parts(z[e], c, px); v[e] *= (c + px); }
-    }
-    if (p.flags & HS_EPI_RESID) v += *(const f32x4*)(p.resid + idx);
-    if (p.out_f32) {
-        if (p.flags & HS_EPI_ATOMIC) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) atomicAdd(&p.out_f32[idx + e], v[e]);
+            for (int e = 0; e < 4; ++e) v[e] *= z[e];                  // aux already holds gelu'(z)
         } else {
-            *(f32x4*)(p.out_f32 + idx) = v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { float c, px; gelu_parts(z[e], c, px); v[e] *= (c + px); }
         }
     }
+    if (p.flags & HS_EPI_RESID) v += res;
+    return v;
+}
+__device__ __forceinline__ void epi_store(const GemmP& p, long idx, f32x4 v, u32x2 keep) {
+    if ((p.flags & HS_EPI_GELU) && p.aux_out) *(u32x2*)((bf16_t*)p.aux_out + idx) = keep;
+    if (p.out_f32) *(f32x4*)(p.out_f32 + idx) = v;
     if (p.out_bf16) {
         u32x2 o;
         o[0] = pack2bf(v[0], v[1]); o[1] = pack2bf(v[2], v[3]);
@@ -353,11 +357,60 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmP p) {
             }
         } else {
             const int rr = lane >> 4, cc = (lane & 15) * 4;
-#pragma unroll 2
-            for (int step = 0; step < 16; ++step) {
-                const int row = step * 4 + rr;
-                const f32x4 v = *(const f32x4*)(my + row * G_EPI_LD + cc);
-                epilogue_vec4(p, cz, mw + row, nw + cc, v, vec_ok);
+            f32x4 csum = {0.f, 0.f, 0.f, 0.f};
+            const bool want_res = (p.flags & HS_EPI_RESID) != 0, want_aux = (p.flags & HS_EPI_GELU_BWD) != 0;
+            if (vec_ok) {
+                f32x4 bias_n = {0.f, 0.f, 0.f, 0.f};
+                if ((p.flags & HS_EPI_BIAS) && !(p.flags & HS_EPI_BIAS_M) && nw + cc + 3 < p.N) bias_n = *(const f32x4*)(p.bias + nw + cc);
+                // groups of 8 steps: 8+8 loads in flight -> all math -> all stores (see epi_math)
+#pragma unroll 1
+                for (int g = 0; g < 2; ++g) {
+                    f32x4 val[8];
+                    u32x2 zbv[8];
+                    bool in[8];
+                    long idx[8];
+#pragma clang loop unroll(full)
+                    for (int i = 0; i < 8; ++i) {
+                        const int m = mw + (g * 8 + i) * 4 + rr, n = nw + cc;
+                        in[i] = m < p.M && n + 3 < p.N;
+                        idx[i] = cz + (long)m * p.ldc + n;
+                        val[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        zbv[i] = u32x2{0u, 0u};
+                        if (want_res && in[i]) val[i] = *(const f32x4*)(p.resid + idx[i]);
+                        if (want_aux && in[i]) zbv[i] = *(const u32x2*)((const bf16_t*)p.aux + idx[i]);
+                    }
+#pragma clang loop unroll(full)
+                    for (int i = 0; i < 8; ++i) {
+                        const int row = (g * 8 + i) * 4 + rr;
+                        const f32x4 v = *(const f32x4*)(my + row * G_EPI_LD + cc);
+                        u32x2 keep = {0u, 0u};
+                        val[i] = epi_math(p, mw + row, v, val[i], zbv[i], bias_n, &keep);
+                        zbv[i] = keep;
+                        if (in[i]) csum += val[i];
+                    }
+#pragma clang loop unroll(full)
+                    for (int i = 0; i < 8; ++i)
+                        if (in[i]) epi_store(p, idx[i], val[i], zbv[i]);
+                }
+            } else {   // rare path (N or ldc not a multiple of 4): element-wise, rolled
+#pragma unroll 1
+                for (int step = 0; step < 16; ++step) {
+                    const int row = step * 4 + rr;
+                    const f32x4 v = *(const f32x4*)(my + row * G_EPI_LD + cc);
+#pragma unroll 1
+                    for (int e = 0; e < 4; ++e) epilogue_store<false>(p, cz, mw + row, nw + cc + e, v[e]);
+                }
+            }
+            if (p.colsum) {   // fused bias gradient: column sums of this wave's 64x64 piece, one atomic per column
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    csum[e] += __shfl_xor(csum[e], 16, 64);
+                    csum[e] += __shfl_xor(csum[e], 32, 64);
+                }
+                if (lane < 16 && nw + cc < p.N) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) atomicAdd(p.colsum + nw + cc + e, csum[e]);
+                }
             }
         }
         if (half + 1 < C::MB / 2) {
@@ -483,6 +536,7 @@ extern "C" int hs_gemm(const hs_gemm_args* a, int prec, void* stream) {
     if ((a->flags & HS_EPI_GELU_BWD) && !a->aux) return HS_ERR_ARG;
     if (a->split_k > 1 && (!(a->flags & HS_EPI_ATOMIC) || a->batch != 1 || !a->out_f32 || a->out_bf16)) return HS_ERR_SHAPE;
     if (prec != HS_PREC_BF16 && prec != HS_PREC_F32) return HS_ERR_ARG;
+    if (a->colsum_out && (prec != HS_PREC_BF16 || (a->N & 3) || (a->ldc & 3) || a->batch != 1 || (a->flags & HS_EPI_ATOMIC))) return HS_ERR_SHAPE;
     const int esz = prec == HS_PREC_BF16 ? 2 : 4;
     const int vec = 16 / esz;  // elements per 16-B chunk
     const bool atr = a->layout == HS_GEMM_TN, btr = a->layout != HS_GEMM_NT;
@@ -496,7 +550,7 @@ extern "C" int hs_gemm(const hs_gemm_args* a, int prec, void* stream) {
     p.A = a->A; p.B = a->B; p.M = a->M; p.N = a->N; p.K = a->K;
     p.lda = a->lda; p.ldb = a->ldb; p.sA = a->strideA; p.sB = a->strideB; p.sC = a->strideC; p.ldc = a->ldc;
     p.out_f32 = a->out_f32; p.out_bf16 = a->out_bf16; p.bias = a->bias; p.resid = a->resid; p.aux = a->aux;
-    p.aux_out = a->aux_out; p.alpha = a->alpha; p.flags = a->flags; p.split_k = a->split_k;
+    p.aux_out = a->aux_out; p.colsum = a->colsum_out; p.alpha = a->alpha; p.flags = a->flags; p.split_k = a->split_k;
     hipStream_t s = (hipStream_t)stream;
     const int zdim = a->split_k > 1 ? a->split_k : a->batch;
     const double mnk = (double)a->M * a->N * a->K * a->batch;

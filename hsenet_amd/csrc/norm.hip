@@ -71,21 +71,22 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 
 // Each wave walks rows (grid-stride), keeps its dgamma/dbeta partials in registers, then the block reduces
 // through LDS and issues one float atomic per column.
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+template <bool DYBF>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restrict__ dy_, const float* __restrict__ x,
                                                             const float* __restrict__ resid, const float* __restrict__ gamma,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ dx_in, float* __restrict__ dx,
                                                             bf16_t* __restrict__ dxb, float* __restrict__ dgamma,
-                                                            float* __restrict__ dbeta, int rows, int d) {
-    __shared__ float red[2][4][LN_MAXCH * 256];
+                                                            float* __restrict__ dbeta, float* __restrict__ dxsum, int rows, int d) {
+    __shared__ float red[3][4][LN_MAXCH * 256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nch = d >> 2;
-    f32x4 g[LN_MAXCH], dg[LN_MAXCH], db[LN_MAXCH];
+    f32x4 g[LN_MAXCH], dg[LN_MAXCH], db[LN_MAXCH], ds[LN_MAXCH];
 #pragma unroll
     for (int i = 0; i < LN_MAXCH; ++i) {
         const int ch = lane + 64 * i;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { dg[i][e] = 0.f; db[i][e] = 0.f; g[i][e] = 0.f; }
+        for (int e = 0; e < 4; ++e) { dg[i][e] = 0.f; db[i][e] = 0.f; g[i][e] = 0.f; ds[i][e] = 0.f; }
         if (ch < nch) g[i] = *(const f32x4*)(gamma + ch * 4);
     }
     for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
@@ -98,7 +99,14 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
             if (ch < nch) {
                 f32x4 xv = *(const f32x4*)(x + (long)row * d + ch * 4);
                 if (resid) xv += *(const f32x4*)(resid + (long)row * d + ch * 4);
-                const f32x4 dv = *(const f32x4*)(dy + (long)row * d + ch * 4);
+                f32x4 dv;
+                if (DYBF) {
+                    const u32x2 pk = *(const u32x2*)((const bf16_t*)dy_ + (long)row * d + ch * 4);
+                    dv[0] = __uint_as_float(pk[0] << 16); dv[1] = __uint_as_float(pk[0] & 0xffff0000u);
+                    dv[2] = __uint_as_float(pk[1] << 16); dv[3] = __uint_as_float(pk[1] & 0xffff0000u);
+                } else {
+                    dv = *(const f32x4*)((const float*)dy_ + (long)row * d + ch * 4);
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     xh[i][e] = (xv[e] - mu) * rs;
@@ -119,6 +127,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = rs * (gy[i][e] - c1 - xh[i][e] * c2);
                 if (dx_in) o += *(const f32x4*)(dx_in + (long)row * d + ch * 4);
+                ds[i] += o;
                 if (dx) *(f32x4*)(dx + (long)row * d + ch * 4) = o;
                 if (dxb) {
                     u32x2 pk;
@@ -129,20 +138,24 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
             }
         }
     }
-    if (!dgamma && !dbeta) return;
+    if (!dgamma && !dbeta && !dxsum) return;
 #pragma unroll
     for (int i = 0; i < LN_MAXCH; ++i)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             red[0][wave][(lane + 64 * i) * 4 + e] = dg[i][e];
             red[1][wave][(lane + 64 * i) * 4 + e] = db[i][e];
+            red[2][wave][(lane + 64 * i) * 4 + e] = ds[i][e];
         }
     __syncthreads();
     for (int col = threadIdx.x; col < d; col += 256) {
         const float a = red[0][0][col] + red[0][1][col] + red[0][2][col] + red[0][3][col];
         const float b = red[1][0][col] + red[1][1][col] + red[1][2][col] + red[1][3][col];
+        const float c = red[2][0][col] + red[2][1][col] + red[2][2][col] + red[2][3][col];
         if (dgamma) atomicAdd(&dgamma[col], a);
         if (dbeta) atomicAdd(&dbeta[col], b);
+        if (dxsum) atomicAdd(&dxsum[col], c);     // column sums of the produced dx: the bias gradient of the Linear
+                                                  // whose output gradient this dx is (no separate colsum pass)
     }
 }
 
@@ -157,16 +170,20 @@ extern "C" int hs_layernorm_fwd(const float* x, const float* resid, const float*
     return HS_OK;
 }
 
-extern "C" int hs_layernorm_bwd(const float* dy, const float* x, const float* resid, const float* gamma, const float* mean,
-                                const float* rstd, const float* dx_in, float* dx, void* dx_bf16, float* dgamma,
-                                float* dbeta, int rows, int d, void* stream) {
+extern "C" int hs_layernorm_bwd(const void* dy, int dy_is_bf16, const float* x, const float* resid, const float* gamma,
+                                const float* mean, const float* rstd, const float* dx_in, float* dx, void* dx_bf16,
+                                float* dgamma, float* dbeta, float* dxsum, int rows, int d, void* stream) {
     if (!dy || !x || !gamma || !mean || !rstd || (!dx && !dx_bf16)) return HS_ERR_ARG;
     if (rows < 1 || d < 4 || (d & 3) || d > LN_MAXCH * 256) return HS_ERR_SHAPE;
     int blocks = (rows + 3) / 4;
     if (blocks > 1024) blocks = 1024;
-    ProfScope prof(HS_PROF_LN_BWD, stream, 0, (double)rows * d * (8 + (resid ? 4 : 0) + (dx_in ? 4 : 0) + (dx ? 4 : 0) + (dx_bf16 ? 2 : 0)));
-    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, x, resid, gamma, mean, rstd,
-                       dx_in, dx, (bf16_t*)dx_bf16, dgamma, dbeta, rows, d);
+    ProfScope prof(HS_PROF_LN_BWD, stream, 0, (double)rows * d * (4 + (dy_is_bf16 ? 2 : 4) + (resid ? 4 : 0) + (dx_in ? 4 : 0) + (dx ? 4 : 0) + (dx_bf16 ? 2 : 0)));
+    if (dy_is_bf16)
+        hipLaunchKernelGGL(layernorm_bwd_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, x, resid, gamma, mean, rstd,
+                           dx_in, dx, (bf16_t*)dx_bf16, dgamma, dbeta, dxsum, rows, d);
+    else
+        hipLaunchKernelGGL(layernorm_bwd_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, x, resid, gamma, mean, rstd,
+                           dx_in, dx, (bf16_t*)dx_bf16, dgamma, dbeta, dxsum, rows, d);
     HS_CHECK_LAUNCH();
     return HS_OK;
 }

@@ -8,7 +8,7 @@
 //   o = softmax(q k^T / 8) v                             attn_fwd (flash, lse saved)
 //   xm = x + o Wo^T + bo                                 gemm NT, epilogue bias+residual -> fp32
 //   h2 = LN2(xm)                                         layernorm_fwd
-//   a = gelu(h2 W1^T + b1)                               gemm NT, epilogue bias+GELU -> bf16 (z saved)
+//   a = gelu(h2 W1^T + b1)                               gemm NT, epilogue bias+GELU -> bf16 (gelu'(z) saved)
 //   x' = xm + a W2^T + b2                                gemm NT, epilogue bias+residual -> fp32 (= hidden[l])
 // The residual stream (x, xm) is fp32 throughout, as under the reference's autocast policy.
 #include "common.h"
@@ -43,7 +43,7 @@ Layout make_layout(const hs_vit_desc& c) {
     L.fstats = take(2 * M * 4);
     const bool bwd = c.save_for_bwd && c.prec == HS_PREC_BF16;
     L.dx = take(bwd ? M * d * 4 : 0);
-    L.dh = take(bwd ? M * d * 4 : 0);
+    L.dh = take(bwd ? M * d * 2 : 0);      // dgrad outputs feeding LN backward: bf16 (autocast's Linear backward dtype)
     L.dxb = take(bwd ? M * d * 2 : 0);
     L.dob = take(bwd ? M * d * 2 : 0);
     L.dz = take(bwd ? M * mlp * 2 : 0);
@@ -66,8 +66,10 @@ int check_desc(const hs_vit_desc* c) {
 enum { P_W1 = 0, P_B1, P_W2, P_B2, P_N1W, P_N1B, P_WO, P_BO, P_WQKV, P_N2W, P_N2B, P_COUNT };
 
 int gemm(int prec, int layout, const void* A, const void* Bm, int M, int N, int K, long lda, long ldb, float* of32, void* obf,
-         long ldc, const float* bias, const float* resid, const void* aux, void* aux_out, int flags, int split_k, void* s) {
+         long ldc, const float* bias, const float* resid, const void* aux, void* aux_out, int flags, int split_k, void* s,
+         float* colsum = nullptr) {
     hs_gemm_args g = {};
+    g.colsum_out = colsum;
     g.A = A; g.B = Bm; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.batch = 1;
     g.out_f32 = of32; g.out_bf16 = obf; g.ldc = ldc; g.bias = bias; g.resid = resid; g.aux = aux; g.aux_out = aux_out;
     g.alpha = 1.0f; g.flags = flags; g.layout = layout; g.split_k = split_k;
@@ -149,7 +151,7 @@ extern "C" int hs_vit_blocks_fwd(const hs_vit_desc* desc, const float* x0, const
         RC(gemm(c.prec, HS_GEMM_NT, o, wo, M, d, d, d, d, xmid, nullptr, d, p[P_BO], xin, nullptr, nullptr, HS_EPI_BIAS | HS_EPI_RESID, 1, stream));
         RC(hs_layernorm_fwd(xmid, nullptr, p[P_N2W], p[P_N2B], bf ? nullptr : (float*)h2, bf ? h2 : nullptr, st + 2 * M, st + 3 * M, M, d, 1e-5f, stream));
         RC(gemm(c.prec, HS_GEMM_NT, h2, w1, M, mlp, d, d, d, bf ? nullptr : (float*)a, bf ? a : nullptr, mlp, p[P_B1], nullptr, nullptr,
-                c.save_for_bwd ? z : nullptr, HS_EPI_BIAS | HS_EPI_GELU, 1, stream));
+                c.save_for_bwd ? z : nullptr, HS_EPI_BIAS | HS_EPI_GELU | HS_EPI_SAVE_DGELU, 1, stream));
         RC(gemm(c.prec, HS_GEMM_NT, a, w2, M, d, mlp, mlp, mlp, xout, nullptr, d, p[P_B2], xmid, nullptr, nullptr, HS_EPI_BIAS | HS_EPI_RESID, 1, stream));
     }
     float* fs = (float*)(w + L.fstats);
@@ -173,7 +175,7 @@ extern "C" int hs_vit_blocks_bwd(const hs_vit_desc* desc, const float* x0, const
     const int M = c.B * c.N, d = c.d, mlp = c.mlp;
     const size_t Md = (size_t)M * d;
     float* dx = (float*)(w + L.dx);
-    float* dh = (float*)(w + L.dh);
+    bf16_t* dh = (bf16_t*)(w + L.dh);
     bf16_t* dxb = (bf16_t*)(w + L.dxb);
     bf16_t* dob = (bf16_t*)(w + L.dob);
     bf16_t* dz = (bf16_t*)(w + L.dz);
@@ -183,7 +185,9 @@ extern "C" int hs_vit_blocks_bwd(const hs_vit_desc* desc, const float* x0, const
 
     if (l_hi == c.L) {
         const float* fs = (const float*)(w + L.fstats);
-        RC(hs_layernorm_bwd(dy, hidden + (size_t)(c.L - 1) * Md, nullptr, np[0], fs, fs + M, nullptr, dx, dxb, ng[0], ng[1], M, d, stream));
+        // (each LN backward also emits the column sums of the dx it produces = the bias gradient of the Linear below it)
+        RC(hs_layernorm_bwd(dy, 0, hidden + (size_t)(c.L - 1) * Md, nullptr, np[0], fs, fs + M, nullptr, dx, dxb, ng[0], ng[1],
+                            lg[(size_t)(c.L - 1) * P_COUNT + P_B2], M, d, stream));
     }
     for (int l = l_hi - 1; l >= l_lo; --l) {
         const float* const* p = lp + (size_t)l * P_COUNT;
@@ -201,27 +205,26 @@ extern "C" int hs_vit_blocks_bwd(const hs_vit_desc* desc, const float* x0, const
         const bf16_t* wl = (const bf16_t*)(w + L.wbf) + (size_t)l * L.per_w;
         const bf16_t *wqkv = wl, *wo = wl + 3 * d * d, *w1 = wl + 4 * d * d, *w2 = wl + 4 * d * d + (size_t)mlp * d;
 
-        // ---- MLP branch: x' = xm + W2 gelu(W1 h2 + b1) + b2
-        RC(hs_colsum(dxb, 1, g[P_B2], M, d, d, stream));
+        // ---- MLP branch: x' = xm + W2 gelu(W1 h2 + b1) + b2        (db2 came with the dx that entered this layer)
         RC(gemm(P, HS_GEMM_TN, dxb, a, d, mlp, M, d, mlp, g[P_W2], nullptr, mlp, nullptr, nullptr, nullptr, nullptr, HS_EPI_ATOMIC,
                 wgrad_split(d, mlp, M), stream));
-        RC(gemm(P, HS_GEMM_NN, dxb, w2, M, mlp, d, d, mlp, nullptr, dz, mlp, nullptr, nullptr, z, nullptr, HS_EPI_GELU_BWD, 1, stream));
-        RC(hs_colsum(dz, 1, g[P_B1], M, mlp, mlp, stream));
+        RC(gemm(P, HS_GEMM_NN, dxb, w2, M, mlp, d, d, mlp, nullptr, dz, mlp, nullptr, nullptr, z, nullptr,
+                HS_EPI_GELU_BWD | HS_EPI_SAVE_DGELU, 1, stream, g[P_B1]));                 // db1 = colsum(dz), fused
         RC(gemm(P, HS_GEMM_TN, dz, h2, mlp, d, M, mlp, d, g[P_W1], nullptr, d, nullptr, nullptr, nullptr, nullptr, HS_EPI_ATOMIC,
                 wgrad_split(mlp, d, M), stream));
-        RC(gemm(P, HS_GEMM_NN, dz, w1, M, d, mlp, mlp, d, dh, nullptr, d, nullptr, nullptr, nullptr, nullptr, 0, 1, stream));
-        RC(hs_layernorm_bwd(dh, xmid, nullptr, p[P_N2W], st + 2 * M, st + 3 * M, dx, dx, dxb, g[P_N2W], g[P_N2B], M, d, stream));
-        // ---- attention branch: xm = x + Wo attn(LN1 x) + bo
-        RC(hs_colsum(dxb, 1, g[P_BO], M, d, d, stream));
+        RC(gemm(P, HS_GEMM_NN, dz, w1, M, d, mlp, mlp, d, nullptr, dh, d, nullptr, nullptr, nullptr, nullptr, 0, 1, stream));
+        RC(hs_layernorm_bwd(dh, 1, xmid, nullptr, p[P_N2W], st + 2 * M, st + 3 * M, dx, dx, dxb, g[P_N2W], g[P_N2B], g[P_BO], M, d, stream));
+        // ---- attention branch: xm = x + Wo attn(LN1 x) + bo         (dbo came from the LN2 backward just above)
         RC(gemm(P, HS_GEMM_TN, dxb, o, d, d, M, d, d, g[P_WO], nullptr, d, nullptr, nullptr, nullptr, nullptr, HS_EPI_ATOMIC,
                 wgrad_split(d, d, M), stream));
         RC(gemm(P, HS_GEMM_NN, dxb, wo, M, d, d, d, d, nullptr, dob, d, nullptr, nullptr, nullptr, nullptr, 0, 1, stream));
         RC(hs_attn_bwd(qkv, o, dob, lse, dqkv, delta, c.B, c.N, c.H, 64, stream));
         RC(gemm(P, HS_GEMM_TN, dqkv, h1, 3 * d, d, M, 3 * d, d, g[P_WQKV], nullptr, d, nullptr, nullptr, nullptr, nullptr, HS_EPI_ATOMIC,
                 wgrad_split(3 * d, d, M), stream));
-        RC(gemm(P, HS_GEMM_NN, dqkv, wqkv, M, d, 3 * d, 3 * d, d, dh, nullptr, d, nullptr, nullptr, nullptr, nullptr, 0, 1, stream));
+        RC(gemm(P, HS_GEMM_NN, dqkv, wqkv, M, d, 3 * d, 3 * d, d, nullptr, dh, d, nullptr, nullptr, nullptr, nullptr, 0, 1, stream));
         float* dxo = (l == 0) ? dx0 : dx;
-        RC(hs_layernorm_bwd(dh, xin, nullptr, p[P_N1W], st, st + M, dx, dxo, l == 0 ? nullptr : dxb, g[P_N1W], g[P_N1B], M, d, stream));
+        float* b2_below = (l == 0) ? nullptr : lg[(size_t)(l - 1) * P_COUNT + P_B2];
+        RC(hs_layernorm_bwd(dh, 1, xin, nullptr, p[P_N1W], st, st + M, dx, dxo, l == 0 ? nullptr : dxb, g[P_N1W], g[P_N1B], b2_below, M, d, stream));
     }
     return HS_OK;
 }

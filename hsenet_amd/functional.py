@@ -55,10 +55,10 @@ def _f32(t: torch.Tensor) -> torch.Tensor:
 # raw ops
 # ----------------------------------------------------------------------------------------------------
 def gemm(A: torch.Tensor, Bm: torch.Tensor, layout: int, *, prec: int, out_f32: Optional[torch.Tensor] = None,
-         out_bf16: Optional[torch.Tensor] = None, bias=None, resid=None, aux=None, aux_out=None, alpha: float = 1.0,
-         flags: int = 0, split_k: int = 1) -> None:
+         out_bf16: Optional[torch.Tensor] = None, bias=None, resid=None, aux=None, aux_out=None, colsum_out=None,
+         alpha: float = 1.0, flags: int = 0, split_k: int = 1) -> None:
     """C[M,N] = sum_k A(m,k) B(n,k); 2-D or batched 3-D operands (see include/hsenet_hip.h)."""
-    _need(A, Bm, out_f32, out_bf16, bias, resid, aux, aux_out)
+    _need(A, Bm, out_f32, out_bf16, bias, resid, aux, aux_out, colsum_out)
     want = torch.bfloat16 if prec == L.PREC_BF16 else torch.float32
     if A.dtype != want or Bm.dtype != want:
         raise L.HsError(f"gemm operands must be {want}")
@@ -82,7 +82,7 @@ def gemm(A: torch.Tensor, Bm: torch.Tensor, layout: int, *, prec: int, out_f32: 
     g.strideB = b2[0] * b2[1] if Bm.dim() == 3 else 0
     g.strideC = M * N
     g.out_f32, g.out_bf16, g.ldc = _p(out_f32), _p(out_bf16), N
-    g.bias, g.resid, g.aux, g.aux_out = _p(bias), _p(resid), _p(aux), _p(aux_out)
+    g.bias, g.resid, g.aux, g.aux_out, g.colsum_out = _p(bias), _p(resid), _p(aux), _p(aux_out), _p(colsum_out)
     g.alpha, g.flags, g.layout, g.split_k = alpha, flags, layout, split_k
     L.call("hs_gemm", C.byref(g), prec, _s())
 
@@ -222,8 +222,8 @@ class LayerNormFn(torch.autograd.Function):
         dx = torch.empty_like(x)
         dg = torch.zeros_like(gamma)
         db = torch.zeros_like(gamma)
-        L.call("hs_layernorm_bwd", dy.data_ptr(), x.data_ptr(), _p(resid), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-               None, dx.data_ptr(), None, dg.data_ptr(), db.data_ptr(), rows, d, _s())
+        L.call("hs_layernorm_bwd", dy.data_ptr(), 0, x.data_ptr(), _p(resid), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+               None, dx.data_ptr(), None, dg.data_ptr(), db.data_ptr(), None, rows, d, _s())
         return dx, (dx if ctx.has_resid else None), dg, db, None
 
 

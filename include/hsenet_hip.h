@@ -43,6 +43,8 @@ extern "C" {
 #define HS_EPI_RESID 8
 #define HS_EPI_ATOMIC 16    /* out_f32 += v with float atomics (split-K wgrad; caller zeroes out_f32)          */
 #define HS_EPI_BIAS_M 32    /* bias indexed by m (row) instead of n                                         */
+#define HS_EPI_SAVE_DGELU 64 /* with HS_EPI_GELU: aux_out receives gelu'(z) instead of z; with HS_EPI_GELU_BWD: aux holds
+                               gelu'(z) (the backward epilogue is then a plain multiply)                        */
 
 typedef struct hs_gemm_args {
     const void* A;          /* bf16 (HS_PREC_BF16) or float (HS_PREC_F32) */
@@ -58,6 +60,7 @@ typedef struct hs_gemm_args {
     const float* resid;     /* [M][ldc] fp32 */
     const void* aux;        /* [M][ldc] pre-activation z for HS_EPI_GELU_BWD (bf16; float in F32 mode) */
     void* aux_out;          /* [M][ldc] pre-activation saved by HS_EPI_GELU (bf16), or NULL */
+    float* colsum_out;      /* [N] or NULL: += column sums of the stored values (bias gradient fused into a dgrad) */
     float alpha;
     int flags;
     int layout;             /* HS_GEMM_* */
@@ -93,11 +96,12 @@ int hs_assemble_tokens_bwd(const float* dtok, const float* pe_pos, const float* 
  * x fp32 [rows][d]; optional resid added first (y = LN(x + resid)); writes y as fp32 and/or bf16; mean/rstd optional. */
 int hs_layernorm_fwd(const float* x, const float* resid, const float* gamma, const float* beta, float* y_f32,
                      void* y_bf16, float* mean, float* rstd, int rows, int d, float eps, void* stream);
-/* dx = LNbwd(dy) (+ dx_in when accumulate!=0); also emits bf16 copy of the result; dgamma/dbeta accumulate
- * atomically (caller zeroes).  x (and resid) are the forward inputs. */
-int hs_layernorm_bwd(const float* dy, const float* x, const float* resid, const float* gamma, const float* mean,
-                     const float* rstd, const float* dx_in, float* dx, void* dx_bf16, float* dgamma, float* dbeta,
-                     int rows, int d, void* stream);
+/* dx = LNbwd(dy) (+ dx_in when given); dy fp32 or bf16 (dy_is_bf16); also emits a bf16 copy of the result;
+ * dgamma/dbeta accumulate atomically (caller zeroes).  x (and resid) are the forward inputs.  dxsum (optional, [d])
+ * accumulates the column sums of the produced dx = the bias gradient of the Linear this dx is the output-gradient of. */
+int hs_layernorm_bwd(const void* dy, int dy_is_bf16, const float* x, const float* resid, const float* gamma,
+                     const float* mean, const float* rstd, const float* dx_in, float* dx, void* dx_bf16, float* dgamma,
+                     float* dbeta, float* dxsum, int rows, int d, void* stream);
 
 /* ---- K4: global multi-head self-attention core of MONAI SABlock: softmax(q k^T * dh^-0.5) v, no mask, no
  * bias, non-causal (reached from the hot loops vit.py:352-354,464-466).  qkv: [B][N][3][H][dh] exactly as

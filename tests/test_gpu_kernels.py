@@ -69,6 +69,18 @@ def test_gemm_epilogues(dev):
     zr = zz.float().double().requires_grad_()
     (g,) = torch.autograd.grad(F.gelu(zr).sum(), zr)
     assert rel(o32, acc * g) < 1e-4
+    # forward keeps gelu'(z) instead of z; backward multiplies by it (HS_EPI_SAVE_DGELU)
+    g16 = torch.empty_like(o16)
+    Fn.gemm(a, b, L.GEMM_NT, prec=L.PREC_BF16, out_bf16=o16, bias=bias, aux_out=g16, flags=L.EPI_BIAS | L.EPI_GELU | L.EPI_SAVE_DGELU)
+    zq = z16.float().double().requires_grad_()
+    (gq,) = torch.autograd.grad(F.gelu(zq).sum(), zq)
+    assert rel(g16.float(), gq) < 4e-3 and rel(o16.float(), F.gelu(z16.float())) < 4e-3
+    Fn.gemm(a, b, L.GEMM_NT, prec=L.PREC_BF16, out_f32=o32, aux=g16, flags=L.EPI_GELU_BWD | L.EPI_SAVE_DGELU)
+    assert rel(o32, acc * g16.double()) < 1e-5
+    # fused column sums of the stored values (bias gradient of a dgrad), on top of an existing value
+    cs = torch.ones(N, device=dev)
+    Fn.gemm(a, b, L.GEMM_NT, prec=L.PREC_BF16, out_bf16=o16, colsum_out=cs)
+    assert rel(cs, 1.0 + acc.sum(0)) < 1e-4
     # split-K atomic accumulate on top of an existing value, alpha
     Mo = 336
     base = rnd((Mo, N), 8, dev)
@@ -160,6 +172,24 @@ def test_layernorm(dev, rows, d):
     out.backward(dy)
     assert rel(x.grad, gx) < 1e-5 and rel(r.grad, gx) < 1e-5
     assert rel(g.grad, gg) < 1e-5 and rel(b.grad, gb) < 1e-5
+
+
+def test_layernorm_bwd_bf16_dy_and_colsum(dev):
+    from hsenet_amd import functional as Fn, _lib as L
+    rows, d = 777, 768
+    x, g, b = rnd((rows, d), 55, dev, 2.0), 1 + 0.1 * rnd((d,), 56, dev), rnd((d,), 57, dev)
+    dyb, dx_in = rnd((rows, d), 58, dev).bfloat16(), rnd((rows, d), 59, dev)
+    _, _, mean, rstd = Fn.layernorm_fwd(x, g, b)
+    dx, dxb = torch.empty_like(x), torch.empty(rows, d, dtype=torch.bfloat16, device=dev)
+    dg, db, dsum = torch.zeros(d, device=dev), torch.zeros(d, device=dev), torch.zeros(d, device=dev)
+    L.call("hs_layernorm_bwd", dyb.data_ptr(), 1, x.data_ptr(), None, g.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx_in.data_ptr(),
+           dx.data_ptr(), dxb.data_ptr(), dg.data_ptr(), db.data_ptr(), dsum.data_ptr(), rows, d, torch.cuda.current_stream().cuda_stream)
+    xr, gr, br = x.double().requires_grad_(), g.double().requires_grad_(), b.double().requires_grad_()
+    ref = F.layer_norm(xr, (d,), gr, br, 1e-5)
+    gx, gg, gb = torch.autograd.grad((ref * dyb.double()).sum(), (xr, gr, br))
+    want = gx + dx_in.double()
+    assert rel(dx, want) < 1e-5 and rel(dxb.float(), want) < 4e-3
+    assert rel(dg, gg) < 1e-5 and rel(db, gb) < 1e-5 and rel(dsum, want.sum(0)) < 1e-5
 
 
 @pytest.mark.parametrize("geom", [((2, 1, 8, 32, 32), (4, 16, 16)), ((1, 1, 32, 64, 48), (16, 16, 16)), ((1, 2, 4, 6, 10), (2, 3, 5))])
