@@ -44,6 +44,20 @@ def flops_per_volume(Np, Pd, d, L):
     return fwd, 3.0 * fwd
 
 
+def measured_traffic(kernel, batch):
+    """HBM bytes per launch of `kernel` from committed rocprofv3 --pmc passes (profiles/r01_traffic.json, produced by
+    tools/collect_traffic.sh: FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled as the MI355X microarch
+    guide prescribes).  None when no measurement for this kernel / batch is committed."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+        e = t.get(kernel)
+        if e and int(e.get("batch", -1)) == int(batch):
+            return e["hbm_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
+
+
 def cpu_baseline(geom, threads, max_seconds=60.0):
     """the oracle (port of the reference's CPU path) on the host cores: 1 volume fwd+bwd, fp32."""
     from oracle import ref_cpu as R
@@ -78,11 +92,17 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: no GPU visible (the HIP path has no CPU fallback)")
+    # HS_BENCH_BACKEND=gloo + fewer visible GPUs than ranks: rehearsal of the N>1 control flow on a 1-GPU box
+    backend = os.environ.get("HS_BENCH_BACKEND", "nccl")
+    local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     if a.gpus != world and rank == 0:
         print(f"[bench] note: --gpus {a.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
 
@@ -101,6 +121,7 @@ def main():
     vols = [torch.from_numpy(rng.random((a.batch, 1) + img, dtype=np.float32)).to(dev) for _ in range(2)]
 
     def sync():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -120,23 +141,26 @@ def main():
     finite = bool(torch.isfinite(eng.y).all().item())
 
     # ---- instrumented pass: per-kernel-class HIP-event timing on the launch stream, same steps --------------
+    # EVERY rank runs these steps (they contain the gradient all-reduces); only rank 0 records and reads the timers.
     roof, classes = None, []
-    if not a.no_roofline and rank == 0:
-        L.call("hs_prof_enable", 1)
+    if not a.no_roofline:
+        if rank == 0:
+            L.call("hs_prof_enable", 1)
         for i in range(max(1, min(a.steps, 3))):
             eng.train_step(vols[i % 2])
         torch.cuda.synchronize()
-        classes = profile_classes()
-        L.call("hs_prof_enable", 0)
-        for c in classes:
-            c["avg_us"] = 1e3 * c["total_ms"] / c["launches"]
-            c["tflops"] = c["flops"] / (c["total_ms"] * 1e-3) / 1e12 if c["flops"] else 0.0
-            c["gbs"] = c["bytes"] / (c["total_ms"] * 1e-3) / 1e9
-        mf = [c for c in classes if c["flops"]]
-        dom = max(mf, key=lambda c: c["total_ms"])
-        roof = dict(kernel=dom["name"], bound="mfma", achieved=round(dom["tflops"], 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
-                    frac=round(dom["tflops"] / PEAK_BF16_TFLOPS, 4), traffic=None,
-                    avg_launch_us=round(dom["avg_us"], 2), flops_per_launch=dom["flops"] / dom["launches"])
+        if rank == 0:
+            classes = profile_classes()
+            L.call("hs_prof_enable", 0)
+            for c in classes:
+                c["avg_us"] = 1e3 * c["total_ms"] / c["launches"]
+                c["tflops"] = c["flops"] / (c["total_ms"] * 1e-3) / 1e12 if c["flops"] else 0.0
+                c["gbs"] = c["bytes"] / (c["total_ms"] * 1e-3) / 1e9
+            mf = [c for c in classes if c["flops"]]
+            dom = max(mf, key=lambda c: c["total_ms"])
+            roof = dict(kernel=dom["name"], bound="mfma", achieved=round(dom["tflops"], 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
+                        frac=round(dom["tflops"] / PEAK_BF16_TFLOPS, 4), traffic=measured_traffic(dom["name"], a.batch),
+                        avg_launch_us=round(dom["avg_us"], 2), flops_per_launch=dom["flops"] / dom["launches"])
     if world > 1:
         dist.barrier()
 

@@ -16,7 +16,7 @@ struct GemmP {
     long lda, ldb, sA, sB, sC, ldc;
     float* out_f32; void* out_bf16;
     const float* bias; const float* resid; const void* aux; void* aux_out; float* colsum;
-    float alpha; int flags; int split_k; int tiles_m;
+    float alpha; int flags; int split_k; int tiles_m, tiles_n;
 };
 
 template <bool F32AUX>
@@ -234,25 +234,29 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmP p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = BIG ? wave >> 2 : wave >> 1, wn = BIG ? wave & 3 : wave & 1;
     const int row0 = wm * (C::MB * 32), col0 = wn * 64;        // this wave's tile inside the block tile
-    // XCD-aware tile order.  Blocks are dealt round-robin over the 8 XCDs (b % 8 labels the blocks sharing an L2), so
-    // first give each XCD a CONTIGUOUS range of a virtual order v (bijective form, cdna guide section 5), then walk v
-    // in groups of 4 row tiles x all column tiles (column-major inside a group): the ~32 blocks an XCD runs at once
-    // form a patch of output tiles that re-use each other's A rows and B columns out of that XCD's L2.
-    // Placement only affects speed, never results.
-    int tm, tn;
+    // XCD-aware tile order.  A CU can pull only ~13 B/clk from beyond its XCD's L2 (a lone block needs ~3000 cycles
+    // per K-tile), so speed hinges on the ~32 blocks an XCD runs at once SHARING operand tiles out of that L2.
+    // Blocks are dealt round-robin over the 8 XCDs (b % 8 labels the blocks sharing an L2): give each XCD a
+    // CONTIGUOUS range of a virtual order v (bijective form, cdna guide section 5); v walks split-K slices slowest
+    // (blocks of one slice share A and B, different slices share nothing), and inside a slice groups of GM row tiles x
+    // all column tiles, column-major inside a group (GM wider when there are few column tiles, so weight tiles are
+    // shared by more blocks).  Placement only affects speed, never results.
+    int tm, tn, z;
     {
         const int nb = gridDim.x, b = blockIdx.x;
         const int q = nb >> 3, r = nb & 7, x = b & 7;
-        const int v = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
-        const int tiles_n = nb / p.tiles_m;
-        const int per_group = 4 * tiles_n;
+        int v = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+        const int tiles = p.tiles_m * p.tiles_n;
+        z = v / tiles;
+        v -= z * tiles;
+        const int GM = p.tiles_n >= 8 ? 4 : (p.tiles_n >= 4 ? 8 : 16);
+        const int per_group = GM * p.tiles_n;
         const int g = v / per_group, w = v - g * per_group;
-        const int gm = min(4, p.tiles_m - g * 4);
-        tm = g * 4 + w % gm;
+        const int gm = min(GM, p.tiles_m - g * GM);
+        tm = g * GM + w % gm;
         tn = w / gm;
     }
     const int m0 = tm * 256, n0 = tn * C::BN;
-    const int z = blockIdx.z;
     const int bz = p.split_k > 1 ? 0 : z;
     const bf16_t* A = (const bf16_t*)p.A + bz * p.sA;
     const bf16_t* B = (const bf16_t*)p.B + bz * p.sB;
@@ -563,7 +567,8 @@ extern "C" int hs_gemm(const hs_gemm_args* a, int prec, void* stream) {
         const long big_blocks = (long)p.tiles_m * ((a->N + 255) / 256) * zdim;
         const char* force = getenv("HS_GEMM_TILE");   // "big" / "small": tools/bench_gemm.py A/B runs
         const bool big = force ? (force[0] == 'b') : (a->layout != HS_GEMM_TN && big_blocks >= 230);
-        dim3 grid(p.tiles_m * ((a->N + (big ? 255 : 127)) / (big ? 256 : 128)), 1, zdim);
+        p.tiles_n = (a->N + (big ? 255 : 127)) / (big ? 256 : 128);
+        dim3 grid(p.tiles_m * p.tiles_n * zdim, 1, 1);
 #define HS_LAUNCH(ATR, BTR)                                                                                          \
     do {                                                                                                             \
         if (big) hipLaunchKernelGGL((gemm_bf16_kernel<ATR, BTR, true>), grid, dim3(512), 0, s, p);                    \

@@ -28,3 +28,18 @@ for name, lay, m, n, k in shapes:
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / reps
     print(f"{name:16s} M={m} N={n} K={k}: {us:8.1f} us  {2.0*m*n*k/us/1e6:7.1f} TFLOP/s", flush=True)
+if only == "TNvsNT":
+    m, n, k = 3072, 768, 40970 // 8 * 8
+    for lay, name in ((L.GEMM_NT, "NT"), (L.GEMM_NN, "NN"), (L.GEMM_TN, "TN")):
+        for split in (1, 7):
+            a = torch.randn((m, k) if lay != L.GEMM_TN else (k, m), device=dev).bfloat16()
+            b = torch.randn((n, k) if lay == L.GEMM_NT else (k, n), device=dev).bfloat16()
+            out = torch.zeros(m, n, device=dev)
+            kw = dict(out_f32=out, flags=L.EPI_ATOMIC, split_k=split)
+            for _ in range(3): Fn.gemm(a, b, lay, prec=L.PREC_BF16, **kw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps): Fn.gemm(a, b, lay, prec=L.PREC_BF16, **kw)
+            e1.record(); torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / reps
+            print(f"{name} split {split}: {us:8.1f} us  {2.0*m*n*k/us/1e6:7.1f} TFLOP/s", flush=True)
