@@ -12,6 +12,7 @@
 // Tiles are staged global -> registers (range-checked buffer loads: rows >= N read 0) -> LDS, written after
 // the MFMA phase, one barrier per tile, double-buffered.
 #include "common.h"
+#include <type_traits>
 
 #define NEG_INF (-__builtin_inff())
 
@@ -57,7 +58,7 @@ __device__ __forceinline__ void store_dT(bf16_t* rowptr, const f32x16 (&acc)[2],
 // ------------------------------------------------------------------------------------------------------
 // forward, bf16.  grid (ceil(N/128), H, B), 4 waves x 32 queries, 64-key tiles.
 // ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
+__global__ __launch_bounds__(256, 3) void attn_fwd_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
                                                             float* __restrict__ lse, int N, int H, float scale) {
     __shared__ __attribute__((aligned(16))) char smem[32768];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, c = lane & 31;
@@ -95,14 +96,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const bf16_t* __r
     float m = NEG_INF, l = 0.f;
     f32x16 oacc[2] = {zero16(), zero16()};
     const int nt = (N + 63) >> 6;
-    gload(0);
-    swrite(0);
-    __syncthreads();
-    int cur = 0;
-    for (int t = 0; t < nt; ++t) {
-        const bool more = t + 1 < nt;
-        if (more) gload(t + 1);
-        const char* Kl = smem + cur * 16384;
+    // one 64-key tile.  LAST (the only tile that can hold keys >= N) is a separate instantiation, so the steady-state
+    // loop carries no masking code at all (if-converted it was ~34 v_cndmask + exec juggling on every tile).
+    auto tile = [&](int t, auto stage_tag, auto last_tag) {
+        constexpr bool LAST = decltype(last_tag)::value;
+        constexpr int ST = decltype(stage_tag)::value;     // compile-time stage: LDS addresses = hoisted base + immediate
+        const char* Kl = smem + ST * 16384;
         const char* Vl = Kl + 8192;
         f32x16 s[2] = {zero16(), zero16()};
 #pragma unroll
@@ -110,8 +109,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const bf16_t* __r
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
                 s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Kl, kb * 32 + c, ks, h), qf[ks], s[kb], 0, 0, 0);
-        if (t == nt - 1 && (N & 63)) {
-            asm volatile("" ::: "memory");   // keep this a wave-uniform BRANCH: if-converted it is 33 v_cndmask on every tile
+        if (LAST) {
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -125,7 +123,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const bf16_t* __r
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float mn = fmaxf(m, mx);
-        const float alpha = __builtin_amdgcn_exp2f((m - mn) * c2);
         const float mc = mn * c2;
         float rs_ = 0.f;
 #pragma unroll
@@ -137,12 +134,18 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const bf16_t* __r
                 rs_ += p;
             }
         rs_ += __shfl_xor(rs_, 32, 64);
-        l = l * alpha + rs_;
-        m = mn;
+        // rescale only when some query's running max moved (wave-uniform test): after the first few tiles it rarely
+        // does, and alpha == 1 exactly then, so skipping is exact (no threshold)
+        if (__builtin_amdgcn_ballot_w64(mn != m) != 0) {
+            const float alpha = __builtin_amdgcn_exp2f((m - mn) * c2);
+            l *= alpha;
 #pragma unroll
-        for (int db = 0; db < 2; ++db)
+            for (int db = 0; db < 2; ++db)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+                for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+            m = mn;
+        }
+        l += rs_;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -153,9 +156,31 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const bf16_t* __r
                     oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Vl, kb * 32 + 16 * sp, db, lane), pf,
                                                                       oacc[db], 0, 0, 0);
             }
-        if (more) swrite(cur ^ 1);
+    };
+    typedef std::integral_constant<int, 0> S0;
+    typedef std::integral_constant<int, 1> S1;
+    gload(0);
+    swrite(0);
+    __syncthreads();
+    int t = 0;
+    for (; t + 2 < nt; t += 2) {       // ring unrolled by two: even tiles live in stage 0, odd tiles in stage 1
+        gload(t + 1);
+        tile(t, S0{}, std::false_type{});
+        swrite(1);
         __syncthreads();
-        cur ^= 1;
+        gload(t + 2);
+        tile(t + 1, S1{}, std::false_type{});
+        swrite(0);
+        __syncthreads();
+    }
+    if (t + 1 < nt) {                   // two tiles left: t (stage 0), then the last one (stage 1)
+        gload(t + 1);
+        tile(t, S0{}, std::false_type{});
+        swrite(1);
+        __syncthreads();
+        tile(t + 1, S1{}, std::true_type{});
+    } else {
+        tile(t, S0{}, std::true_type{});
     }
     const int query = q0 + c;
     if (query < N) {
@@ -436,7 +461,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const bf16_t* __r
 }
 
 // dQ: grid (ceil(N/128), H, B); each wave owns 32 queries, sweeps all keys in 64-row tiles.
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
+__global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
                                                           const float* __restrict__ lse, const float* __restrict__ delta,
                                                           bf16_t* __restrict__ dqkv, int N, int H, float scale) {
     __shared__ __attribute__((aligned(16))) char smem[32768];
@@ -475,14 +500,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
     };
     f32x16 dq[2] = {zero16(), zero16()};
     const int nt = (N + 63) >> 6;
-    gload(0);
-    swrite(0);
-    __syncthreads();
-    int cur = 0;
-    for (int t = 0; t < nt; ++t) {
-        const bool more = t + 1 < nt;
-        if (more) gload(t + 1);
-        const char* Kl = smem + cur * 16384;
+    // one 64-key tile; LAST = the only tile that can hold keys >= N (separate instantiation: no masking in the loop)
+    auto tile = [&](int t, auto stage_tag, auto last_tag) {
+        constexpr bool LAST = decltype(last_tag)::value;
+        constexpr int ST = decltype(stage_tag)::value;
+        const char* Kl = smem + ST * 16384;
         const char* Vl = Kl + 8192;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
@@ -493,15 +515,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
                 dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Vl, kb * 32 + c, ks, h), dof[ks], dpt, 0, 0, 0);
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) st[r] = __builtin_amdgcn_exp2f(st[r] * c2 - lq);
-            if ((t == nt - 1) && (N & 63)) {
-                asm volatile("" ::: "memory");   // wave-uniform branch, not 16 v_cndmask per key block on every tile
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (t * 64 + kb * 32 + acc_row(r, h) >= N) st[r] = 0.f;
+            for (int r = 0; r < 16; ++r) {
+                float p = __builtin_amdgcn_exp2f(st[r] * c2 - lq);
+                if (LAST && t * 64 + kb * 32 + acc_row(r, h) >= N) p = 0.f;
+                dpt[r] = p * (dpt[r] - dq_);
             }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) dpt[r] = st[r] * (dpt[r] - dq_);
 #pragma unroll
             for (int sp = 0; sp < 2; ++sp) {
                 const bf16x8 dsf = pack8(dpt, sp);
@@ -510,9 +528,31 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
                     dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Kl, kb * 32 + 16 * sp, db, lane), dsf, dq[db], 0, 0, 0);
             }
         }
-        if (more) swrite(cur ^ 1);
+    };
+    typedef std::integral_constant<int, 0> S0;
+    typedef std::integral_constant<int, 1> S1;
+    gload(0);
+    swrite(0);
+    __syncthreads();
+    int t = 0;
+    for (; t + 2 < nt; t += 2) {       // ring unrolled by two: even tiles live in stage 0, odd tiles in stage 1
+        gload(t + 1);
+        tile(t, S0{}, std::false_type{});
+        swrite(1);
         __syncthreads();
-        cur ^= 1;
+        gload(t + 2);
+        tile(t + 1, S1{}, std::false_type{});
+        swrite(0);
+        __syncthreads();
+    }
+    if (t + 1 < nt) {                   // two tiles left: t (stage 0), then the last one (stage 1)
+        gload(t + 1);
+        tile(t, S0{}, std::false_type{});
+        swrite(1);
+        __syncthreads();
+        tile(t + 1, S1{}, std::true_type{});
+    } else {
+        tile(t, S0{}, std::true_type{});
     }
     const int query = q0 + c;
     if (query < N) store_dT(dqkv + ((long)b * N + query) * D3 + head * 64, dq, scale, h);
