@@ -10,7 +10,7 @@ import os
 import threading
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libhsenet_hip.so")
+LIB_PATH = os.environ.get("HS_LIB_PATH") or os.path.join(HERE, "lib", "libhsenet_hip.so")   # override: ablation builds only
 
 HS_OK, HS_ERR_SHAPE, HS_ERR_ARCH, HS_ERR_LAUNCH, HS_ERR_ARG = 0, -1, -2, -3, -4
 PREC_BF16, PREC_F32 = 0, 1

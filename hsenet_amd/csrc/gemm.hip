@@ -9,6 +9,7 @@
 // f32 kernel (parity mode): 64x64x32 tile, v_mfma_f32_32x32x2_f32 (exact f32 fma chain).
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 struct GemmP {
     const void* A; const void* B;
@@ -90,9 +91,14 @@ __device__ __forceinline__ void dma_piece(__amdgpu_buffer_rsrc_t rs, char* lds_a
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (LDS_PTR(void))(lds_area + (j * 8 + wave) * 1024), 16, voff, soff, 0, 0);
 }
 // fragment of the 32-wide block starting at `sub` (0..255) of an operand image, k-step ks
+#ifdef HS_ABLATE_TR   // ablation build only: read T images with plain row reads (wrong data, same bytes)
+#define HS_TR_AS_ROW 1
+#else
+#define HS_TR_AS_ROW 0
+#endif
 template <bool TR>
 __device__ __forceinline__ bf16x8 g_frag(const char* lds, int sub, int ks, int lane) {
-    if (!TR) {
+    if (!TR || HS_TR_AS_ROW) {
         return *(const bf16x8*)(lds + offR(sub + (lane & 31), 2 * ks + (lane >> 5)));
     } else {
         const char* img = lds + (sub >> 7) * 16384;
@@ -168,6 +174,35 @@ template <bool BIG> struct GCfg {
 };
 #define G_EPI_LD 68   // floats per staged row (64 + 4 pad)
 
+// ---- transposed fragment reads from inline asm ---------------------------------------------------------------
+// hipcc cannot prove that the ds_read_tr builtin does not alias the LDS-DMA writes in flight, so it puts
+// `s_waitcnt vmcnt(0)` in front of every group of them — draining the prefetch ring at every k-step (NN/TN ran at
+// 0.6x of NT for that reason alone).  Issued from asm they are invisible to that pass; their completion is waited
+// for explicitly (tr_settle), with the fragment registers as "+v" operands so no consumer can move above the wait.
+__device__ __forceinline__ unsigned lds_off(const char* p) { return (unsigned)(__UINTPTR_TYPE__)(LDS_PTR(const char))p; }
+// byte addresses (k-step 0) of the two 4-row groups of the 32-wide block at `sub` of a T image
+__device__ __forceinline__ void tr_bases(const char* lds, int sub, int lane, unsigned (&b)[2]) {
+    const int g = lane >> 4, h = g >> 1, p = lane & 3, q = (lane >> 2) & 3;
+    const int col = (sub & 127) + 16 * (g & 1) + 4 * p;
+    const unsigned img = lds_off(lds) + (sub >> 7) * 16384 + 8 * (p & 1);
+    b[0] = img + offT(8 * h + q, col >> 3);
+    b[1] = img + offT(8 * h + q + 4, col >> 3);
+}
+// k-step KS adds 16 rows = 4096 B (the swizzle of a row depends on row & 15 only): an immediate offset
+template <int KS>
+__device__ __forceinline__ void tr_issue(u32x4& f, const unsigned (&b)[2]) {
+    u32x2 lo, hi;
+    asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%4\n\tds_read_b64_tr_b16 %1, %3 offset:%4"
+                 : "=&v"(lo), "=&v"(hi) : "v"(b[0]), "v"(b[1]), "i"(KS * 4096) : "memory");
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = hi[0]; f[3] = hi[1];
+}
+__device__ __forceinline__ bf16x8 as_frag(u32x4 f) { return __builtin_bit_cast(bf16x8, f); }
+// wait for every LDS read issued so far; the registers are "+v" so that nothing that consumes them is scheduled above
+__device__ __forceinline__ void tr_settle(u32x4& a, u32x4& b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b)::"memory"); }
+__device__ __forceinline__ void tr_settle(u32x4& a, u32x4& b, u32x4& c, u32x4& d) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)::"memory");
+}
+
 // one K-tile of MFMA work for a wave, with the DMA pieces of the prefetched K-tile (if any: `issue`, wave-uniform)
 // issued behind the MFMA groups.  A single code path keeps the 64-128 accumulator registers out of phi copies.
 template <bool ATR, bool BTR, bool BIG>
@@ -175,54 +210,82 @@ __device__ __forceinline__ void ktile_step(f32x16 (&acc)[GCfg<BIG>::MB][2], cons
                                            int wave, int lane, __amdgpu_buffer_rsrc_t rsA, __amdgpu_buffer_rsrc_t rsB,
                                            const unsigned (&va)[4], const unsigned (&vb)[GCfg<BIG>::PB], unsigned sa, unsigned sb, bool issue) {
     typedef GCfg<BIG> C;
-    constexpr int MODE = 1;
+    typedef std::integral_constant<int, 0> K0;
+    typedef std::integral_constant<int, 1> K1;
+    typedef std::integral_constant<int, 2> K2;
+    typedef std::integral_constant<int, 3> K3;
     auto piece = [&](int q) {
         if (issue) {
             if (q < 4) dma_piece(rsA, nxt, q, wave, va[q], sa); else dma_piece(rsB, nxt + 32768, q - 4, wave, vb[q - 4], sb);
         }
     };
-    // Software pipeline inside the K-tile: the fragments of k-step ks+1 are read BEFORE the MFMAs of k-step ks are
-    // issued and the DMA pieces go after those MFMAs, so LDS read latency (~200 cycles) and DMA issue cost (~65
-    // cycles per piece) elapse under the matrix pipe.
+    unsigned tb[2][2];
+    if (BTR) {
+        tr_bases(b_l, col0, lane, tb[0]);
+        tr_bases(b_l, col0 + 32, lane, tb[1]);
+    }
     if (BIG) {
         // 128x64 wave tile: the accumulator already takes 128 of the 256 registers available at 2 waves/SIMD, so the
         // A fragments stream one 32-row block at a time (2 MFMAs each) instead of being double-buffered.
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const bf16x8 b0 = g_frag<BTR>(b_l, col0, ks, lane);
-            const bf16x8 b1 = g_frag<BTR>(b_l, col0 + 32, ks, lane);
+        auto step = [&](auto ks_tag) {
+            constexpr int KS = decltype(ks_tag)::value;
+            u32x4 b0, b1;
+            if (BTR) {
+                tr_issue<KS>(b0, tb[0]);
+                tr_issue<KS>(b1, tb[1]);
+                tr_settle(b0, b1);
+            } else {
+                b0 = __builtin_bit_cast(u32x4, g_frag<false>(b_l, col0, KS, lane));
+                b1 = __builtin_bit_cast(u32x4, g_frag<false>(b_l, col0 + 32, KS, lane));
+            }
 #pragma unroll
             for (int i = 0; i < C::MB; ++i) {
-                const bf16x8 a = g_frag<ATR>(a_l, row0 + 32 * i, ks, lane);
-                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b0, acc[i][0], 0, 0, 0);
-                acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1, acc[i][1], 0, 0, 0);
+                const bf16x8 a = g_frag<ATR>(a_l, row0 + 32 * i, KS, lane);   // (TN never uses the big tile: hs_gemm)
+                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, as_frag(b0), acc[i][0], 0, 0, 0);
+                acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, as_frag(b1), acc[i][1], 0, 0, 0);
             }
-            if (MODE != 0) { piece(2 * ks); piece(2 * ks + 1); }     // 8 pieces: 2 per k-step
-        }
+            piece(2 * KS);
+            piece(2 * KS + 1);                                       // 8 pieces: 2 per k-step
+        };
+        step(K0{}); step(K1{}); step(K2{}); step(K3{});
     } else {
-        bf16x8 fa[2][C::MB], fb[2][2];
+        // Software pipeline inside the K-tile: the fragments of k-step ks+1 are read BEFORE the MFMAs of k-step ks are
+        // issued and the DMA pieces go after those MFMAs, so LDS read latency (~200 cycles) and DMA issue cost (~65
+        // cycles per piece) elapse under the matrix pipe.
+        unsigned ta[2][2];
+        if (ATR) {
+            tr_bases(a_l, row0, lane, ta[0]);
+            tr_bases(a_l, row0 + 32, lane, ta[1]);
+        }
+        u32x4 fa[2][2], fb[2][2];
+        auto fetch = [&](auto ks_tag, auto set_tag) {
+            constexpr int KS = decltype(ks_tag)::value, S = decltype(set_tag)::value;
 #pragma unroll
-        for (int i = 0; i < C::MB; ++i) fa[0][i] = g_frag<ATR>(a_l, row0 + 32 * i, 0, lane);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) fb[0][j] = g_frag<BTR>(b_l, col0 + 32 * j, 0, lane);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int cur = ks & 1, nx = cur ^ 1;
-            if (ks < 3) {
-#pragma unroll
-                for (int i = 0; i < C::MB; ++i) fa[nx][i] = g_frag<ATR>(a_l, row0 + 32 * i, ks + 1, lane);
-#pragma unroll
-                for (int j = 0; j < 2; ++j) fb[nx][j] = g_frag<BTR>(b_l, col0 + 32 * j, ks + 1, lane);
+            for (int i = 0; i < 2; ++i) {
+                if (ATR) tr_issue<KS>(fa[S][i], ta[i]);
+                else fa[S][i] = __builtin_bit_cast(u32x4, g_frag<false>(a_l, row0 + 32 * i, KS, lane));
+                if (BTR) tr_issue<KS>(fb[S][i], tb[i]);
+                else fb[S][i] = __builtin_bit_cast(u32x4, g_frag<false>(b_l, col0 + 32 * i, KS, lane));
             }
+        };
+        auto settle = [&](auto set_tag) {
+            constexpr int S = decltype(set_tag)::value;
+            if (ATR || BTR) tr_settle(fa[S][0], fa[S][1], fb[S][0], fb[S][1]);
+        };
+        auto step = [&](auto ks_tag) {
+            constexpr int KS = decltype(ks_tag)::value, CUR = KS & 1, NX = CUR ^ 1;
+            if (KS < 3) fetch(std::integral_constant<int, (KS < 3 ? KS + 1 : 3)>{}, std::integral_constant<int, NX>{});
 #pragma unroll
-            for (int i = 0; i < C::MB; ++i)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
-            if (MODE != 0) {
-                if (ks < 2) { piece(2 * ks); piece(2 * ks + 1); } else piece(ks + 2);   // 6 pieces: (0,1)(2,3)(4)(5)
-            }
-        }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(fa[CUR][i]), as_frag(fb[CUR][j]), acc[i][j], 0, 0, 0);
+            if (KS < 2) { piece(2 * KS); piece(2 * KS + 1); } else piece(KS + 2);   // 6 pieces: (0,1)(2,3)(4)(5)
+            if (KS < 3) settle(std::integral_constant<int, NX>{});
+        };
+        fetch(K0{}, K0{});
+        settle(K0{});
+        step(K0{}); step(K1{}); step(K2{}); step(K3{});
     }
 }
 
