@@ -1,0 +1,24 @@
+"""profiles/r01_traffic.json from the two --pmc passes of tools/collect_traffic.sh.
+hbm_bytes_per_launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024   (FETCH_SIZE/WRITE_SIZE are in KiB; FETCH_SIZE x2 on gfx950)."""
+import csv, glob, json, sys, collections
+out, batch = sys.argv[1], int(sys.argv[2])
+CLASS = {"attn_fwd_bf16_kernel": "attn_fwd", "attn_bwd_dkdv_kernel": "attn_bwd_dkdv", "attn_bwd_dq_kernel": "attn_bwd_dq",
+         "gemm_bf16_kernel<false, false": "gemm_nt", "gemm_bf16_kernel<false, true": "gemm_nn", "gemm_bf16_kernel<true, true": "gemm_tn",
+         "layernorm_bwd_kernel": "layernorm_bwd", "layernorm_fwd_kernel": "layernorm_fwd"}
+vals = collections.defaultdict(lambda: collections.defaultdict(list))
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    f = glob.glob(f"{out}/{c}/**/*counter_collection.csv", recursive=True)[0]
+    for r in csv.DictReader(open(f)):
+        for k, name in CLASS.items():
+            if k in r["Kernel_Name"] and r["Counter_Name"] == c:
+                vals[name][c].append(float(r["Counter_Value"]))
+res = {}
+for name, v in vals.items():
+    fs, ws = v["FETCH_SIZE"], v["WRITE_SIZE"]
+    if fs and ws:
+        f, w = sum(fs) / len(fs), sum(ws) / len(ws)
+        res[name] = dict(batch=batch, launches=len(fs), fetch_size_kib=f, write_size_kib=w,
+                         hbm_bytes_per_launch=(2 * f + w) * 1024, note="FETCH_SIZE doubled (gfx950), separate --pmc passes")
+json.dump(res, open("profiles/r01_traffic.json", "w"), indent=1)
+for k, e in res.items():
+    print(f"{k:16s} fetch {e['fetch_size_kib']/1024:9.1f} MiB  write {e['write_size_kib']/1024:9.1f} MiB  -> hbm {e['hbm_bytes_per_launch']/1e6:9.1f} MB/launch")
