@@ -71,19 +71,21 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 
 // Each wave walks rows (grid-stride), keeps its dgamma/dbeta partials in registers, then the block reduces
 // through LDS and issues one float atomic per column.
-template <bool DYBF>
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restrict__ dy_, const float* __restrict__ x,
+// NCH = 256-column chunks per row actually used (d <= NCH*256): sizes the register arrays and the LDS reduction
+// buffer, which set the occupancy of this HBM-bound kernel (NCH=4 for every d cost 200 VGPRs / 48 KiB: 2 waves/SIMD).
+template <bool DYBF, int NCH>
+__global__ __launch_bounds__(256, 4) void layernorm_bwd_kernel(const void* __restrict__ dy_, const float* __restrict__ x,
                                                             const float* __restrict__ resid, const float* __restrict__ gamma,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ dx_in, float* __restrict__ dx,
                                                             bf16_t* __restrict__ dxb, float* __restrict__ dgamma,
                                                             float* __restrict__ dbeta, float* __restrict__ dxsum, int rows, int d) {
-    __shared__ float red[3][4][LN_MAXCH * 256];
+    __shared__ float red[3][4][NCH * 256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nch = d >> 2;
-    f32x4 g[LN_MAXCH], dg[LN_MAXCH], db[LN_MAXCH], ds[LN_MAXCH];
+    f32x4 g[NCH], dg[NCH], db[NCH], ds[NCH];
 #pragma unroll
-    for (int i = 0; i < LN_MAXCH; ++i) {
+    for (int i = 0; i < NCH; ++i) {
         const int ch = lane + 64 * i;
 #pragma unroll
         for (int e = 0; e < 4; ++e) { dg[i][e] = 0.f; db[i][e] = 0.f; g[i][e] = 0.f; ds[i][e] = 0.f; }
@@ -91,10 +93,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
     }
     for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
         const float mu = mean[row], rs = rstd[row];
-        f32x4 xh[LN_MAXCH], gy[LN_MAXCH];
+        f32x4 xh[NCH], gy[NCH];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < LN_MAXCH; ++i) {
+        for (int i = 0; i < NCH; ++i) {
             const int ch = lane + 64 * i;
             if (ch < nch) {
                 f32x4 xv = *(const f32x4*)(x + (long)row * d + ch * 4);
@@ -120,7 +122,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
         }
         const float c1 = wave_sum(s1) / d, c2 = wave_sum(s2) / d;
 #pragma unroll
-        for (int i = 0; i < LN_MAXCH; ++i) {
+        for (int i = 0; i < NCH; ++i) {
             const int ch = lane + 64 * i;
             if (ch < nch) {
                 f32x4 o;
@@ -140,7 +142,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
     }
     if (!dgamma && !dbeta && !dxsum) return;
 #pragma unroll
-    for (int i = 0; i < LN_MAXCH; ++i)
+    for (int i = 0; i < NCH; ++i)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             red[0][wave][(lane + 64 * i) * 4 + e] = dg[i][e];
@@ -176,14 +178,18 @@ extern "C" int hs_layernorm_bwd(const void* dy, int dy_is_bf16, const float* x, 
     if (!dy || !x || !gamma || !mean || !rstd || (!dx && !dx_bf16)) return HS_ERR_ARG;
     if (rows < 1 || d < 4 || (d & 3) || d > LN_MAXCH * 256) return HS_ERR_SHAPE;
     int blocks = (rows + 3) / 4;
-    if (blocks > 1024) blocks = 1024;
+    if (blocks > 2048) blocks = 2048;
     ProfScope prof(HS_PROF_LN_BWD, stream, 0, (double)rows * d * (4 + (dy_is_bf16 ? 2 : 4) + (resid ? 4 : 0) + (dx_in ? 4 : 0) + (dx ? 4 : 0) + (dx_bf16 ? 2 : 0)));
-    if (dy_is_bf16)
-        hipLaunchKernelGGL(layernorm_bwd_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, x, resid, gamma, mean, rstd,
-                           dx_in, dx, (bf16_t*)dx_bf16, dgamma, dbeta, dxsum, rows, d);
-    else
-        hipLaunchKernelGGL(layernorm_bwd_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, x, resid, gamma, mean, rstd,
-                           dx_in, dx, (bf16_t*)dx_bf16, dgamma, dbeta, dxsum, rows, d);
+    const int nchunks = (d + 255) / 256;
+#define HS_LN_BWD(DYBF, NCH)                                                                                              \
+    hipLaunchKernelGGL((layernorm_bwd_kernel<DYBF, NCH>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, x, resid, gamma, \
+                       mean, rstd, dx_in, dx, (bf16_t*)dx_bf16, dgamma, dbeta, dxsum, rows, d)
+    if (dy_is_bf16) {
+        if (nchunks == 1) HS_LN_BWD(true, 1); else if (nchunks == 2) HS_LN_BWD(true, 2); else if (nchunks == 3) HS_LN_BWD(true, 3); else HS_LN_BWD(true, 4);
+    } else {
+        if (nchunks == 1) HS_LN_BWD(false, 1); else if (nchunks == 2) HS_LN_BWD(false, 2); else if (nchunks == 3) HS_LN_BWD(false, 3); else HS_LN_BWD(false, 4);
+    }
+#undef HS_LN_BWD
     HS_CHECK_LAUNCH();
     return HS_OK;
 }
