@@ -8,7 +8,8 @@ from .functional import set_precision, get_precision  # noqa: F401
 from .encoder import (ViT_stage1, ViT_stage2, ViT3DTower_dual_encoders, regular_attention,  # noqa: F401
                       build_vision_tower, PatchEmbeddingBlock, TransformerBlock)
 from .projector import (VisualPacker_3d_phi_v3, resolution_attention_v3, build_mm_projector, encode_images)  # noqa: F401
+from .clip import encode_image_cls, image_text_contrastive_learning  # noqa: F401
 
 __all__ = ["ViT_stage1", "ViT_stage2", "ViT3DTower_dual_encoders", "regular_attention", "build_vision_tower",
            "VisualPacker_3d_phi_v3", "resolution_attention_v3", "build_mm_projector", "encode_images",
-           "set_precision", "get_precision"]
+           "encode_image_cls", "image_text_contrastive_learning", "set_precision", "get_precision"]

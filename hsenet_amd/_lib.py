@@ -69,6 +69,7 @@ SIGNATURES = {
     "hs_l2norm_fwd": [_vp, _vp, _i, _i, _f, _vp],
     "hs_l2norm_bwd": [_vp, _vp, _vp, _i, _i, _f, _vp],
     "hs_adamw": [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _f, _i, _vp],
+    "hs_clip_ce": [_vp, _vp, _vp, _i, _vp],
     "hs_scale": [_vp, _vp, _f, _i64, _vp],
     "hs_prof_enable": [_i],
     "hs_prof_read": [_i, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)],

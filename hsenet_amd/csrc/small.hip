@@ -709,6 +709,55 @@ extern "C" int hs_adamw(float* p, const float* g, float* m, float* v, int64_t n,
     return HS_OK;
 }
 
+// ------------------------------------------------------------------------------------------------------
+// N1: CLIP InfoNCE head (CLIP_stage1.py:141-155): loss = (CE(logits, arange) + CE(logits^T, arange)) / 2 on an
+// n x n logits matrix, and dL/dlogits.  Tiny (n = global batch): one wave per row / per column, two launches.
+// pass 0 (rows):  dlogits = softmax_row / (2n);              loss += sum_i (lse_row_i - logit_ii) / (2n)
+// pass 1 (cols):  dlogits += softmax_col / (2n) - I / n;     loss += sum_j (lse_col_j - logit_jj) / (2n);
+//                 loss[1] += sum(dlogits * logits)   (= logit_scale * dL/dlogit_scale)
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void clip_ce_kernel(const float* __restrict__ logits, float* __restrict__ dlogits,
+                                                      float* __restrict__ loss, int n, int pass) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const long stride = pass == 0 ? 1 : n, base = pass == 0 ? (long)i * n : i;
+    float m = -__builtin_inff();
+    for (int j = lane; j < n; j += 64) m = fmaxf(m, logits[base + j * stride]);
+    m = wave_max(m);
+    float z = 0.f;
+    for (int j = lane; j < n; j += 64) z += __expf(logits[base + j * stride] - m);
+    z = wave_sum(z);
+    const float inv = 1.0f / z, w = 0.5f / n;
+    float dot = 0.f;
+    for (int j = lane; j < n; j += 64) {
+        const float lg = logits[base + j * stride];
+        const float pr = __expf(lg - m) * inv * w;
+        float* o = dlogits + base + j * stride;
+        if (pass == 0) {
+            *o = pr;
+        } else {
+            const float dfin = *o + pr - (j == i ? 1.0f / n : 0.f);
+            *o = dfin;
+            dot += dfin * lg;        // sum(dlogits * logits) = logit_scale * dL/d(logit_scale)
+        }
+    }
+    dot = wave_sum(dot);
+    if (lane == 0) {
+        atomicAdd(loss, (m + __logf(z) - logits[(long)i * n + i]) * w);
+        if (pass == 1) atomicAdd(loss + 1, dot);
+    }
+}
+extern "C" int hs_clip_ce(const float* logits, float* dlogits, float* loss, int n, void* stream) {
+    if (!logits || !dlogits || !loss) return HS_ERR_ARG;
+    if (n < 1) return HS_ERR_SHAPE;
+    ProfScope prof(HS_PROF_OTHER, stream, 0, (double)n * n * 16);
+    hipLaunchKernelGGL(clip_ce_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, dlogits, loss, n, 0);
+    hipLaunchKernelGGL(clip_ce_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, dlogits, loss, n, 1);
+    HS_CHECK_LAUNCH();
+    return HS_OK;
+}
+
 __global__ __launch_bounds__(256) void scale_kernel(const float* __restrict__ x, float* __restrict__ y, float alpha, long n) {
     const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i + 4 <= n) {

@@ -158,6 +158,11 @@ int hs_l2norm_bwd(const float* x, const float* dy, float* dx, int rows, int d, f
 int hs_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
              float weight_decay, float grad_scale, int step, void* stream);
 
+/* ---- N1: CLIP InfoNCE head (CLIP_stage1.py:141-155): symmetric cross-entropy with labels = arange(n) on an n x n
+ * fp32 logits matrix.  loss[0] += (CE(logits) + CE(logits^T)) / 2;  dlogits = dL/dlogits;  loss[1] += sum(dlogits*logits)
+ * (= logit_scale * dL/dlogit_scale).  loss: 2 floats, caller zeroes. */
+int hs_clip_ce(const float* logits, float* dlogits, float* loss, int n, void* stream);
+
 /* y = alpha * x (fp32): the synthetic bench loss gradient dL/dy = y * 2/numel of L = mean(y^2) */
 int hs_scale(const float* x, float* y, float alpha, int64_t n, void* stream);
 

@@ -330,3 +330,31 @@ def test_adamw(dev):
         opt.step()
         Fn.adamw_step(p, g * step, m, v, lr=1e-2, weight_decay=0.05, step=step)
     assert rel(p, pr.detach()) < 1e-6
+
+
+@pytest.mark.parametrize("n", [4, 8, 80])
+def test_clip_head_vs_oracle(dev, n):
+    """N1: cls projection + normalize + symmetric InfoNCE (CLIP_stage1.py:97-102,141-155) incl. all gradients."""
+    from hsenet_amd import clip, _lib as L
+    from oracle import ref_cpu as R
+    d = 768
+    tokens = rnd((n, 5, d), 300, dev)
+    proj = torch.nn.Linear(d, d).to(dev)
+    txt = F.normalize(rnd((n, d), 301, dev), dim=-1).requires_grad_()
+    scale = torch.tensor(float(np.log(1 / 0.07)), device=dev, requires_grad=True)
+    tokens.requires_grad_()
+    img = clip.encode_image_cls(tokens, proj, L.PREC_F32)
+    loss, lpi, lpt = clip.image_text_contrastive_learning(img, txt, scale)
+    loss.backward()
+    t2 = tokens.detach().double().cpu().requires_grad_()
+    p2 = torch.nn.Linear(d, d).double()
+    p2.load_state_dict({k: v.double().cpu() for k, v in proj.state_dict().items()})
+    txt2 = txt.detach().double().cpu().requires_grad_()
+    s2 = scale.detach().double().cpu().requires_grad_()
+    img2 = F.normalize(p2(t2), dim=-1)[:, 0]          # the reference projects every token, then keeps [:, 0]
+    ref = R.clip_contrastive_loss(img2, txt2, s2)
+    ref.backward()
+    assert rel(img, img2) < 1e-5 and abs(float(loss) - float(ref)) < 1e-5 * max(1.0, abs(float(ref)))
+    assert rel(lpi, s2.detach() * img2.detach() @ txt2.detach().t()) < 1e-5 and torch.equal(lpt, lpi.t())
+    assert rel(tokens.grad, t2.grad) < 1e-4 and rel(txt.grad, txt2.grad) < 1e-4
+    assert rel(proj.weight.grad, p2.weight.grad) < 1e-4 and rel(scale.grad, s2.grad) < 1e-4
