@@ -80,7 +80,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=10, help="volumes per GPU per step")
+    ap.add_argument("--batch", type=int, default=20, help="volumes per GPU per step")
     ap.add_argument("--workload", default="vit256", choices=list(GEOM))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
