@@ -16,6 +16,8 @@ HS_OK, HS_ERR_SHAPE, HS_ERR_ARCH, HS_ERR_LAUNCH, HS_ERR_ARG = 0, -1, -2, -3, -4
 PREC_BF16, PREC_F32 = 0, 1
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 EPI_BIAS, EPI_GELU, EPI_GELU_BWD, EPI_RESID, EPI_ATOMIC, EPI_BIAS_M, EPI_SAVE_DGELU = 1, 2, 4, 8, 16, 32, 64
+ATTN_Q_PRESCALED = 1
+Q_PRESCALE = 0.125 * 1.44269504088896341   # dh^-0.5 * log2(e) for dh = 64 (hs_gemm scale_cols_alpha for the q third)
 
 _ERR = {HS_ERR_SHAPE: "unsupported shape/alignment", HS_ERR_ARCH: "no gfx950 device", HS_ERR_LAUNCH: "HIP launch error",
         HS_ERR_ARG: "bad argument"}
@@ -31,7 +33,8 @@ class GemmArgs(C.Structure):
                 ("strideA", C.c_int64), ("strideB", C.c_int64), ("strideC", C.c_int64),
                 ("out_f32", C.c_void_p), ("out_bf16", C.c_void_p), ("ldc", C.c_int64),
                 ("bias", C.c_void_p), ("resid", C.c_void_p), ("aux", C.c_void_p), ("aux_out", C.c_void_p),
-                ("colsum_out", C.c_void_p), ("alpha", C.c_float), ("flags", C.c_int), ("layout", C.c_int), ("split_k", C.c_int)]
+                ("colsum_out", C.c_void_p), ("alpha", C.c_float), ("flags", C.c_int), ("layout", C.c_int), ("split_k", C.c_int),
+                ("scale_cols", C.c_int), ("scale_cols_alpha", C.c_float)]
 
 
 class VitDesc(C.Structure):
@@ -51,8 +54,8 @@ SIGNATURES = {
     "hs_assemble_tokens_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "hs_layernorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp],
     "hs_layernorm_bwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
-    "hs_attn_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
-    "hs_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "hs_attn_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "hs_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "hs_cross_attn_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "hs_cross_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "hs_rowdot_sigmoid_fwd": [_vp, _vp, _vp, _vp, _i, _i, _vp],

@@ -73,17 +73,25 @@ __device__ __forceinline__ void store_dT(bf16_t* rowptr, const f32x16 (&acc)[2],
 // ------------------------------------------------------------------------------------------------------
 // forward, bf16.  grid (ceil(N/128), H, B), 4 waves x 32 queries, 64-key tiles.
 // ------------------------------------------------------------------------------------------------------
+// GUARD: run only the 128-query blocks in which the fast kernel (below) left a NaN lse, i.e. rows whose optimistic
+// softmax left the f32 window; every other block exits after one load.
+template <bool GUARD>
 __global__ __launch_bounds__(256, 3) void attn_fwd_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
-                                                            float* __restrict__ lse, int N, int H, float scale) {
+                                                            float* __restrict__ lse, int N, int H, float c2) {
+    // c2 = log2(e) x the factor still to be applied to q.k (dh^-0.5, or 1/log2(e) when q arrives pre-scaled)
     __shared__ __attribute__((aligned(16))) char smem[32768];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, c = lane & 31;
     int blk, head, b;
     attn_block_coords((N + 127) >> 7, H, blk, head, b);
+    if (GUARD) {
+        const int qg = blk * 128 + tid;
+        const float v = (tid < 128 && qg < N) ? lse[((long)b * H + head) * N + qg] : 0.f;
+        if (!__syncthreads_or(v != v)) return;
+    }
     const int q0 = blk * 128 + wave * 32;
     const int Dm = H * 64, D3 = 3 * Dm;
     const bf16_t* base = qkv + (long)b * N * D3;
     const __amdgpu_buffer_rsrc_t rs = make_rsrc(base, (size_t)N * D3 * 2);
-    const float c2 = scale * 1.44269504088896341f;
 
     const int qrow = min(q0 + c, N - 1);
     bf16x8 qf[4];
@@ -202,7 +210,218 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_bf16_kernel(const bf16_t* __r
     const int query = q0 + c;
     if (query < N) {
         store_dT(o + ((long)b * N + query) * Dm + head * 64, oacc, 1.0f / l, h);
-        if (h == 0) lse[((long)b * H + head) * N + query] = m * scale + __logf(l);
+        if (h == 0) lse[((long)b * H + head) * N + query] = m * (c2 * 0.69314718055994531f) + __logf(l);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// forward, bf16, fast path ("optimistic softmax").  4 waves x 64 queries (two 32-query blocks A, B per wave that share
+// every K / V fragment read), 64-key tiles by LDS-DMA into a 3-stage ring (prefetch distance 2, counted vmcnt, raw
+// barrier: no staging registers, no ds_write).
+//
+// Softmax without a running maximum.  softmax is invariant to the reference point subtracted before exp; the online
+// algorithm re-references to the running row maximum only to stay inside the f32 range.  Here the reference is fixed
+// at 0: p = exp2(q' . k) with q' = q * scale * log2(e) folded into the Q fragments, l = sum p, O = sum p v, out = O / l,
+// lse = ln l.  No max, no subtraction, no rescale: per score one v_exp, one add, half a cvt_pk — at head dim 64 the
+// loop is bound by vector-issue slots, not by the matrix pipe, so this is the lever.  Nothing is approximated: f32 / bf16
+// keep relative precision over 2^+-126, so the result equals the max-referenced one to rounding WHENEVER every row's
+// l stays inside [2^-60, 2^100] (scaled logits within about -41 .. +63 nats).  A row outside that window gets
+// lse = NaN, and hs_attn_fwd always runs the guarded exact kernel (attn_fwd_bf16_kernel with GUARD) behind this one: its
+// 128-query blocks recompute, with the running maximum, exactly the blocks that hold a NaN lse and exit at once
+// otherwise.  tests/test_gpu_kernels.py forces both the overflow and the underflow side.
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned lds_addr(const char* p) { return (unsigned)(__UINTPTR_TYPE__)(LDS_PTR(const char))p; }
+// two transposed 4-row reads (rows r, r+8 of a 16-row group) = one 32x16 MFMA operand fragment; issued from asm so that
+// hipcc does not drain the LDS-DMA ring in front of them (it cannot prove the builtin does not alias the DMA writes)
+template <int IMM>
+__device__ __forceinline__ void trR_issue(u32x4& f, unsigned b0, unsigned b1) {
+    u32x2 lo, hi;
+    asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%4\n\tds_read_b64_tr_b16 %1, %3 offset:%4"
+                 : "=&v"(lo), "=&v"(hi) : "v"(b0), "v"(b1), "i"(IMM) : "memory");
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = hi[0]; f[3] = hi[1];
+}
+__device__ __forceinline__ void lds_settle2(u32x4& a, u32x4& b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b)::"memory"); }
+__device__ __forceinline__ bf16x8 scale_frag(u32x4 raw, float mul) {
+    u32x4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        r[i] = pack2bf(__uint_as_float(raw[i] << 16) * mul, __uint_as_float(raw[i] & 0xffff0000u) * mul);
+    return __builtin_bit_cast(bf16x8, r);
+}
+
+__global__ __launch_bounds__(256, 2) void attn_fwd_fast_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
+                                                            float* __restrict__ lse, int N, int H, float qmul) {
+    // qmul: factor applied to the Q fragments (dh^-0.5 * log2(e), or exactly 1 when q arrives pre-scaled)
+    __shared__ __attribute__((aligned(16))) char smem[3 * 16384];     // stage: K image 8 KiB | V image 8 KiB
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int blk, head, b;
+    attn_block_coords((N + 255) >> 8, H, blk, head, b);
+    const int q0 = blk * 256 + wave * 64;
+    const bool active = q0 < N;                                        // wave-uniform; false only in the last block
+    const int Dm = H * 64, D3 = 3 * Dm;
+    const bf16_t* base = qkv + (long)b * N * D3;
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(base, (size_t)N * D3 * 2);
+    const int nt = (N + 63) >> 6;
+
+    // DMA: piece p (1 KiB = rows 8p..8p+7 of an image) of K and of V for p = 2*wave, 2*wave+1; the swizzle of image R
+    // is applied to the SOURCE chunk.  Tile t adds the wave-uniform soffset t*64 rows; the last tile uses offsets
+    // whose rows >= N are out of range (zero fill).
+    unsigned vk[2], vkl[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = (2 * wave + j) * 8 + (lane >> 3);
+        const int ch = (lane & 7) ^ swzR(row);
+        vk[j] = (unsigned)(((long)row * D3 + Dm + head * 64 + ch * 8) * 2);
+        vkl[j] = (nt - 1) * 64 + row < N ? vk[j] : HS_OOB_OFF;
+    }
+    const unsigned tile_bytes = (unsigned)(64 * D3 * 2), v_off = (unsigned)(Dm * 2);
+    auto issue = [&](int t, int st) {
+        const bool last = t == nt - 1;
+        const unsigned so = (unsigned)t * tile_bytes;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const unsigned vo = last ? vkl[j] : vk[j];
+            char* dst = smem + st * 16384 + (2 * wave + j) * 1024;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (LDS_PTR(void))dst, 16, vo, so, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (LDS_PTR(void))(dst + 8192), 16, vo == HS_OOB_OFF ? vo : vo + v_off, so, 0, 0);
+        }
+    };
+    issue(0, 0);
+    if (nt > 1) issue(1, 1);
+
+    bf16x8 qf[2][4];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const int qrow = min(q0 + 32 * qb + c, N - 1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            qf[qb][ks] = scale_frag(buf_load16(rs, (unsigned)(((long)qrow * D3 + head * 64 + ks * 16 + 8 * h) * 2)), qmul);
+    }
+    // transposed-read bases (image R): rows 4h+q and 4h+q+8 of a 16-row group, 32-column block db
+    unsigned tb0[2][2];
+    {
+        const int g = lane >> 4, p = lane & 3, q = (lane >> 2) & 3;
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+            const int col = db * 32 + 16 * (g & 1) + 4 * p;
+            tb0[db][0] = lds_addr(smem) + offR(4 * h + q, col >> 3) + 8 * (p & 1);
+            tb0[db][1] = lds_addr(smem) + offR(4 * h + q + 8, col >> 3) + 8 * (p & 1);
+        }
+    }
+
+    float l[2] = {0.f, 0.f};
+    f32x16 oacc[2][2] = {{zero16(), zero16()}, {zero16(), zero16()}};
+    // MID tiles: compile-time stage (every LDS address = hoisted base + immediate).  The LAST tile (the only one that can
+    // hold keys >= N) runs once: one instantiation with the stage folded into the base registers at run time.
+    auto tile = [&](int t, auto stage_tag, auto last_tag, int rst) {
+        constexpr bool LAST = decltype(last_tag)::value;
+        constexpr int ST = LAST ? 0 : decltype(stage_tag)::value;
+        const char* Kl = smem + ST * 16384 + (LAST ? rst * 16384 : 0);
+        constexpr int VB = ST * 16384 + 8192;
+        unsigned tb[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) tb[i][j] = tb0[i][j] + (LAST ? rst * 16384 : 0);
+        f32x16 s[2][2];                                     // [key block][query block]
+        u32x4 va[2], vb[2];                                 // V fragments [db] of one 16-key step, double-buffered
+        bf16x8 pf[2][2];                                    // packed P^T [query block][sp]
+        auto softmax = [&](int kb) {
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float p = __builtin_amdgcn_exp2f(s[kb][qb][r]);
+                    if (LAST && t * 64 + kb * 32 + acc_row(r, h) >= N) p = 0.f;
+                    s[kb][qb][r] = p;
+                    // a single-issue add: -O3 would SLP-pack the two query blocks' sums into v_pk_add_f32, which costs more
+                    // issue time beside MFMAs than the two adds it replaces (MI355X_MICROARCH, cycle constants)
+                    asm("v_add_f32 %0, %1, %0" : "+v"(l[qb]) : "v"(p));
+                }
+                pf[qb][0] = pack8(s[kb][qb], 0);
+                pf[qb][1] = pack8(s[kb][qb], 1);
+            }
+        };
+        auto pv = [&](u32x4 (&f)[2], int sp) {               // 4 MFMAs: 16 keys x (2 d blocks) x (2 query blocks)
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb)
+                    oacc[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f[db]), pf[qb][sp], oacc[qb][db], 0, 0, 0);
+        };
+        // step 1: S^T of key block 0 for both query blocks (each K fragment feeds two MFMAs)
+        s[0][0] = zero16(); s[0][1] = zero16(); s[1][0] = zero16(); s[1][1] = zero16();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const bf16x8 kf = row_frag(Kl, c, ks, h);
+            s[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[0][ks], s[0][0], 0, 0, 0);
+            s[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[1][ks], s[0][1], 0, 0, 0);
+        }
+        // V fragments of keys 0..15 fly while step 2 runs
+        trR_issue<VB + 0>(va[0], tb[0][0], tb[0][1]);
+        trR_issue<VB + 0>(va[1], tb[1][0], tb[1][1]);
+        // step 2: S^T of key block 1 || softmax of key block 0
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const bf16x8 kf = row_frag(Kl, 32 + c, ks, h);
+            s[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[0][ks], s[1][0], 0, 0, 0);
+            s[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[1][ks], s[1][1], 0, 0, 0);
+        }
+        softmax(0);
+        // steps 3, 4: O^T += V^T P^T, 16 keys at a time, the next fragments in flight behind each group of MFMAs;
+        // the softmax of key block 1 sits between the two halves of key block 0's product
+        lds_settle2(va[0], va[1]);
+        trR_issue<VB + 2048>(vb[0], tb[0][0], tb[0][1]);
+        trR_issue<VB + 2048>(vb[1], tb[1][0], tb[1][1]);
+        pv(va, 0);
+        lds_settle2(vb[0], vb[1]);
+        trR_issue<VB + 4096>(va[0], tb[0][0], tb[0][1]);
+        trR_issue<VB + 4096>(va[1], tb[1][0], tb[1][1]);
+        pv(vb, 1);
+        softmax(1);
+        lds_settle2(va[0], va[1]);
+        trR_issue<VB + 6144>(vb[0], tb[0][0], tb[0][1]);
+        trR_issue<VB + 6144>(vb[1], tb[1][0], tb[1][1]);
+        pv(va, 0);
+        lds_settle2(vb[0], vb[1]);
+        pv(vb, 1);
+    };
+    typedef std::integral_constant<int, 0> S0;
+    typedef std::integral_constant<int, 1> S1;
+    typedef std::integral_constant<int, 2> S2;
+    // ring of 3 stages, prefetch distance 2.  At tile t: all but the newest tile's 4 DMA pieces have landed (vmcnt(4)),
+    // barrier (every wave's pieces of tile t have landed AND every wave is done reading tile t-1), then tile t+2 goes
+    // into the stage tile t-1 occupied.
+    auto step = [&](int t, auto stage_tag) {               // a tile that is not the last one
+        constexpr int ST = decltype(stage_tag)::value;
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (t + 2 < nt) issue(t + 2, (ST + 2) % 3);
+        if (active) tile(t, stage_tag, std::false_type{}, 0);
+    };
+    int t = 0;
+    for (; t + 3 < nt; t += 3) {
+        step(t, S0{});
+        step(t + 1, S1{});
+        step(t + 2, S2{});
+    }
+    int rst = 0;
+    if (t + 1 < nt) { step(t, S0{}); ++t; rst = 1; }
+    if (t + 1 < nt) { step(t, S1{}); ++t; rst = 2; }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (active) tile(t, S0{}, std::true_type{}, rst);
+    if (!active) return;
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const int query = q0 + 32 * qb + c;
+        const float lt = l[qb] + __shfl_xor(l[qb], 32, 64);
+        const bool ok = lt > 8.6736174e-19f && lt < 1.2676506e30f;          // 2^-60 .. 2^100
+        if (query < N) {
+            store_dT(o + ((long)b * N + query) * Dm + head * 64, oacc[qb], 1.0f / lt, h);
+            if (h == 0) lse[((long)b * H + head) * N + query] = ok ? __logf(lt) : __builtin_nanf("");
+        }
     }
 }
 
@@ -215,14 +434,13 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_bf16_kernel(const bf16_t* __r
 __device__ __forceinline__ int offF(int r, int c) { return r * 256 + ((c ^ (r & 15)) << 4); }
 
 __global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const float* __restrict__ qkv, float* __restrict__ o,
-                                                           float* __restrict__ lse, int N, int H, float scale) {
+                                                           float* __restrict__ lse, int N, int H, float c2) {
     __shared__ __attribute__((aligned(16))) char smem[65536];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, c = lane & 31;
     const int b = blockIdx.z, head = blockIdx.y, q0 = blockIdx.x * 128 + wave * 32;
     const int Dm = H * 64, D3 = 3 * Dm;
     const float* base = qkv + (long)b * N * D3;
     const __amdgpu_buffer_rsrc_t rs = make_rsrc(base, (size_t)N * D3 * 4);
-    const float c2 = scale * 1.44269504088896341f;
     const int qrow = min(q0 + c, N - 1);
     f32x4 qf[8];
 #pragma unroll
@@ -327,7 +545,7 @@ __global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const float* __restri
                 for (int e = 0; e < 4; ++e) v[e] = oacc[db][4 * g4 + e] * inv;
                 *(f32x4*)(orow + db * 32 + 8 * g4 + 4 * h) = v;
             }
-        if (h == 0 && lse) lse[((long)b * H + head) * N + query] = m * scale + logf(l);
+        if (h == 0 && lse) lse[((long)b * H + head) * N + query] = m * (c2 * 0.69314718055994531f) + logf(l);
     }
 }
 
@@ -365,8 +583,9 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
 // dK, dV: grid (ceil(N/128), H, B); each wave owns 32 keys, sweeps all queries in 64-row tiles.
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
                                                             const float* __restrict__ lse, const float* __restrict__ delta,
-                                                            bf16_t* __restrict__ dqkv, int N, int H, float scale) {
-    // stage: Q image 8 KiB | dO image 8 KiB | -lse/scale [64] f32 | -delta [64] f32
+                                                            bf16_t* __restrict__ dqkv, int N, int H, float c2, float dk_mul) {
+    // c2 as in the forward kernels; dk_mul = dh^-0.5 / (factor q already carries)
+    // stage: Q image 8 KiB | dO image 8 KiB | -lse*log2(e)/c2 [64] f32 | -delta [64] f32
     __shared__ __attribute__((aligned(16))) char smem[2 * 16896];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, c = lane & 31;
     int blk, head, b;
@@ -377,7 +596,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const bf16_t* __r
     const __amdgpu_buffer_rsrc_t rsd = make_rsrc(d_o + (long)b * N * Dm, (size_t)N * Dm * 2);
     const float* lse_b = lse + ((long)b * H + head) * N;
     const float* del_b = delta + ((long)b * H + head) * N;
-    const float c2 = scale * 1.44269504088896341f, inv_scale = 1.0f / scale;
+    const float inv_scale = 1.44269504088896341f / c2;
 
     const int key = k0 + c;
     bf16x8 kf[4], vf[4];
@@ -474,7 +693,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const bf16_t* __r
     }
     if (key < N) {
         bf16_t* row = dqkv + ((long)b * N + key) * D3 + head * 64;
-        store_dT(row + Dm, dk, scale, h);
+        store_dT(row + Dm, dk, dk_mul, h);
         store_dT(row + 2 * Dm, dv, 1.0f, h);
     }
 }
@@ -482,7 +701,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const bf16_t* __r
 // dQ: grid (ceil(N/128), H, B); each wave owns 32 queries, sweeps all keys in 64-row tiles.
 __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
                                                           const float* __restrict__ lse, const float* __restrict__ delta,
-                                                          bf16_t* __restrict__ dqkv, int N, int H, float scale) {
+                                                          bf16_t* __restrict__ dqkv, int N, int H, float c2, float scale) {
     __shared__ __attribute__((aligned(16))) char smem[32768];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, c = lane & 31;
     int blk, head, b;
@@ -491,7 +710,6 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const bf16_t* __res
     const int Dm = H * 64, D3 = 3 * Dm;
     const __amdgpu_buffer_rsrc_t rs = make_rsrc(qkv + (long)b * N * D3, (size_t)N * D3 * 2);
     const __amdgpu_buffer_rsrc_t rsd = make_rsrc(d_o + (long)b * N * Dm, (size_t)N * Dm * 2);
-    const float c2 = scale * 1.44269504088896341f;
     const int qrow = min(q0 + c, N - 1);
     bf16x8 qf[4], dof[4];
 #pragma unroll
@@ -579,13 +797,16 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const bf16_t* __res
     if (query < N) store_dT(dqkv + ((long)b * N + query) * D3 + head * 64, dq, scale, h);
 }
 
-extern "C" int hs_attn_fwd(const void* qkv, void* o, float* lse, int B, int N, int H, int dh, int prec, void* stream) {
+extern "C" int hs_attn_fwd(const void* qkv, void* o, float* lse, int B, int N, int H, int dh, int prec, int flags, void* stream) {
     if (!qkv || !o) return HS_ERR_ARG;
     if (dh != 64 || B < 1 || N < 1 || H < 1) return HS_ERR_SHAPE;
+    if (flags & ~HS_ATTN_Q_PRESCALED) return HS_ERR_ARG;
     const size_t esz = prec == HS_PREC_BF16 ? 2 : 4;
     if ((size_t)N * 3 * H * 64 * esz >= HS_MAX_RECORDS) return HS_ERR_SHAPE;
     if (((uintptr_t)qkv | (uintptr_t)o) & 15) return HS_ERR_SHAPE;
-    const float scale = 0.125f;  // dh^-0.5
+    const float LOG2E = 1.44269504088896341f;
+    const bool pre = (flags & HS_ATTN_Q_PRESCALED) != 0;
+    const float c2 = pre ? 1.0f : 0.125f * LOG2E;          // what still multiplies q.k (then exp2); dh^-0.5 = 1/8
     dim3 grid((N + 127) / 128, H, B);
     dim3 grid1((unsigned)(((N + 127) / 128) * H * B));      // bf16 kernels decode (block, head, batch) themselves (XCD order)
     hipStream_t s = (hipStream_t)stream;
@@ -593,9 +814,17 @@ extern "C" int hs_attn_fwd(const void* qkv, void* o, float* lse, int B, int N, i
     ProfScope prof(HS_PROF_ATTN_FWD, stream, 4.0 * nn, (double)B * N * H * 64 * 4 * esz);
     if (prec == HS_PREC_BF16) {
         if (!lse) return HS_ERR_ARG;
-        hipLaunchKernelGGL(attn_fwd_bf16_kernel, grid1, dim3(256), 0, s, (const bf16_t*)qkv, (bf16_t*)o, lse, N, H, scale);
+        if (g_hs_dbg[0] == 1) {       // diagnostic: the exact (running-max) kernel alone
+            hipLaunchKernelGGL(attn_fwd_bf16_kernel<false>, grid1, dim3(256), 0, s, (const bf16_t*)qkv, (bf16_t*)o, lse, N, H, c2);
+        } else {
+            // optimistic kernel, then the guarded exact kernel over the blocks it flagged (normally none: one load + exit)
+            dim3 grid2((unsigned)(((N + 255) / 256) * H * B));
+            hipLaunchKernelGGL(attn_fwd_fast_kernel, grid2, dim3(256), 0, s, (const bf16_t*)qkv, (bf16_t*)o, lse, N, H, c2);
+            if (g_hs_dbg[0] != 2)
+                hipLaunchKernelGGL(attn_fwd_bf16_kernel<true>, grid1, dim3(256), 0, s, (const bf16_t*)qkv, (bf16_t*)o, lse, N, H, c2);
+        }
     } else if (prec == HS_PREC_F32) {
-        hipLaunchKernelGGL(attn_fwd_f32_kernel, grid, dim3(256), 0, s, (const float*)qkv, (float*)o, lse, N, H, scale);
+        hipLaunchKernelGGL(attn_fwd_f32_kernel, grid, dim3(256), 0, s, (const float*)qkv, (float*)o, lse, N, H, c2);
     } else {
         return HS_ERR_ARG;
     }
@@ -604,12 +833,16 @@ extern "C" int hs_attn_fwd(const void* qkv, void* o, float* lse, int B, int N, i
 }
 
 extern "C" int hs_attn_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv, float* delta_ws,
-                           int B, int N, int H, int dh, void* stream) {
+                           int B, int N, int H, int dh, int flags, void* stream) {
     if (!qkv || !o || !d_o || !lse || !dqkv || !delta_ws) return HS_ERR_ARG;
     if (dh != 64 || B < 1 || N < 1 || H < 1) return HS_ERR_SHAPE;
+    if (flags & ~HS_ATTN_Q_PRESCALED) return HS_ERR_ARG;
     if ((size_t)N * 3 * H * 64 * 2 >= HS_MAX_RECORDS) return HS_ERR_SHAPE;
     if (((uintptr_t)qkv | (uintptr_t)o | (uintptr_t)d_o | (uintptr_t)dqkv) & 15) return HS_ERR_SHAPE;
-    const float scale = 0.125f;
+    const float scale = 0.125f, LOG2E = 1.44269504088896341f;
+    const bool pre = (flags & HS_ATTN_Q_PRESCALED) != 0;
+    const float c2 = pre ? 1.0f : scale * LOG2E;
+    const float dk_mul = pre ? 1.0f / LOG2E : scale;        // dK = dh^-0.5 dS^T q = dS^T q' / log2(e)
     hipStream_t s = (hipStream_t)stream;
     const long total = (long)B * N * H * 8;
     const double nn = (double)B * H * N * N * 64;   // algorithmic bwd = 5 products = 10*nn, split 6:4 over the two kernels
@@ -623,12 +856,12 @@ extern "C" int hs_attn_bwd(const void* qkv, const void* o, const void* d_o, cons
     {
         ProfScope prof(HS_PROF_ATTN_DKDV, stream, 6.0 * nn, 6 * io);
         hipLaunchKernelGGL(attn_bwd_dkdv_kernel, grid, dim3(256), 0, s, (const bf16_t*)qkv, (const bf16_t*)d_o, lse, delta_ws,
-                           (bf16_t*)dqkv, N, H, scale);
+                           (bf16_t*)dqkv, N, H, c2, dk_mul);
     }
     {
         ProfScope prof(HS_PROF_ATTN_DQ, stream, 4.0 * nn, 5 * io);
         hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, s, (const bf16_t*)qkv, (const bf16_t*)d_o, lse, delta_ws,
-                           (bf16_t*)dqkv, N, H, scale);
+                           (bf16_t*)dqkv, N, H, c2, scale);
     }
     HS_CHECK_LAUNCH();
     return HS_OK;

@@ -100,6 +100,8 @@ struct ProfScope {
     ~ProfScope() { hs_prof_end(tok, s); }
 };
 
+extern int g_hs_dbg[8];   // diagnostic variant selectors (prof.hip: hs_debug_set)
+
 #define HS_CHECK_LAUNCH()                                   \
     do {                                                    \
         hipError_t e__ = hipGetLastError();                 \

@@ -18,12 +18,13 @@ struct GemmP {
     float* out_f32; void* out_bf16;
     const float* bias; const float* resid; const void* aux; void* aux_out; float* colsum;
     float alpha; int flags; int split_k; int tiles_m, tiles_n;
+    int scale_cols; float scale_alpha;     // columns n < scale_cols carry the extra factor scale_alpha
 };
 
 template <bool F32AUX>
 __device__ __forceinline__ void epilogue_store(const GemmP& p, long cz, int m, int n, float v) {
     if (m >= p.M || n >= p.N) return;
-    v *= p.alpha;
+    v *= n < p.scale_cols ? p.alpha * p.scale_alpha : p.alpha;
     if (p.flags & HS_EPI_BIAS) v += p.bias[(p.flags & HS_EPI_BIAS_M) ? m : n];
     const long idx = cz + (long)m * p.ldc + n;
     if (p.flags & HS_EPI_GELU) {
@@ -117,8 +118,8 @@ __device__ __forceinline__ bf16x8 g_frag(const char* lds, int sub, int ks, int l
 // hipcc waits vmcnt(0) before every use of a loaded value — with a store between two uses that is one store round trip
 // per step (~32 per block), which cost more than the K=768 main loop.
 // epi_math: v -> final value (bias, GELU(+value to save), GELU', residual); *keep = bf16x4 to store to aux_out.
-__device__ __forceinline__ f32x4 epi_math(const GemmP& p, int m, f32x4 v, f32x4 res, u32x2 zb_in, f32x4 bias_n, u32x2* keep) {
-    v *= p.alpha;
+__device__ __forceinline__ f32x4 epi_math(const GemmP& p, int m, f32x4 v, f32x4 res, u32x2 zb_in, f32x4 bias_n, float alpha_n, u32x2* keep) {
+    v *= alpha_n;
     if (p.flags & HS_EPI_BIAS) {
         if (p.flags & HS_EPI_BIAS_M) v += p.bias[m]; else v += bias_n;      // column bias: hoisted by the caller
     }
@@ -428,6 +429,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmP p) {
             const bool want_res = (p.flags & HS_EPI_RESID) != 0, want_aux = (p.flags & HS_EPI_GELU_BWD) != 0;
             if (vec_ok) {
                 f32x4 bias_n = {0.f, 0.f, 0.f, 0.f};
+                const float alpha_n = nw + cc < p.scale_cols ? p.alpha * p.scale_alpha : p.alpha;   // scale_cols % 4 == 0
                 if ((p.flags & HS_EPI_BIAS) && !(p.flags & HS_EPI_BIAS_M) && nw + cc + 3 < p.N) bias_n = *(const f32x4*)(p.bias + nw + cc);
                 // groups of 8 steps: 8+8 loads in flight -> all math -> all stores (see epi_math)
 #pragma unroll 1
@@ -451,7 +453,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmP p) {
                         const int row = (g * 8 + i) * 4 + rr;
                         const f32x4 v = *(const f32x4*)(my + row * G_EPI_LD + cc);
                         u32x2 keep = {0u, 0u};
-                        val[i] = epi_math(p, mw + row, v, val[i], zbv[i], bias_n, &keep);
+                        val[i] = epi_math(p, mw + row, v, val[i], zbv[i], bias_n, alpha_n, &keep);
                         zbv[i] = keep;
                         if (in[i]) csum += val[i];
                     }
@@ -603,6 +605,7 @@ extern "C" int hs_gemm(const hs_gemm_args* a, int prec, void* stream) {
     if ((a->flags & HS_EPI_GELU_BWD) && !a->aux) return HS_ERR_ARG;
     if (a->split_k > 1 && (!(a->flags & HS_EPI_ATOMIC) || a->batch != 1 || !a->out_f32 || a->out_bf16)) return HS_ERR_SHAPE;
     if (prec != HS_PREC_BF16 && prec != HS_PREC_F32) return HS_ERR_ARG;
+    if (a->scale_cols < 0 || (a->scale_cols & 3) || (a->scale_cols && (a->flags & HS_EPI_ATOMIC))) return HS_ERR_SHAPE;
     if (a->colsum_out && (prec != HS_PREC_BF16 || (a->N & 3) || (a->ldc & 3) || a->batch != 1 || (a->flags & HS_EPI_ATOMIC))) return HS_ERR_SHAPE;
     const int esz = prec == HS_PREC_BF16 ? 2 : 4;
     const int vec = 16 / esz;  // elements per 16-B chunk
@@ -618,6 +621,7 @@ extern "C" int hs_gemm(const hs_gemm_args* a, int prec, void* stream) {
     p.lda = a->lda; p.ldb = a->ldb; p.sA = a->strideA; p.sB = a->strideB; p.sC = a->strideC; p.ldc = a->ldc;
     p.out_f32 = a->out_f32; p.out_bf16 = a->out_bf16; p.bias = a->bias; p.resid = a->resid; p.aux = a->aux;
     p.aux_out = a->aux_out; p.colsum = a->colsum_out; p.alpha = a->alpha; p.flags = a->flags; p.split_k = a->split_k;
+    p.scale_cols = a->scale_cols; p.scale_alpha = a->scale_cols_alpha;
     hipStream_t s = (hipStream_t)stream;
     const int zdim = a->split_k > 1 ? a->split_k : a->batch;
     const double mnk = (double)a->M * a->N * a->K * a->batch;

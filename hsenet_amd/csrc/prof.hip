@@ -69,3 +69,8 @@ extern "C" int hs_prof_read(int id, int* count, double* total_ms, double* flops,
 static const char* kNames[HS_PROF_COUNT] = {"gemm_nt", "gemm_nn", "gemm_tn", "attn_fwd", "attn_bwd_delta", "attn_bwd_dkdv",
                                             "attn_bwd_dq", "layernorm_fwd", "layernorm_bwd", "colsum", "cast", "patchify", "other"};
 extern "C" const char* hs_prof_name(int id) { return (id >= 0 && id < HS_PROF_COUNT) ? kNames[id] : ""; }
+
+// Diagnostic knob for kernel A/B work (tools/kbench.cpp): selects a kernel variant per class.  Not part of the public
+// header; every value defaults to 0 = the shipped kernel.
+int g_hs_dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+extern "C" void hs_debug_set(int key, int value) { if (key >= 0 && key < 8) g_hs_dbg[key] = value; }

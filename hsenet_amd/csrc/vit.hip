@@ -67,9 +67,10 @@ enum { P_W1 = 0, P_B1, P_W2, P_B2, P_N1W, P_N1B, P_WO, P_BO, P_WQKV, P_N2W, P_N2
 
 int gemm(int prec, int layout, const void* A, const void* Bm, int M, int N, int K, long lda, long ldb, float* of32, void* obf,
          long ldc, const float* bias, const float* resid, const void* aux, void* aux_out, int flags, int split_k, void* s,
-         float* colsum = nullptr) {
+         float* colsum = nullptr, int scale_cols = 0, float scale_cols_alpha = 1.0f) {
     hs_gemm_args g = {};
     g.colsum_out = colsum;
+    g.scale_cols = scale_cols; g.scale_cols_alpha = scale_cols_alpha;
     g.A = A; g.B = Bm; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.batch = 1;
     g.out_f32 = of32; g.out_bf16 = obf; g.ldc = ldc; g.bias = bias; g.resid = resid; g.aux = aux; g.aux_out = aux_out;
     g.alpha = 1.0f; g.flags = flags; g.layout = layout; g.split_k = split_k;
@@ -90,6 +91,8 @@ int wgrad_split(int Mo, int No, int K) {
     }
     return best;
 }
+
+const float kQScale = 0.125f * 1.44269504088896341f;   // dh^-0.5 * log2(e), dh = 64
 
 #define RC(x) do { int rc__ = (x); if (rc__ != HS_OK) return rc__; } while (0)
 
@@ -145,9 +148,11 @@ extern "C" int hs_vit_blocks_fwd(const hs_vit_desc* desc, const float* x0, const
             wqkv = p[P_WQKV]; wo = p[P_WO]; w1 = p[P_W1]; w2 = p[P_W2];
         }
         RC(hs_layernorm_fwd(xin, nullptr, p[P_N1W], p[P_N1B], bf ? nullptr : (float*)h1, bf ? h1 : nullptr, st, st + M, M, d, 1e-5f, stream));
+        // bf16: the q third leaves the projection already multiplied by dh^-0.5 * log2(e) (one rounding), which is what the
+        // attention kernels' exp2-based softmax consumes (HS_ATTN_Q_PRESCALED); the f32 parity path keeps raw q
         RC(gemm(c.prec, HS_GEMM_NT, h1, wqkv, M, 3 * d, d, d, d, bf ? nullptr : (float*)qkv, bf ? qkv : nullptr, 3 * d, nullptr, nullptr,
-                nullptr, nullptr, 0, 1, stream));
-        RC(hs_attn_fwd(qkv, o, lse, c.B, c.N, c.H, 64, c.prec, stream));
+                nullptr, nullptr, 0, 1, stream, nullptr, bf ? d : 0, kQScale));
+        RC(hs_attn_fwd(qkv, o, lse, c.B, c.N, c.H, 64, c.prec, bf ? HS_ATTN_Q_PRESCALED : 0, stream));
         RC(gemm(c.prec, HS_GEMM_NT, o, wo, M, d, d, d, d, xmid, nullptr, d, p[P_BO], xin, nullptr, nullptr, HS_EPI_BIAS | HS_EPI_RESID, 1, stream));
         RC(hs_layernorm_fwd(xmid, nullptr, p[P_N2W], p[P_N2B], bf ? nullptr : (float*)h2, bf ? h2 : nullptr, st + 2 * M, st + 3 * M, M, d, 1e-5f, stream));
         RC(gemm(c.prec, HS_GEMM_NT, h2, w1, M, mlp, d, d, d, bf ? nullptr : (float*)a, bf ? a : nullptr, mlp, p[P_B1], nullptr, nullptr,
@@ -218,7 +223,7 @@ extern "C" int hs_vit_blocks_bwd(const hs_vit_desc* desc, const float* x0, const
         RC(gemm(P, HS_GEMM_TN, dxb, o, d, d, M, d, d, g[P_WO], nullptr, d, nullptr, nullptr, nullptr, nullptr, HS_EPI_ATOMIC,
                 wgrad_split(d, d, M), stream));
         RC(gemm(P, HS_GEMM_NN, dxb, wo, M, d, d, d, d, nullptr, dob, d, nullptr, nullptr, nullptr, nullptr, 0, 1, stream));
-        RC(hs_attn_bwd(qkv, o, dob, lse, dqkv, delta, c.B, c.N, c.H, 64, stream));
+        RC(hs_attn_bwd(qkv, o, dob, lse, dqkv, delta, c.B, c.N, c.H, 64, HS_ATTN_Q_PRESCALED, stream));
         RC(gemm(P, HS_GEMM_TN, dqkv, h1, 3 * d, d, M, 3 * d, d, g[P_WQKV], nullptr, d, nullptr, nullptr, nullptr, nullptr, HS_EPI_ATOMIC,
                 wgrad_split(3 * d, d, M), stream));
         RC(gemm(P, HS_GEMM_NN, dqkv, wqkv, M, d, 3 * d, 3 * d, d, nullptr, dh, d, nullptr, nullptr, nullptr, nullptr, 0, 1, stream));

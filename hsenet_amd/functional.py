@@ -56,7 +56,7 @@ def _f32(t: torch.Tensor) -> torch.Tensor:
 # ----------------------------------------------------------------------------------------------------
 def gemm(A: torch.Tensor, Bm: torch.Tensor, layout: int, *, prec: int, out_f32: Optional[torch.Tensor] = None,
          out_bf16: Optional[torch.Tensor] = None, bias=None, resid=None, aux=None, aux_out=None, colsum_out=None,
-         alpha: float = 1.0, flags: int = 0, split_k: int = 1) -> None:
+         alpha: float = 1.0, flags: int = 0, split_k: int = 1, scale_cols: int = 0, scale_cols_alpha: float = 1.0) -> None:
     """C[M,N] = sum_k A(m,k) B(n,k); 2-D or batched 3-D operands (see include/hsenet_hip.h)."""
     _need(A, Bm, out_f32, out_bf16, bias, resid, aux, aux_out, colsum_out)
     want = torch.bfloat16 if prec == L.PREC_BF16 else torch.float32
@@ -84,6 +84,7 @@ def gemm(A: torch.Tensor, Bm: torch.Tensor, layout: int, *, prec: int, out_f32: 
     g.out_f32, g.out_bf16, g.ldc = _p(out_f32), _p(out_bf16), N
     g.bias, g.resid, g.aux, g.aux_out, g.colsum_out = _p(bias), _p(resid), _p(aux), _p(aux_out), _p(colsum_out)
     g.alpha, g.flags, g.layout, g.split_k = alpha, flags, layout, split_k
+    g.scale_cols, g.scale_cols_alpha = scale_cols, scale_cols_alpha
     L.call("hs_gemm", C.byref(g), prec, _s())
 
 
@@ -119,23 +120,24 @@ def _wgrad_split(Mo: int, No: int, K: int, tile=(256, 128), kt: int = 64) -> int
     return best
 
 
-def attn_fwd(qkv: torch.Tensor, H: int, prec: int):
-    """qkv [B,N,3*H*64] -> (o [B,N,H*64], lse [B,H,N])."""
+def attn_fwd(qkv: torch.Tensor, H: int, prec: int, q_prescaled: bool = False):
+    """qkv [B,N,3*H*64] -> (o [B,N,H*64], lse [B,H,N]).  q_prescaled: the q third already carries dh^-0.5*log2(e)."""
     _need(qkv)
     B, N, D3 = qkv.shape
     o = torch.empty(B, N, D3 // 3, dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty(B, H, N, dtype=torch.float32, device=qkv.device)
-    L.call("hs_attn_fwd", qkv.data_ptr(), o.data_ptr(), lse.data_ptr(), B, N, H, 64, prec, _s())
+    L.call("hs_attn_fwd", qkv.data_ptr(), o.data_ptr(), lse.data_ptr(), B, N, H, 64, prec,
+           L.ATTN_Q_PRESCALED if q_prescaled else 0, _s())
     return o, lse
 
 
-def attn_bwd(qkv, o, d_o, lse, H: int):
+def attn_bwd(qkv, o, d_o, lse, H: int, q_prescaled: bool = False):
     _need(qkv, o, d_o, lse)
     B, N, _ = qkv.shape
     dqkv = torch.empty_like(qkv)
     delta = torch.empty(B, H, N, dtype=torch.float32, device=qkv.device)
     L.call("hs_attn_bwd", qkv.data_ptr(), o.data_ptr(), d_o.data_ptr(), lse.data_ptr(), dqkv.data_ptr(), delta.data_ptr(),
-           B, N, H, 64, _s())
+           B, N, H, 64, L.ATTN_Q_PRESCALED if q_prescaled else 0, _s())
     return dqkv
 
 

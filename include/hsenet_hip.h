@@ -65,6 +65,9 @@ typedef struct hs_gemm_args {
     int flags;
     int layout;             /* HS_GEMM_* */
     int split_k;            /* >=1; >1 requires HS_EPI_ATOMIC and batch==1 */
+    int scale_cols;         /* 0, or a multiple of 4: output columns n < scale_cols get the extra factor           */
+    float scale_cols_alpha; /*   scale_cols_alpha on top of alpha (before bias).  The ViT driver uses it to emit the q  */
+                            /*   third of a qkv projection pre-multiplied by dh^-0.5 * log2(e): HS_ATTN_Q_PRESCALED      */
 } hs_gemm_args;
 
 /* ---- library ------------------------------------------------------------------------------------------ */
@@ -106,11 +109,15 @@ int hs_layernorm_bwd(const void* dy, int dy_is_bf16, const float* x, const float
 /* ---- K4: global multi-head self-attention core of MONAI SABlock: softmax(q k^T * dh^-0.5) v, no mask, no
  * bias, non-causal (reached from the hot loops vit.py:352-354,464-466).  qkv: [B][N][3][H][dh] exactly as
  * the qkv Linear emits it ('b n (qkv h dh)'); o: [B][N][H*dh]; lse: [B][H][N] fp32 (natural log-sum-exp of the
- * scaled scores).  dh must be 64.  Flash-style: the N x N matrix is never materialised. */
-int hs_attn_fwd(const void* qkv, void* o, float* lse, int B, int N, int H, int dh, int prec, void* stream);
+ * scaled scores).  dh must be 64.  Flash-style: the N x N matrix is never materialised.
+ * flags: HS_ATTN_Q_PRESCALED = the q third of qkv already holds q * dh^-0.5 * log2(e) (hs_gemm's scale_cols emits it
+ * that way, one rounding); without it the bf16 kernels apply that factor to their register fragments (a second
+ * bf16 rounding of q).  o, lse and dqkv mean the same either way (dqkv is the gradient of the UNSCALED q, k, v). */
+#define HS_ATTN_Q_PRESCALED 1
+int hs_attn_fwd(const void* qkv, void* o, float* lse, int B, int N, int H, int dh, int prec, int flags, void* stream);
 /* dqkv from (qkv, o, do, lse); delta_ws: fp32 scratch [B][H][N].  bf16 only. */
 int hs_attn_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv, float* delta_ws,
-                int B, int N, int H, int dh, void* stream);
+                int B, int N, int H, int dh, int flags, void* stream);
 
 /* ---- K5: slice-guided scoring core of regular_attention (vit.py:25-33,57-60): single head, d_k = d,
  * P = softmax(q k^T / sqrt(d)) over nk keys (nk <= 64, nk % 4 == 0), out = P v.  q: [B][nq][d] fp32;
