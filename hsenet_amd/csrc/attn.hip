@@ -241,6 +241,17 @@ __device__ __forceinline__ void trR_issue(u32x4& f, unsigned b0, unsigned b1) {
     f[0] = lo[0]; f[1] = lo[1]; f[2] = hi[0]; f[3] = hi[1];
 }
 __device__ __forceinline__ void lds_settle2(u32x4& a, u32x4& b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b)::"memory"); }
+// Row-fragment reads issued from asm as well: left to hipcc, each pair of ds_read_b128 is issued just in time and
+// waited for with lgkmcnt(0) right in front of its MFMAs (one LDS round trip per two MFMAs).  Issued in groups ahead of
+// use and retired with COUNTED waits instead; the waits name the registers they release ("+v") so no consumer moves up.
+template <int IMM>
+__device__ __forceinline__ void ldsr128(u32x4& f, unsigned base) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f) : "v"(base), "i"(IMM) : "memory");
+}
+template <int CNT>
+__device__ __forceinline__ void lds_wait4(u32x4& a, u32x4& b, u32x4& c, u32x4& d) {
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "i"(CNT) : "memory");
+}
 __device__ __forceinline__ bf16x8 scale_frag(u32x4 raw, float mul) {
     u32x4 r;
 #pragma unroll
@@ -310,6 +321,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fast_kernel(const bf16_t* __r
         }
     }
 
+    unsigned rbk[4];                                         // K row-fragment bases: row c, chunk 2ks+h
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) rbk[ks] = lds_addr(smem) + offR(c, 2 * ks + h);
     float l[2] = {0.f, 0.f};
     f32x16 oacc[2][2] = {{zero16(), zero16()}, {zero16(), zero16()}};
     // MID tiles: compile-time stage (every LDS address = hoisted base + immediate).  The LAST tile (the only one that can
@@ -317,13 +331,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fast_kernel(const bf16_t* __r
     auto tile = [&](int t, auto stage_tag, auto last_tag, int rst) {
         constexpr bool LAST = decltype(last_tag)::value;
         constexpr int ST = LAST ? 0 : decltype(stage_tag)::value;
-        const char* Kl = smem + ST * 16384 + (LAST ? rst * 16384 : 0);
         constexpr int VB = ST * 16384 + 8192;
         unsigned tb[2][2];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) tb[i][j] = tb0[i][j] + (LAST ? rst * 16384 : 0);
+        unsigned rbase[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) rbase[ks] = rbk[ks] + (LAST ? rst * 16384 : 0);
         f32x16 s[2][2];                                     // [key block][query block]
         u32x4 va[2], vb[2];                                 // V fragments [db] of one 16-key step, double-buffered
         bf16x8 pf[2][2];                                    // packed P^T [query block][sp]
@@ -335,9 +351,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fast_kernel(const bf16_t* __r
                     float p = __builtin_amdgcn_exp2f(s[kb][qb][r]);
                     if (LAST && t * 64 + kb * 32 + acc_row(r, h) >= N) p = 0.f;
                     s[kb][qb][r] = p;
-                    // a single-issue add: -O3 would SLP-pack the two query blocks' sums into v_pk_add_f32, which costs more
-                    // issue time beside MFMAs than the two adds it replaces (MI355X_MICROARCH, cycle constants)
-                    asm("v_add_f32 %0, %1, %0" : "+v"(l[qb]) : "v"(p));
+                    // (this file is built with -fno-slp-vectorize: -O3 would pack the two query blocks' sums into
+                    // v_pk_add_f32, which costs more issue time beside MFMAs than the two adds it replaces.  Not done with
+                    // an asm v_add: hipcc pads no hazards inside asm, and a VALU reading a v_exp result needs a wait state)
+                    l[qb] += p;
                 }
                 pf[qb][0] = pack8(s[kb][qb], 0);
                 pf[qb][1] = pack8(s[kb][qb], 1);
@@ -350,21 +367,28 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fast_kernel(const bf16_t* __r
                 for (int qb = 0; qb < 2; ++qb)
                     oacc[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f[db]), pf[qb][sp], oacc[qb][db], 0, 0, 0);
         };
-        // step 1: S^T of key block 0 for both query blocks (each K fragment feeds two MFMAs)
+        // K row fragments of both key blocks are issued up front (asm reads, counted waits); each feeds two MFMAs
+        u32x4 ka[4], kc[4];
+        constexpr int KO = ST * 16384;
+        ldsr128<KO>(ka[0], rbase[0]); ldsr128<KO>(ka[1], rbase[1]); ldsr128<KO>(ka[2], rbase[2]); ldsr128<KO>(ka[3], rbase[3]);
+        ldsr128<KO + 4096>(kc[0], rbase[0]); ldsr128<KO + 4096>(kc[1], rbase[1]); ldsr128<KO + 4096>(kc[2], rbase[2]); ldsr128<KO + 4096>(kc[3], rbase[3]);
         s[0][0] = zero16(); s[0][1] = zero16(); s[1][0] = zero16(); s[1][1] = zero16();
+        lds_wait4<4>(ka[0], ka[1], ka[2], ka[3]);
+        // step 1: S^T of key block 0 for both query blocks
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            const bf16x8 kf = row_frag(Kl, c, ks, h);
+            const bf16x8 kf = __builtin_bit_cast(bf16x8, ka[ks]);
             s[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[0][ks], s[0][0], 0, 0, 0);
             s[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[1][ks], s[0][1], 0, 0, 0);
         }
         // V fragments of keys 0..15 fly while step 2 runs
         trR_issue<VB + 0>(va[0], tb[0][0], tb[0][1]);
         trR_issue<VB + 0>(va[1], tb[1][0], tb[1][1]);
+        lds_wait4<4>(kc[0], kc[1], kc[2], kc[3]);
         // step 2: S^T of key block 1 || softmax of key block 0
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            const bf16x8 kf = row_frag(Kl, 32 + c, ks, h);
+            const bf16x8 kf = __builtin_bit_cast(bf16x8, kc[ks]);
             s[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[0][ks], s[1][0], 0, 0, 0);
             s[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[1][ks], s[1][1], 0, 0, 0);
         }
@@ -797,6 +821,450 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const bf16_t* __res
     if (query < N) store_dT(dqkv + ((long)b * N + query) * D3 + head * 64, dq, scale, h);
 }
 
+// ------------------------------------------------------------------------------------------------------
+// backward v2.  attn_stats_kernel leaves, per (b, head, query): ws[0] = -delta = -sum_d dO*O and ws[1] = -lse*log2(e), the
+// two row constants both sweeps preload into their MFMA accumulators (S' = q'.k - lse*log2e, dP' = dO.v - delta), so
+// that P = exp2(S') and dS = P * dP' need no subtraction (cdna guide, attention backward, "row constants as the initial
+// accumulator").  P = exp2(S' ) <= 1 always: unlike the forward fast path nothing here is optimistic.
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_stats_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ d_o,
+                                                         const float* __restrict__ lse, float* __restrict__ ws, int B, int N, int H) {
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)B * N * H * 8;
+    float acc = 0.f;
+    const bool ok = gid < total;
+    if (ok) {
+        const u32x4 a = *(const u32x4*)(o + gid * 8);
+        const u32x4 g = *(const u32x4*)(d_o + gid * 8);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            acc += __uint_as_float(a[i] << 16) * __uint_as_float(g[i] << 16);
+            acc += __uint_as_float(a[i] & 0xffff0000u) * __uint_as_float(g[i] & 0xffff0000u);
+        }
+    }
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    acc += __shfl_xor(acc, 4, 64);
+    if (ok && (threadIdx.x & 7) == 0) {
+        const long row = gid >> 3;  // (b*N + n)*H + head
+        const int head = (int)(row % H);
+        const long bn = row / H;
+        const int n = (int)(bn % N), b = (int)(bn / N);
+        const long i = ((long)b * H + head) * N + n;
+        ws[i] = -acc;
+        ws[(long)B * H * N + i] = -lse[i] * 1.44269504088896341f;
+    }
+}
+
+__device__ __forceinline__ void lds_settle4(u32x4& a, u32x4& b, u32x4& c, u32x4& d) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)::"memory");
+}
+__device__ __forceinline__ f32x16 splat16(float v) {
+    f32x16 z;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[r] = v;
+    return z;
+}
+
+// dQ v2: NW waves x 32 queries per block; K/V tiles by LDS-DMA (3-stage ring, prefetch distance 2).  Per 32-key block:
+// S'^T = K q'^T + (-lse*log2e), dP'^T = V dO^T + (-delta)  (row constants = splat accumulators, loop-invariant here),
+// dS^T = exp2(S'^T) * dP'^T -> bf16 -> dQ^T[d][q] += K^T dS^T (K read transposed from the same image).
+// NW = 4 with two blocks per CU: the two waves of a SIMD then belong to different blocks and drift out of phase, so one
+// wave's exp/convert stretch runs under the other's MFMAs (two waves of ONE block are phase-locked by the tile barrier).
+template <int NW>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void attn_bwd_dq2_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
+                                                           const float* __restrict__ ws, bf16_t* __restrict__ dqkv, int B,
+                                                           int N, int H, float qmul, float out_mul) {
+    __shared__ __attribute__((aligned(16))) char smem[3 * 16384];
+    constexpr int QB = NW * 32, NP = 8 / NW;                 // queries per block; K (and V) DMA pieces per wave per tile
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int blk, head, b;
+    attn_block_coords((N + QB - 1) / QB, H, blk, head, b);
+    const int q0 = blk * QB + wave * 32;
+    const bool active = q0 < N;
+    const int Dm = H * 64, D3 = 3 * Dm;
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(qkv + (long)b * N * D3, (size_t)N * D3 * 2);
+    const __amdgpu_buffer_rsrc_t rsd = make_rsrc(d_o + (long)b * N * Dm, (size_t)N * Dm * 2);
+    const int nt = (N + 63) >> 6;
+    unsigned vk[NP], vkl[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const int row = (wave * NP + j) * 8 + (lane >> 3);
+        const int ch = (lane & 7) ^ swzR(row);
+        vk[j] = (unsigned)(((long)row * D3 + Dm + head * 64 + ch * 8) * 2);
+        vkl[j] = (nt - 1) * 64 + row < N ? vk[j] : HS_OOB_OFF;
+    }
+    const unsigned tile_bytes = (unsigned)(64 * D3 * 2), v_off = (unsigned)(Dm * 2);
+    auto issue = [&](int t, int st) {
+        const unsigned so = (unsigned)t * tile_bytes;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const unsigned vo = t == nt - 1 ? vkl[j] : vk[j];
+            char* dst = smem + st * 16384 + (wave * NP + j) * 1024;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (LDS_PTR(void))dst, 16, vo, so, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (LDS_PTR(void))(dst + 8192), 16, vo == HS_OOB_OFF ? vo : vo + v_off, so, 0, 0);
+        }
+    };
+    issue(0, 0);
+    if (nt > 1) issue(1, 1);
+
+    const int qrow = min(q0 + c, N - 1);
+    bf16x8 qf[4], dof[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        qf[ks] = scale_frag(buf_load16(rs, (unsigned)(((long)qrow * D3 + head * 64 + ks * 16 + 8 * h) * 2)), qmul);
+        dof[ks] = __builtin_bit_cast(bf16x8, buf_load16(rsd, (unsigned)(((long)qrow * Dm + head * 64 + ks * 16 + 8 * h) * 2)));
+    }
+    const long srow = ((long)b * H + head) * N + qrow;
+    f32x16 cd = splat16(ws[srow]), cl = splat16(ws[(long)B * H * N + srow]);
+    asm volatile("" : "+v"(cd), "+v"(cl));          // opaque: keep the 2 x 16 registers instead of re-splatting per use
+    unsigned rb0[4];                                         // row-fragment bases: row c, chunk 2ks+h (image R swizzle)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) rb0[ks] = lds_addr(smem) + offR(c, 2 * ks + h);
+    unsigned tb0[2][2];
+    {
+        const int g = lane >> 4, p = lane & 3, q = (lane >> 2) & 3;
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+            const int col = db * 32 + 16 * (g & 1) + 4 * p;
+            tb0[db][0] = lds_addr(smem) + offR(4 * h + q, col >> 3) + 8 * (p & 1);
+            tb0[db][1] = lds_addr(smem) + offR(4 * h + q + 8, col >> 3) + 8 * (p & 1);
+        }
+    }
+    f32x16 dq[2] = {zero16(), zero16()};
+    auto tile = [&](int t, auto stage_tag, auto last_tag, int rst) {
+        constexpr bool LAST = decltype(last_tag)::value;
+        constexpr int ST = LAST ? 0 : decltype(stage_tag)::value;
+        constexpr int KB = ST * 16384;
+        unsigned tb[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) tb[i][j] = tb0[i][j] + (LAST ? rst * 16384 : 0);
+        f32x16 st[2], dpt[2];
+        u32x4 fa[4], fb[4];                                  // K^T fragments [sp*2 + db] of key block 0 / 1
+        u32x4 ra[4], rb_[4];                                 // row fragments {K ks, V ks, K ks+1, V ks+1}, double-buffered
+        unsigned rbase[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) rbase[ks] = rb0[ks] + (LAST ? rst * 16384 : 0);
+        // group G = (kb, half): K and V row fragments of k-steps 2*half, 2*half+1 of key block kb
+        auto rows = [&](u32x4 (&r)[4], auto kb_tag, auto half_tag) {
+            constexpr int OFF = KB + decltype(kb_tag)::value * 4096, HF = decltype(half_tag)::value;
+            ldsr128<OFF>(r[0], rbase[2 * HF]);
+            ldsr128<OFF + 8192>(r[1], rbase[2 * HF]);
+            ldsr128<OFF>(r[2], rbase[2 * HF + 1]);
+            ldsr128<OFF + 8192>(r[3], rbase[2 * HF + 1]);
+        };
+        auto sdp = [&](u32x4 (&r)[4], int kb, int half) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, r[2 * i]), qf[2 * half + i], st[kb], 0, 0, 0);
+                dpt[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, r[2 * i + 1]), dof[2 * half + i], dpt[kb], 0, 0, 0);
+            }
+        };
+        auto valu = [&](int kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float ds = __builtin_amdgcn_exp2f(st[kb][r]) * dpt[kb][r];
+                if (LAST && t * 64 + kb * 32 + acc_row(r, h) >= N) ds = 0.f;
+                dpt[kb][r] = ds;
+            }
+        };
+        auto acc = [&](u32x4 (&f)[4], int kb) {
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp) {
+                const bf16x8 dsf = pack8(dpt[kb], sp);
+#pragma unroll
+                for (int db = 0; db < 2; ++db)
+                    dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f[sp * 2 + db]), dsf, dq[db], 0, 0, 0);
+            }
+        };
+        typedef std::integral_constant<int, 0> I0;
+        typedef std::integral_constant<int, 1> I1;
+        st[0] = cl; dpt[0] = cd; st[1] = cl; dpt[1] = cd;
+        rows(ra, I0{}, I0{});
+        rows(rb_, I0{}, I1{});
+        lds_wait4<4>(ra[0], ra[1], ra[2], ra[3]);
+        sdp(ra, 0, 0);
+        rows(ra, I1{}, I0{});
+        lds_wait4<4>(rb_[0], rb_[1], rb_[2], rb_[3]);
+        sdp(rb_, 0, 1);
+        rows(rb_, I1{}, I1{});
+        lds_wait4<4>(ra[0], ra[1], ra[2], ra[3]);
+        sdp(ra, 1, 0);
+        // (never more than 15 LDS reads in flight: lgkmcnt is a 4-bit counter)
+        trR_issue<KB + 0>(fa[0], tb[0][0], tb[0][1]);            // 8 transposed reads: K^T fragments of key block 0
+        trR_issue<KB + 0>(fa[1], tb[1][0], tb[1][1]);
+        trR_issue<KB + 2048>(fa[2], tb[0][0], tb[0][1]);
+        trR_issue<KB + 2048>(fa[3], tb[1][0], tb[1][1]);
+        valu(0);
+        lds_wait4<8>(rb_[0], rb_[1], rb_[2], rb_[3]);
+        sdp(rb_, 1, 1);
+        lds_wait4<0>(fa[0], fa[1], fa[2], fa[3]);
+        trR_issue<KB + 4096>(fb[0], tb[0][0], tb[0][1]);
+        trR_issue<KB + 4096>(fb[1], tb[1][0], tb[1][1]);
+        trR_issue<KB + 6144>(fb[2], tb[0][0], tb[0][1]);
+        trR_issue<KB + 6144>(fb[3], tb[1][0], tb[1][1]);
+        acc(fa, 0);
+        valu(1);
+        lds_wait4<0>(fb[0], fb[1], fb[2], fb[3]);
+        acc(fb, 1);
+    };
+    typedef std::integral_constant<int, 0> S0;
+    typedef std::integral_constant<int, 1> S1;
+    typedef std::integral_constant<int, 2> S2;
+    auto step = [&](int t, auto stage_tag) {
+        constexpr int ST = decltype(stage_tag)::value;
+        if (NP == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (t + 2 < nt) issue(t + 2, (ST + 2) % 3);
+        if (active) tile(t, stage_tag, std::false_type{}, 0);
+    };
+    int t = 0;
+    for (; t + 3 < nt; t += 3) {
+        step(t, S0{});
+        step(t + 1, S1{});
+        step(t + 2, S2{});
+    }
+    int rst = 0;
+    if (t + 1 < nt) { step(t, S0{}); ++t; rst = 1; }
+    if (t + 1 < nt) { step(t, S1{}); ++t; rst = 2; }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (!active) return;
+    tile(t, S0{}, std::true_type{}, rst);
+    const int query = q0 + c;
+    if (query < N) store_dT(dqkv + ((long)b * N + query) * D3 + head * 64, dq, out_mul, h);
+}
+
+template <int CNT>
+__device__ __forceinline__ void lds_wait8(u32x4& a, u32x4& b, u32x4& c, u32x4& d, u32x4& e, u32x4& f, u32x4& g, u32x4& i) {
+    asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(i) : "i"(CNT) : "memory");
+}
+__device__ __forceinline__ f32x16 cat16(u32x4 a, u32x4 b, u32x4 c, u32x4 d) {
+    f32x16 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        r[e] = __uint_as_float(a[e]); r[4 + e] = __uint_as_float(b[e]);
+        r[8 + e] = __uint_as_float(c[e]); r[12 + e] = __uint_as_float(d[e]);
+    }
+    return r;
+}
+
+// dK, dV v2: NW waves x 32 keys per block (K, V fragments and the dK^T, dV^T accumulators stay in registers), sweeping the
+// queries in 64-row tiles that arrive by LDS-DMA: Q' image | dO image | -lse*log2e [64] | -delta [64] per stage, 3-stage
+// ring.  Per 32-query block: S' = Q' K^T + (-lse*log2e)[q], dP' = dO V^T + (-delta)[q] (row constants preloaded as the
+// accumulators, read from the stage), P = exp2(S'), dS = P * dP'; dV^T += dO^T P, dK^T += Q'^T dS (Q', dO read
+// transposed from the same images).  Query rows >= N arrive as zeros (range-checked DMA): P = 1 there but dO = 0 and
+// dP' = 0, so they add nothing.  Every LDS read is issued from asm in chunks ahead of use, with counted waits.
+template <int NW>
+__device__ __forceinline__ void attn_bwd_dkdv2_body(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
+                                                    const float* __restrict__ ws, bf16_t* __restrict__ dqkv, int B,
+                                                    int N, int H, float kmul, float dk_mul) {
+    constexpr int STG = 16896, KBK = NW * 32, NP = 8 / NW;
+    __shared__ __attribute__((aligned(16))) char smem[3 * STG];
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int blk, head, b;
+    attn_block_coords((N + KBK - 1) / KBK, H, blk, head, b);
+    const int k0 = blk * KBK + wave * 32;
+    const bool active = k0 < N;
+    const int Dm = H * 64, D3 = 3 * Dm;
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(qkv + (long)b * N * D3, (size_t)N * D3 * 2);
+    const __amdgpu_buffer_rsrc_t rsd = make_rsrc(d_o + (long)b * N * Dm, (size_t)N * Dm * 2);
+    // waves 0 / 1 also bring the tile's 64 row constants (4 B per lane): -lse*log2e (ws[1]) / -delta (ws[0])
+    const __amdgpu_buffer_rsrc_t rst_ = make_rsrc(ws + (wave == 0 ? (long)B * H * N : 0) + ((long)b * H + head) * N, (size_t)N * 4);
+    const int nt = (N + 63) >> 6;
+    unsigned vq[NP], vd[NP], vql[NP], vdl[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const int row = (wave * NP + j) * 8 + (lane >> 3);
+        const int ch = (lane & 7) ^ swzR(row);
+        vq[j] = (unsigned)(((long)row * D3 + head * 64 + ch * 8) * 2);
+        vd[j] = (unsigned)(((long)row * Dm + head * 64 + ch * 8) * 2);
+        const bool in = (nt - 1) * 64 + row < N;
+        vql[j] = in ? vq[j] : HS_OOB_OFF;
+        vdl[j] = in ? vd[j] : HS_OOB_OFF;
+    }
+    const unsigned vs = (unsigned)lane * 4u, vsl = (nt - 1) * 64 + lane < N ? vs : HS_OOB_OFF;
+    const unsigned qtile = (unsigned)(64 * D3 * 2), dtile = (unsigned)(64 * Dm * 2);
+    auto issue = [&](int t, int st) {
+        const bool last = t == nt - 1;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            char* dst = smem + st * STG + (wave * NP + j) * 1024;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (LDS_PTR(void))dst, 16, last ? vql[j] : vq[j], (unsigned)t * qtile, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsd, (LDS_PTR(void))(dst + 8192), 16, last ? vdl[j] : vd[j], (unsigned)t * dtile, 0, 0);
+        }
+        if (wave < 2)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rst_, (LDS_PTR(void))(smem + st * STG + 16384 + wave * 256), 4, last ? vsl : vs,
+                                                     (unsigned)t * 256u, 0, 0);
+    };
+    issue(0, 0);
+    if (nt > 1) issue(1, 1);
+
+    const int key = k0 + c;
+    bf16x8 kf[4], vf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const unsigned off = key < N ? (unsigned)(((long)key * D3 + Dm + head * 64 + ks * 16 + 8 * h) * 2) : HS_OOB_OFF;
+        kf[ks] = scale_frag(buf_load16(rs, off), kmul);
+        vf[ks] = __builtin_bit_cast(bf16x8, buf_load16(rs, key < N ? off + Dm * 2 : HS_OOB_OFF));
+    }
+    unsigned rb0[4], tb0[2][2];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) rb0[ks] = lds_addr(smem) + offR(c, 2 * ks + h);
+    {
+        const int g = lane >> 4, p = lane & 3, q = (lane >> 2) & 3;
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+            const int col = db * 32 + 16 * (g & 1) + 4 * p;
+            tb0[db][0] = lds_addr(smem) + offR(4 * h + q, col >> 3) + 8 * (p & 1);
+            tb0[db][1] = lds_addr(smem) + offR(4 * h + q + 8, col >> 3) + 8 * (p & 1);
+        }
+    }
+    const unsigned sb0 = lds_addr(smem) + 16384 + 16 * h;      // row constants of rows 4h..4h+3 (+32 B per 8 rows)
+
+    f32x16 dk[2] = {zero16(), zero16()}, dv[2] = {zero16(), zero16()};
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 1> I1;
+    auto tile = [&](auto stage_tag, int rst) {
+        constexpr int ST = decltype(stage_tag)::value;            // -1: run-time stage (last tile)
+        constexpr int SB = ST < 0 ? 0 : ST * STG;
+        const unsigned dyn = ST < 0 ? (unsigned)rst * STG : 0u;
+        unsigned rbase[4], tb[2][2];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) rbase[ks] = rb0[ks] + dyn;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) tb[i][j] = tb0[i][j] + dyn;
+        const unsigned sbase = sb0 + dyn;
+        u32x4 c1[2][8];                                      // row constants [qb][{lse x4, delta x4}]
+        u32x4 ra[4], rb_[4];                                 // row fragments {Q ks, dO ks, Q ks+1, dO ks+1}
+        u32x4 ta[4], tc[4];                                  // transposed fragments {dO^T db0, dO^T db1, Q^T db0, Q^T db1} of one q-step
+        f32x16 s[2], dp[2];
+        auto stats = [&](auto qb_tag) {
+            constexpr int QB = decltype(qb_tag)::value, O = SB + QB * 128;
+            ldsr128<O>(c1[QB][0], sbase); ldsr128<O + 32>(c1[QB][1], sbase); ldsr128<O + 64>(c1[QB][2], sbase); ldsr128<O + 96>(c1[QB][3], sbase);
+            ldsr128<O + 256>(c1[QB][4], sbase); ldsr128<O + 288>(c1[QB][5], sbase); ldsr128<O + 320>(c1[QB][6], sbase); ldsr128<O + 352>(c1[QB][7], sbase);
+        };
+        auto rows = [&](u32x4 (&r)[4], auto qb_tag, auto half_tag) {
+            constexpr int OFF = SB + decltype(qb_tag)::value * 4096, HF = decltype(half_tag)::value;
+            ldsr128<OFF>(r[0], rbase[2 * HF]);
+            ldsr128<OFF + 8192>(r[1], rbase[2 * HF]);
+            ldsr128<OFF>(r[2], rbase[2 * HF + 1]);
+            ldsr128<OFF + 8192>(r[3], rbase[2 * HF + 1]);
+        };
+        auto trs = [&](u32x4 (&f)[4], auto qb_tag, auto sp_tag) {
+            constexpr int OFF = SB + decltype(qb_tag)::value * 4096 + decltype(sp_tag)::value * 2048;
+            trR_issue<OFF + 8192>(f[0], tb[0][0], tb[0][1]);
+            trR_issue<OFF + 8192>(f[1], tb[1][0], tb[1][1]);
+            trR_issue<OFF>(f[2], tb[0][0], tb[0][1]);
+            trR_issue<OFF>(f[3], tb[1][0], tb[1][1]);
+        };
+        auto sdp = [&](u32x4 (&r)[4], int qb, int half) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                s[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, r[2 * i]), kf[2 * half + i], s[qb], 0, 0, 0);
+                dp[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, r[2 * i + 1]), vf[2 * half + i], dp[qb], 0, 0, 0);
+            }
+        };
+        auto valu = [&](int qb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __builtin_amdgcn_exp2f(s[qb][r]);
+                s[qb][r] = p;
+                dp[qb][r] = p * dp[qb][r];
+            }
+        };
+        auto dvdk = [&](u32x4 (&f)[4], int qb, int sp) {
+            const bf16x8 pf = pack8(s[qb], sp), dsf = pack8(dp[qb], sp);
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f[db]), pf, dv[db], 0, 0, 0);
+                dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f[2 + db]), dsf, dk[db], 0, 0, 0);
+            }
+        };
+        // never more than 15 LDS reads in flight (lgkmcnt is a 4-bit counter); counts in brackets = in flight after the line
+        stats(I0{});                                                                                 // [8]
+        rows(ra, I0{}, I0{});                                                                        // [12]
+        lds_wait8<4>(c1[0][0], c1[0][1], c1[0][2], c1[0][3], c1[0][4], c1[0][5], c1[0][6], c1[0][7]);
+        s[0] = cat16(c1[0][0], c1[0][1], c1[0][2], c1[0][3]);
+        dp[0] = cat16(c1[0][4], c1[0][5], c1[0][6], c1[0][7]);
+        rows(rb_, I0{}, I1{});                                                                       // [8]
+        lds_wait4<4>(ra[0], ra[1], ra[2], ra[3]);
+        sdp(ra, 0, 0);
+        stats(I1{});                                                                                 // [12]
+        lds_wait4<8>(rb_[0], rb_[1], rb_[2], rb_[3]);
+        sdp(rb_, 0, 1);
+        rows(ra, I1{}, I0{});                                                                        // [12]
+        lds_wait8<4>(c1[1][0], c1[1][1], c1[1][2], c1[1][3], c1[1][4], c1[1][5], c1[1][6], c1[1][7]);
+        s[1] = cat16(c1[1][0], c1[1][1], c1[1][2], c1[1][3]);
+        dp[1] = cat16(c1[1][4], c1[1][5], c1[1][6], c1[1][7]);
+        rows(rb_, I1{}, I1{});                                                                       // [8]
+        valu(0);
+        lds_wait4<4>(ra[0], ra[1], ra[2], ra[3]);
+        sdp(ra, 1, 0);
+        trs(ta, I0{}, I0{});                                                                         // [12]
+        lds_wait4<8>(rb_[0], rb_[1], rb_[2], rb_[3]);
+        sdp(rb_, 1, 1);
+        lds_wait4<0>(ta[0], ta[1], ta[2], ta[3]);
+        trs(tc, I0{}, I1{});                                                                         // [8]
+        dvdk(ta, 0, 0);
+        valu(1);
+        lds_wait4<0>(tc[0], tc[1], tc[2], tc[3]);
+        trs(ta, I1{}, I0{});                                                                         // [8]
+        dvdk(tc, 0, 1);
+        lds_wait4<0>(ta[0], ta[1], ta[2], ta[3]);
+        trs(tc, I1{}, I1{});                                                                         // [8]
+        dvdk(ta, 1, 0);
+        lds_wait4<0>(tc[0], tc[1], tc[2], tc[3]);
+        dvdk(tc, 1, 1);
+    };
+    typedef std::integral_constant<int, 2> I2;
+    typedef std::integral_constant<int, -1> IR;
+    auto step = [&](int t, auto stage_tag) {
+        constexpr int ST = decltype(stage_tag)::value;
+        if (wave < 2) { if (NP == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); }
+        else { if (NP == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+        __builtin_amdgcn_s_barrier();
+        if (t + 2 < nt) issue(t + 2, (ST + 2) % 3);
+        if (active) tile(stage_tag, 0);
+    };
+    int t = 0;
+    for (; t + 3 < nt; t += 3) {
+        step(t, I0{});
+        step(t + 1, I1{});
+        step(t + 2, I2{});
+    }
+    int rst = 0;
+    if (t + 1 < nt) { step(t, I0{}); ++t; rst = 1; }
+    if (t + 1 < nt) { step(t, I1{}); ++t; rst = 2; }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (!active) return;
+    tile(IR{}, rst);
+    if (key < N) {
+        bf16_t* row = dqkv + ((long)b * N + key) * D3 + head * 64;
+        store_dT(row + Dm, dk, dk_mul, h);
+        store_dT(row + 2 * Dm, dv, 1.0f, h);
+    }
+}
+
+// (thin non-template kernels: hipcc's host pass silently dropped the launch stub of the templated __global__ form)
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv2_w4_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
+                                                                  const float* __restrict__ ws, bf16_t* __restrict__ dqkv, int B,
+                                                                  int N, int H, float kmul, float dk_mul) {
+    attn_bwd_dkdv2_body<4>(qkv, d_o, ws, dqkv, B, N, H, kmul, dk_mul);
+}
+__global__ __launch_bounds__(512, 2) void attn_bwd_dkdv2_w8_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
+                                                                  const float* __restrict__ ws, bf16_t* __restrict__ dqkv, int B,
+                                                                  int N, int H, float kmul, float dk_mul) {
+    attn_bwd_dkdv2_body<8>(qkv, d_o, ws, dqkv, B, N, H, kmul, dk_mul);
+}
+
 extern "C" int hs_attn_fwd(const void* qkv, void* o, float* lse, int B, int N, int H, int dh, int prec, int flags, void* stream) {
     if (!qkv || !o) return HS_ERR_ARG;
     if (dh != 64 || B < 1 || N < 1 || H < 1) return HS_ERR_SHAPE;
@@ -847,21 +1315,42 @@ extern "C" int hs_attn_bwd(const void* qkv, const void* o, const void* d_o, cons
     const long total = (long)B * N * H * 8;
     const double nn = (double)B * H * N * N * 64;   // algorithmic bwd = 5 products = 10*nn, split 6:4 over the two kernels
     const double io = (double)B * N * H * 64 * 2;
+    // g_hs_dbg[1] / [2] (diagnostic): 9 = the v1 dQ / dK,dV kernel; 1 = the 8-wave form of the v2 kernel
+    const int vq_ = g_hs_dbg[1], vk_ = g_hs_dbg[2];
+    float* nstat = delta_ws;                                  // [0] = -delta, [1] = -lse*log2e   (2 x [B][H][N])
+    float* delta_v1 = delta_ws + 2 * (size_t)B * H * N;       // +delta for the v1 kernels (diagnostic runs only: 3 x [B][H][N])
     {
         ProfScope prof(HS_PROF_ATTN_DELTA, stream, 0, 2 * io);
-        hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const bf16_t*)o,
-                           (const bf16_t*)d_o, delta_ws, B, N, H);
+        hipLaunchKernelGGL(attn_stats_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const bf16_t*)o,
+                           (const bf16_t*)d_o, lse, nstat, B, N, H);
+        if (vq_ == 9 || vk_ == 9)
+            hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const bf16_t*)o,
+                               (const bf16_t*)d_o, delta_v1, B, N, H);
     }
-    dim3 grid((unsigned)(((N + 127) / 128) * H * B));
+    dim3 grid((unsigned)(((N + 127) / 128) * H * B)), grid2((unsigned)(((N + 255) / 256) * H * B));
     {
         ProfScope prof(HS_PROF_ATTN_DKDV, stream, 6.0 * nn, 6 * io);
-        hipLaunchKernelGGL(attn_bwd_dkdv_kernel, grid, dim3(256), 0, s, (const bf16_t*)qkv, (const bf16_t*)d_o, lse, delta_ws,
-                           (bf16_t*)dqkv, N, H, c2, dk_mul);
+        if (vk_ == 9)
+            hipLaunchKernelGGL(attn_bwd_dkdv_kernel, grid, dim3(256), 0, s, (const bf16_t*)qkv, (const bf16_t*)d_o, lse, delta_v1,
+                               (bf16_t*)dqkv, N, H, c2, dk_mul);
+        else if (vk_ == 1)
+            hipLaunchKernelGGL(attn_bwd_dkdv2_w8_kernel, grid2, dim3(512), 0, s, (const bf16_t*)qkv, (const bf16_t*)d_o, nstat,
+                               (bf16_t*)dqkv, B, N, H, c2, dk_mul);
+        else
+            hipLaunchKernelGGL(attn_bwd_dkdv2_w4_kernel, grid, dim3(256), 0, s, (const bf16_t*)qkv, (const bf16_t*)d_o, nstat,
+                               (bf16_t*)dqkv, B, N, H, c2, dk_mul);
     }
     {
         ProfScope prof(HS_PROF_ATTN_DQ, stream, 4.0 * nn, 5 * io);
-        hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, s, (const bf16_t*)qkv, (const bf16_t*)d_o, lse, delta_ws,
-                           (bf16_t*)dqkv, N, H, c2, scale);
+        if (vq_ == 9)
+            hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, s, (const bf16_t*)qkv, (const bf16_t*)d_o, lse, delta_v1,
+                               (bf16_t*)dqkv, N, H, c2, scale);
+        else if (vq_ == 1)
+            hipLaunchKernelGGL(attn_bwd_dq2_kernel<8>, grid2, dim3(512), 0, s, (const bf16_t*)qkv, (const bf16_t*)d_o, nstat,
+                               (bf16_t*)dqkv, B, N, H, c2, scale);
+        else
+            hipLaunchKernelGGL(attn_bwd_dq2_kernel<4>, grid, dim3(256), 0, s, (const bf16_t*)qkv, (const bf16_t*)d_o, nstat,
+                               (bf16_t*)dqkv, B, N, H, c2, scale);
     }
     HS_CHECK_LAUNCH();
     return HS_OK;

@@ -48,7 +48,7 @@ Layout make_layout(const hs_vit_desc& c) {
     L.dob = take(bwd ? M * d * 2 : 0);
     L.dz = take(bwd ? M * mlp * 2 : 0);
     L.dqkv = take(bwd ? M * 3 * d * 2 : 0);
-    L.delta = take(bwd ? (size_t)c.B * c.H * c.N * 4 : 0);
+    L.delta = take(bwd ? (size_t)c.B * c.H * c.N * 4 * 2 : 0);   // hs_attn_bwd scratch: -delta | -lse*log2e
     L.total = off;
     return L;
 }

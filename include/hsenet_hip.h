@@ -115,7 +115,8 @@ int hs_layernorm_bwd(const void* dy, int dy_is_bf16, const float* x, const float
  * bf16 rounding of q).  o, lse and dqkv mean the same either way (dqkv is the gradient of the UNSCALED q, k, v). */
 #define HS_ATTN_Q_PRESCALED 1
 int hs_attn_fwd(const void* qkv, void* o, float* lse, int B, int N, int H, int dh, int prec, int flags, void* stream);
-/* dqkv from (qkv, o, do, lse); delta_ws: fp32 scratch [B][H][N].  bf16 only. */
+/* dqkv from (qkv, o, do, lse); delta_ws: fp32 scratch 2 x [B][H][N] (row constants -sum(dO*O) and -lse*log2(e)).
+ * bf16 only. */
 int hs_attn_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv, float* delta_ws,
                 int B, int N, int H, int dh, int flags, void* stream);
 

@@ -161,13 +161,20 @@ int main(int argc, char** argv) {
             void* d_o = dev_bf16_gauss(no, 1.0f);
             void* dqkv[2] = {dev_zero(nq * 2), dev_zero(nq * 2)};
             float* delta = (float*)dev_zero(nl * 4 * 2 + (size_t)B * N * Dm * 4);
-            for (int i = 0; i < 2; ++i) { dbg(key, var[i]); int rc = bwd(qkv, o[0], d_o, lse[0], dqkv[i], delta, B, N, H, 64, aflags, 0); if (rc) { printf("variant %d rc=%d\n", var[i], rc); return 3; } }
+            for (int i = 0; i < 2; ++i) { dbg(1, var[i] % 10); dbg(2, var[i] / 10); int rc = bwd(qkv, o[0], d_o, lse[0], dqkv[i], delta, B, N, H, 64, aflags, 0); if (rc) { printf("variant %d rc=%d\n", var[i], rc); return 3; } }
             CK(hipDeviceSynchronize());
             Cmp c = cmp_bf16(dqkv[0], dqkv[1], nq);
             printf("attn bwd B=%d N=%d: variant %d vs %d: dqkv rel %.3e maxabs %.3e\n", B, N, vA, vB, c.rel, c.maxabs);
+            {   // per section (dq | dk | dv)
+                std::vector<uint16_t> ha(nq), hb(nq);
+                CK(hipMemcpy(ha.data(), dqkv[0], nq * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(hb.data(), dqkv[1], nq * 2, hipMemcpyDeviceToHost));
+                double num[3] = {0, 0, 0}, den[3] = {0, 0, 0};
+                for (size_t i = 0; i < nq; ++i) { const int sec = (int)((i % (3 * Dm)) / Dm); const double x = bf2f(ha[i]), y = bf2f(hb[i]); num[sec] += (x - y) * (x - y); den[sec] += x * x; }
+                printf("   dq rel %.3e | dk rel %.3e | dv rel %.3e\n", std::sqrt(num[0] / den[0]), std::sqrt(num[1] / den[1]), std::sqrt(num[2] / den[2]));
+            }
             for (int round = 0; round < 3; ++round)
                 for (int i = 0; i < 2; ++i) {
-                    dbg(key, var[i]);
+                    dbg(1, var[i] % 10); dbg(2, var[i] / 10);      // variant = 10 * (dK/dV kernel) + (dQ kernel)
                     const double us = time_us([&] { bwd(qkv, o[0], d_o, lse[0], dqkv[i], delta, B, N, H, 64, aflags, 0); }, reps);
                     printf("  round %d variant %d: %9.1f us  %7.1f TFLOP/s (algorithmic 10 N^2 d)\n", round, var[i], us, 2.5 * fl_f / us / 1e6);
                 }
