@@ -19,6 +19,7 @@ struct GemmP {
     const float* bias; const float* resid; const void* aux; void* aux_out; float* colsum;
     float alpha; int flags; int split_k; int tiles_m, tiles_n;
     int scale_cols; float scale_alpha;     // columns n < scale_cols carry the extra factor scale_alpha
+    int dbg;                               // diagnostic (tools/kbench): 1 = skip the epilogue, 2 = one K-tile only
 };
 
 template <bool F32AUX>
@@ -118,12 +119,12 @@ __device__ __forceinline__ bf16x8 g_frag(const char* lds, int sub, int ks, int l
 // hipcc waits vmcnt(0) before every use of a loaded value — with a store between two uses that is one store round trip
 // per step (~32 per block), which cost more than the K=768 main loop.
 // epi_math: v -> final value (bias, GELU(+value to save), GELU', residual); *keep = bf16x4 to store to aux_out.
-__device__ __forceinline__ f32x4 epi_math(const GemmP& p, int m, f32x4 v, f32x4 res, u32x2 zb_in, f32x4 bias_n, float alpha_n, u32x2* keep) {
+__device__ __forceinline__ f32x4 epi_math(const GemmP& p, const int flags, int m, f32x4 v, f32x4 res, u32x2 zb_in, f32x4 bias_n, float alpha_n, u32x2* keep) {
     v *= alpha_n;
-    if (p.flags & HS_EPI_BIAS) {
-        if (p.flags & HS_EPI_BIAS_M) v += p.bias[m]; else v += bias_n;      // column bias: hoisted by the caller
+    if (flags & HS_EPI_BIAS) {
+        if (flags & HS_EPI_BIAS_M) v += p.bias[m]; else v += bias_n;      // column bias: hoisted by the caller
     }
-    if (p.flags & HS_EPI_GELU) {
+    if (flags & HS_EPI_GELU) {
         u32x2 zb;
         zb[0] = pack2bf(v[0], v[1]); zb[1] = pack2bf(v[2], v[3]);       // autocast: linear1 emits bf16
         v[0] = __uint_as_float(zb[0] << 16); v[1] = __uint_as_float(zb[0] & 0xffff0000u);
@@ -133,13 +134,13 @@ __device__ __forceinline__ f32x4 epi_math(const GemmP& p, int m, f32x4 v, f32x4 
         for (int e = 0; e < 4; ++e) { float c, px; gelu_parts(v[e], c, px); v[e] *= c; dg[e] = c + px; }
         // HS_EPI_SAVE_DGELU: keep gelu'(z) (it shares exp(-z^2/2) with gelu) instead of z, so the backward epilogue is
         // one multiply instead of an erf + exp per element
-        if (p.flags & HS_EPI_SAVE_DGELU) { zb[0] = pack2bf(dg[0], dg[1]); zb[1] = pack2bf(dg[2], dg[3]); }
+        if (flags & HS_EPI_SAVE_DGELU) { zb[0] = pack2bf(dg[0], dg[1]); zb[1] = pack2bf(dg[2], dg[3]); }
         *keep = zb;
     }
-    if (p.flags & HS_EPI_GELU_BWD) {
+    if (flags & HS_EPI_GELU_BWD) {
         const float z[4] = {__uint_as_float(zb_in[0] << 16), __uint_as_float(zb_in[0] & 0xffff0000u),
                             __uint_as_float(zb_in[1] << 16), __uint_as_float(zb_in[1] & 0xffff0000u)};
-        if (p.flags & HS_EPI_SAVE_DGELU) {
+        if (flags & HS_EPI_SAVE_DGELU) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] *= z[e];                  // aux already holds gelu'(z)
         } else {
@@ -147,7 +148,7 @@ __device__ __forceinline__ f32x4 epi_math(const GemmP& p, int m, f32x4 v, f32x4 
             for (int e = 0; e < 4; ++e) { float c, px; gelu_parts(z[e], c, px); v[e] *= (c + px); }
         }
     }
-    if (p.flags & HS_EPI_RESID) v += res;
+    if (flags & HS_EPI_RESID) v += res;
     return v;
 }
 __device__ __forceinline__ void epi_store(const GemmP& p, long idx, f32x4 v, u32x2 keep) {
@@ -290,7 +291,23 @@ __device__ __forceinline__ void ktile_step(f32x16 (&acc)[GCfg<BIG>::MB][2], cons
     }
 }
 
-template <bool ATR, bool BTR, bool BIG>
+// diagnostic (dbg == 4): per-phase cycle sums of the epilogue, wave 0 lane 0 of every block (tools/kbench)
+__device__ unsigned long long g_gemm_stamps[8];
+extern "C" void hs_debug_gemm_stamps(unsigned long long* out, int reset) {
+    if (out) (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gemm_stamps), sizeof(g_gemm_stamps));
+    if (reset) { unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_stamps), z, sizeof(z)); }
+}
+#define STAMP(i) do { if (p.dbg == 4) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0) atomicAdd(&g_gemm_stamps[i], t_ - t_prev); t_prev = t_; } } while (0)
+
+// (asm with register constraints lives in __device__ helpers, never directly in a templated __global__ body: hipcc's
+// host pass then silently drops the kernel's launch stub)
+__device__ __forceinline__ void keep_alive(const f32x16& v) { asm volatile("" ::"v"(v)); }
+__device__ __forceinline__ void keep4(const f32x4& v) { asm volatile("" ::"v"(v)); }
+
+// EF >= 0: the epilogue flags as a compile-time constant (the launcher checked p.flags == EF and the 8-column
+// conditions): the flag tests fold away.  Run-time flags (EF = -1) cost ~1500 cycles of branches per epilogue step --
+// 24k cycles per 256x256 tile, more than half of a K = 768 main loop.
+template <bool ATR, bool BTR, bool BIG, int EF>
 __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmP p) {
     typedef GCfg<BIG> C;
     __shared__ __attribute__((aligned(16))) char smem[C::SMEM];
@@ -336,6 +353,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmP p) {
         kt1 = min(kt_total, kt0 + per);
         if (kt0 >= kt1) return;
     }
+    if (p.dbg == 2) kt1 = kt0 + 1;
+    unsigned long long t_prev = p.dbg == 4 ? __builtin_amdgcn_s_memtime() : 0ull;
     f32x16 acc[C::MB][2];
 #pragma unroll
     for (int i = 0; i < C::MB; ++i)
@@ -367,6 +386,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmP p) {
             }
         }
     };
+    STAMP(0);     // setup
     // ring: prefetch distance D = NSTAGE-1 tiles.  At step kt: wait until tile kt has landed (D-1 newer tiles may stay
     // in flight: counted vmcnt), barrier, then issue tile kt+D into the stage every wave finished reading before
     // that barrier (the one consumed at step kt-1).
@@ -400,9 +420,17 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmP p) {
     // ---- epilogue through LDS: each wave parks a 64x64 fp32 piece of its tile in its own 17 KiB slice of the (now
     // idle) ring and reads it back row-wise, so global stores/atomics and the bias/resid/aux loads are 128-256-B row
     // segments instead of one 4-8-B piece per row (which cost more than the K=768 main loop).
+    STAMP(1);     // main loop
     __builtin_amdgcn_s_barrier();     // every wave is done reading the operand stages
+    STAMP(2);     // post-loop barrier
+    if (p.dbg == 1) {
+#pragma unroll
+        for (int i = 0; i < C::MB; ++i) { keep_alive(acc[i][0]); keep_alive(acc[i][1]); }
+        return;
+    }
     float* my = (float*)(smem + wave * (64 * G_EPI_LD * 4));
     const int h = lane >> 5, c = lane & 31;
+    const int flags = EF >= 0 ? EF : p.flags;
     const bool vec_ok = !(p.N & 3) && !(p.ldc & 3);
 #pragma unroll
     for (int half = 0; half < C::MB / 2; ++half) {
@@ -415,8 +443,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmP p) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        STAMP(3);     // staging writes
         const int mw = m0 + row0 + half * 64, nw = n0 + col0;
-        if (p.flags & HS_EPI_ATOMIC) {
+        if (flags & HS_EPI_ATOMIC) {
             // one float per lane: every atomic wave-instruction is 256 contiguous bytes of one row
             const int n = nw + lane;
             for (int row = 0; row < 64; ++row) {
@@ -424,13 +453,89 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmP p) {
                 if (m < p.M && n < p.N) atomicAdd(p.out_f32 + cz + (long)m * p.ldc + n, my[row * G_EPI_LD + lane] * p.alpha);
             }
         } else {
+            const bool want_res = (flags & HS_EPI_RESID) != 0, want_aux = (flags & HS_EPI_GELU_BWD) != 0;
+            if (EF >= 0 || (vec_ok && !(p.N & 7) && !(p.ldc & 7) && !(p.scale_cols & 7))) {
+                // 8 consecutive columns per lane, 8 rows per wave-instruction: bf16 outputs leave as 16-B stores (the
+                // store tail is issue-bound: half as many store instructions at equal bytes), fp32 ones as 2 x 16 B.
+                const int r8 = lane >> 3, c8 = (lane & 7) * 8, n = nw + c8;
+                f32x4 bias_lo = {0.f, 0.f, 0.f, 0.f}, bias_hi = {0.f, 0.f, 0.f, 0.f}, cs_lo = bias_lo, cs_hi = bias_lo;
+                const float alpha_n = n < p.scale_cols ? p.alpha * p.scale_alpha : p.alpha;
+                const bool n_in = n < p.N;
+                if ((flags & HS_EPI_BIAS) && !(flags & HS_EPI_BIAS_M) && n_in) {
+                    bias_lo = *(const f32x4*)(p.bias + n);
+                    bias_hi = *(const f32x4*)(p.bias + n + 4);
+                }
+                constexpr int GS = BIG ? 2 : 4;
+                // groups of GS steps: all loads in flight -> all math -> all stores (see epi_math).  The 256x256 tile still holds
+                // 64-128 accumulator registers here: smaller groups keep the epilogue out of scratch (a reload is a memory round trip)
+#pragma unroll 1
+                for (int g = 0; g < 8 / GS; ++g) {
+                    f32x4 vlo[GS], vhi[GS];
+                    u32x4 zb[GS];
+                    bool in[GS];
+                    long idx[GS];
+#pragma clang loop unroll(full)
+                    for (int i = 0; i < GS; ++i) {
+                        const int m = mw + (g * GS + i) * 8 + r8;
+                        in[i] = m < p.M && n_in;
+                        idx[i] = cz + (long)m * p.ldc + n;
+                        vlo[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        vhi[i] = vlo[i];
+                        zb[i] = u32x4{0u, 0u, 0u, 0u};
+                        if (want_res && in[i]) { vlo[i] = *(const f32x4*)(p.resid + idx[i]); vhi[i] = *(const f32x4*)(p.resid + idx[i] + 4); }
+                        if (want_aux && in[i]) zb[i] = *(const u32x4*)((const bf16_t*)p.aux + idx[i]);
+                    }
+#pragma clang loop unroll(full)
+                    for (int i = 0; i < GS; ++i) {
+                        const int row = (g * GS + i) * 8 + r8;
+                        const f32x4 a = *(const f32x4*)(my + row * G_EPI_LD + c8), b = *(const f32x4*)(my + row * G_EPI_LD + c8 + 4);
+                        u32x2 k0 = {0u, 0u}, k1 = {0u, 0u};
+                        vlo[i] = epi_math(p, flags, mw + row, a, vlo[i], u32x2{zb[i][0], zb[i][1]}, bias_lo, alpha_n, &k0);
+                        vhi[i] = epi_math(p, flags, mw + row, b, vhi[i], u32x2{zb[i][2], zb[i][3]}, bias_hi, alpha_n, &k1);
+                        zb[i] = u32x4{k0[0], k0[1], k1[0], k1[1]};
+                        if (in[i]) { cs_lo += vlo[i]; cs_hi += vhi[i]; }
+                    }
+#pragma clang loop unroll(full)
+                    for (int i = 0; i < GS; ++i)
+                        if (in[i] && p.dbg == 3) { keep4(vlo[i]); keep4(vhi[i]); }
+                        else if (in[i]) {
+                            if ((flags & HS_EPI_GELU) && p.aux_out) *(u32x4*)((bf16_t*)p.aux_out + idx[i]) = zb[i];
+                            if (p.out_f32) { *(f32x4*)(p.out_f32 + idx[i]) = vlo[i]; *(f32x4*)(p.out_f32 + idx[i] + 4) = vhi[i]; }
+                            if (p.out_bf16) {
+                                u32x4 o;
+                                o[0] = pack2bf(vlo[i][0], vlo[i][1]); o[1] = pack2bf(vlo[i][2], vlo[i][3]);
+                                o[2] = pack2bf(vhi[i][0], vhi[i][1]); o[3] = pack2bf(vhi[i][2], vhi[i][3]);
+                                *(u32x4*)((bf16_t*)p.out_bf16 + idx[i]) = o;
+                            }
+                        }
+                }
+                if (p.colsum) {   // fused bias gradient: column sums of this wave's 64x64 piece, one atomic per column
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        cs_lo[e] += __shfl_xor(cs_lo[e], 8, 64);  cs_hi[e] += __shfl_xor(cs_hi[e], 8, 64);
+                        cs_lo[e] += __shfl_xor(cs_lo[e], 16, 64); cs_hi[e] += __shfl_xor(cs_hi[e], 16, 64);
+                        cs_lo[e] += __shfl_xor(cs_lo[e], 32, 64); cs_hi[e] += __shfl_xor(cs_hi[e], 32, 64);
+                    }
+                    if (lane < 8 && n_in) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { atomicAdd(p.colsum + n + e, cs_lo[e]); atomicAdd(p.colsum + n + 4 + e, cs_hi[e]); }
+                    }
+                }
+                if (half + 1 < C::MB / 2) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                }
+                STAMP(4);     // read back + math + stores issued
+                continue;
+            }
+            if constexpr (EF < 0) {
             const int rr = lane >> 4, cc = (lane & 15) * 4;
             f32x4 csum = {0.f, 0.f, 0.f, 0.f};
-            const bool want_res = (p.flags & HS_EPI_RESID) != 0, want_aux = (p.flags & HS_EPI_GELU_BWD) != 0;
             if (vec_ok) {
                 f32x4 bias_n = {0.f, 0.f, 0.f, 0.f};
                 const float alpha_n = nw + cc < p.scale_cols ? p.alpha * p.scale_alpha : p.alpha;   // scale_cols % 4 == 0
-                if ((p.flags & HS_EPI_BIAS) && !(p.flags & HS_EPI_BIAS_M) && nw + cc + 3 < p.N) bias_n = *(const f32x4*)(p.bias + nw + cc);
+                if ((flags & HS_EPI_BIAS) && !(flags & HS_EPI_BIAS_M) && nw + cc + 3 < p.N) bias_n = *(const f32x4*)(p.bias + nw + cc);
                 // groups of 8 steps: 8+8 loads in flight -> all math -> all stores (see epi_math)
 #pragma unroll 1
                 for (int g = 0; g < 2; ++g) {
@@ -453,7 +558,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmP p) {
                         const int row = (g * 8 + i) * 4 + rr;
                         const f32x4 v = *(const f32x4*)(my + row * G_EPI_LD + cc);
                         u32x2 keep = {0u, 0u};
-                        val[i] = epi_math(p, mw + row, v, val[i], zbv[i], bias_n, alpha_n, &keep);
+                        val[i] = epi_math(p, flags, mw + row, v, val[i], zbv[i], bias_n, alpha_n, &keep);
                         zbv[i] = keep;
                         if (in[i]) csum += val[i];
                     }
@@ -481,6 +586,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmP p) {
                     for (int e = 0; e < 4; ++e) atomicAdd(p.colsum + nw + cc + e, csum[e]);
                 }
             }
+            }   // EF < 0
         }
         if (half + 1 < C::MB / 2) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -622,6 +728,7 @@ extern "C" int hs_gemm(const hs_gemm_args* a, int prec, void* stream) {
     p.out_f32 = a->out_f32; p.out_bf16 = a->out_bf16; p.bias = a->bias; p.resid = a->resid; p.aux = a->aux;
     p.aux_out = a->aux_out; p.colsum = a->colsum_out; p.alpha = a->alpha; p.flags = a->flags; p.split_k = a->split_k;
     p.scale_cols = a->scale_cols; p.scale_alpha = a->scale_cols_alpha;
+    p.dbg = g_hs_dbg[3];
     hipStream_t s = (hipStream_t)stream;
     const int zdim = a->split_k > 1 ? a->split_k : a->batch;
     const double mnk = (double)a->M * a->N * a->K * a->batch;
@@ -636,15 +743,28 @@ extern "C" int hs_gemm(const hs_gemm_args* a, int prec, void* stream) {
         const bool big = force ? (force[0] == 'b') : (a->layout != HS_GEMM_TN && big_blocks >= 230);
         p.tiles_n = (a->N + (big ? 255 : 127)) / (big ? 256 : 128);
         dim3 grid(p.tiles_m * p.tiles_n * zdim, 1, 1);
-#define HS_LAUNCH(ATR, BTR)                                                                                          \
+        // epilogue specialisations (compile-time flags); anything else runs the generic kernel (EF = -1)
+        const bool col8 = !(a->N & 7) && !(a->ldc & 7) && !(a->scale_cols & 7);
+        const int f = a->flags;
+#define HS_LAUNCH_E(ATR, BTR, EF)                                                                                    \
     do {                                                                                                             \
-        if (big) hipLaunchKernelGGL((gemm_bf16_kernel<ATR, BTR, true>), grid, dim3(512), 0, s, p);                    \
-        else hipLaunchKernelGGL((gemm_bf16_kernel<ATR, BTR, false>), grid, dim3(512), 0, s, p);                       \
+        if (big) hipLaunchKernelGGL((gemm_bf16_kernel<ATR, BTR, true, EF>), grid, dim3(512), 0, s, p);                \
+        else hipLaunchKernelGGL((gemm_bf16_kernel<ATR, BTR, false, EF>), grid, dim3(512), 0, s, p);                   \
     } while (0)
-        if (a->layout == HS_GEMM_NT) HS_LAUNCH(false, false);
-        else if (a->layout == HS_GEMM_NN) HS_LAUNCH(false, true);
-        else HS_LAUNCH(true, true);
-#undef HS_LAUNCH
+        if (a->layout == HS_GEMM_NT) {
+            if (col8 && f == 0) HS_LAUNCH_E(false, false, 0);
+            else if (col8 && f == (HS_EPI_BIAS | HS_EPI_RESID)) HS_LAUNCH_E(false, false, HS_EPI_BIAS | HS_EPI_RESID);
+            else if (col8 && f == (HS_EPI_BIAS | HS_EPI_GELU | HS_EPI_SAVE_DGELU)) HS_LAUNCH_E(false, false, HS_EPI_BIAS | HS_EPI_GELU | HS_EPI_SAVE_DGELU);
+            else HS_LAUNCH_E(false, false, -1);
+        } else if (a->layout == HS_GEMM_NN) {
+            if (col8 && f == 0) HS_LAUNCH_E(false, true, 0);
+            else if (col8 && f == (HS_EPI_GELU_BWD | HS_EPI_SAVE_DGELU)) HS_LAUNCH_E(false, true, HS_EPI_GELU_BWD | HS_EPI_SAVE_DGELU);
+            else HS_LAUNCH_E(false, true, -1);
+        } else {
+            if (f == HS_EPI_ATOMIC) hipLaunchKernelGGL((gemm_bf16_kernel<true, true, false, HS_EPI_ATOMIC>), grid, dim3(512), 0, s, p);
+            else hipLaunchKernelGGL((gemm_bf16_kernel<true, true, false, -1>), grid, dim3(512), 0, s, p);
+        }
+#undef HS_LAUNCH_E
     } else {
         p.tiles_m = (a->M + 63) / 64;
         dim3 grid(p.tiles_m * ((a->N + 63) / 64), 1, zdim);

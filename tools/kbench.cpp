@@ -184,6 +184,7 @@ int main(int argc, char** argv) {
     if (mode == "gemm") {
         auto gemm = sym<gemm_t>("hs_gemm");
         const char* filt = argc > 4 ? argv[4] : "";
+        if (getenv("HS_GEMM_DBG")) dbg(3, atoi(getenv("HS_GEMM_DBG")));
         const int M = B * N;
         struct Sh { const char* name; int lay, m, n, k; int flags; };
         const Sh shapes[] = {
@@ -218,6 +219,16 @@ int main(int argc, char** argv) {
             CK(hipDeviceSynchronize());
             const double us = time_us([&] { gemm(&a, HS_PREC_BF16, 0); }, reps);
             printf("%-16s M=%6d N=%5d K=%6d: %8.1f us  %7.1f TFLOP/s\n", s.name, s.m, s.n, s.k, us, 2.0 * s.m * s.n * s.k / us / 1e6);
+            if (getenv("HS_GEMM_DBG") && atoi(getenv("HS_GEMM_DBG")) == 4) {
+                typedef void (*st_t)(unsigned long long*, int);
+                auto st = sym<st_t>("hs_debug_gemm_stamps");
+                unsigned long long v[8];
+                st(nullptr, 1);
+                gemm(&a, HS_PREC_BF16, 0); CK(hipDeviceSynchronize());
+                st(v, 0);
+                const double nb = (double)((s.m + 255) / 256) * ((s.n + 255) / 256);
+                printf("    cycles/block (wave 0): setup %.0f | main loop %.0f | barrier %.0f | staging %.0f | readback+math+stores %.0f\n", v[0] / nb, v[1] / nb, v[2] / nb, v[3] / nb, v[4] / nb);
+            }
             fflush(stdout);
             CK(hipFree(A)); CK(hipFree(Bm)); CK(hipFree(out));
         }
