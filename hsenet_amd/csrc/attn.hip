@@ -241,17 +241,6 @@ __device__ __forceinline__ void trR_issue(u32x4& f, unsigned b0, unsigned b1) {
     f[0] = lo[0]; f[1] = lo[1]; f[2] = hi[0]; f[3] = hi[1];
 }
 __device__ __forceinline__ void lds_settle2(u32x4& a, u32x4& b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b)::"memory"); }
-// Row-fragment reads issued from asm as well: left to hipcc, each pair of ds_read_b128 is issued just in time and
-// waited for with lgkmcnt(0) right in front of its MFMAs (one LDS round trip per two MFMAs).  Issued in groups ahead of
-// use and retired with COUNTED waits instead; the waits name the registers they release ("+v") so no consumer moves up.
-template <int IMM>
-__device__ __forceinline__ void ldsr128(u32x4& f, unsigned base) {
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f) : "v"(base), "i"(IMM) : "memory");
-}
-template <int CNT>
-__device__ __forceinline__ void lds_wait4(u32x4& a, u32x4& b, u32x4& c, u32x4& d) {
-    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "i"(CNT) : "memory");
-}
 __device__ __forceinline__ bf16x8 scale_frag(u32x4 raw, float mul) {
     u32x4 r;
 #pragma unroll

@@ -88,6 +88,23 @@ __device__ __forceinline__ bf16x8 cat4(bf16x4 a, bf16x4 b) {
     return r;
 }
 
+// ---- LDS reads issued from asm ----------------------------------------------------------------
+// Row-fragment reads issued from asm: left to hipcc, each pair of ds_read_b128 is issued just in time and
+// waited for with lgkmcnt(0) right in front of its MFMAs (one LDS round trip per two MFMAs).  Issued in groups ahead of
+// use and retired with COUNTED waits instead; the waits name the registers they release ("+v") so no consumer moves up.
+template <int IMM>
+__device__ __forceinline__ void ldsr128(u32x4& f, unsigned base) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f) : "v"(base), "i"(IMM) : "memory");
+}
+template <int CNT>
+__device__ __forceinline__ void lds_wait4(u32x4& a, u32x4& b, u32x4& c, u32x4& d) {
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "i"(CNT) : "memory");
+}
+template <int CNT>
+__device__ __forceinline__ void lds_wait6(u32x4& a, u32x4& b, u32x4& c, u32x4& d, u32x4& e, u32x4& f) {
+    asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f) : "i"(CNT) : "memory");
+}
+
 // per-kernel-class profiling (prof.hip); ids mirror hs_prof_name()
 enum { HS_PROF_GEMM_NT = 0, HS_PROF_GEMM_NN, HS_PROF_GEMM_TN, HS_PROF_ATTN_FWD, HS_PROF_ATTN_DELTA, HS_PROF_ATTN_DKDV,
        HS_PROF_ATTN_DQ, HS_PROF_LN_FWD, HS_PROF_LN_BWD, HS_PROF_COLSUM, HS_PROF_CAST, HS_PROF_PATCHIFY, HS_PROF_OTHER,

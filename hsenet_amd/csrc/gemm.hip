@@ -291,6 +291,104 @@ __device__ __forceinline__ void ktile_step(f32x16 (&acc)[GCfg<BIG>::MB][2], cons
     }
 }
 
+// ---- main loop of the 256x256 tile, software-pipelined by hand -----------------------------------------------------
+// Left to hipcc, the fragment reads of this tile are issued just in time (4 ds_read_b128, lgkmcnt(0), 4 MFMAs, 2 reads,
+// wait, 2 MFMAs, ...): three exposed LDS round trips per 8 MFMAs, ~55 % of the matrix rate.  Here every LDS read is an
+// asm statement: the fragments of k-step ks+1 are issued before the MFMAs of k-step ks and retired with a COUNTED
+// lgkmcnt, across the K-tile boundary too: the tile barrier sits between k-steps 2 and 3, so that k-step 3 prefetches
+// the next tile's first fragments and issues half of the DMA of the tile after it.
+//   per K-tile t (stage s = t & 1):   ks0: read F(t,1) | MFMA F(t,0) | DMA pieces 4-7 of tile t+1 -> stage s^1
+//                                     ks1: read F(t,2) | MFMA F(t,1)
+//                                     ks2: read F(t,3) | MFMA F(t,2)
+//                                     lgkmcnt(0) (every read of stage s retired), vmcnt(0) (tile t+1 landed), s_barrier
+//                                     ks3: read F(t+1,0) from stage s^1 | MFMA F(t,3) | DMA pieces 0-3 of tile t+2 -> stage s
+// Requires K % 64 == 0 (hs_gemm picks the 256x128 tile otherwise).
+template <bool BTR>
+__device__ __forceinline__ void big_mainloop(f32x16 (&acc)[4][2], char* smem, int row0, int col0, int wave, int lane,
+                                             __amdgpu_buffer_rsrc_t rsA, __amdgpu_buffer_rsrc_t rsB, const unsigned (&va)[4],
+                                             const unsigned (&vb)[4], unsigned ka, unsigned kb, int kt0, int kt1, int dbg) {
+    constexpr int STAGE = GCfg<true>::STAGE;       // 65536: beyond a ds_read immediate, so stage bases live in registers
+    const int h = lane >> 5, c = lane & 31;
+    unsigned ab0[4], bb0[4], tbb0[2][2];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        ab0[ks] = lds_off(smem) + offR(row0 + c, 2 * ks + h);
+        bb0[ks] = lds_off(smem) + 32768 + offR(col0 + c, 2 * ks + h);
+    }
+    if (BTR) {
+        tr_bases(smem + 32768, col0, lane, tbb0[0]);
+        tr_bases(smem + 32768, col0 + 32, lane, tbb0[1]);
+    }
+    u32x4 fa[2][4], fb[2][2];
+    // fragments of k-step KS of the tile in the stage at byte offset so -> set S
+    auto rd = [&](auto set_tag, auto ks_tag, unsigned so) {
+        constexpr int S = decltype(set_tag)::value, KS = decltype(ks_tag)::value;
+        const unsigned a = ab0[KS] + so;
+        ldsr128<0>(fa[S][0], a); ldsr128<4096>(fa[S][1], a); ldsr128<8192>(fa[S][2], a); ldsr128<12288>(fa[S][3], a);
+        if (!BTR) {
+            const unsigned b = bb0[KS] + so;
+            ldsr128<0>(fb[S][0], b); ldsr128<4096>(fb[S][1], b);
+        } else {
+            unsigned t0[2] = {tbb0[0][0] + so, tbb0[0][1] + so}, t1[2] = {tbb0[1][0] + so, tbb0[1][1] + so};
+            tr_issue<KS>(fb[S][0], t0);
+            tr_issue<KS>(fb[S][1], t1);
+        }
+    };
+    auto settle = [&](auto set_tag, auto cnt_tag) {
+        constexpr int S = decltype(set_tag)::value, CNT = decltype(cnt_tag)::value;
+        lds_wait6<CNT>(fa[S][0], fa[S][1], fa[S][2], fa[S][3], fb[S][0], fb[S][1]);
+    };
+    auto mma = [&](auto set_tag) {
+        constexpr int S = decltype(set_tag)::value;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(fa[S][i]), as_frag(fb[S][j]), acc[i][j], 0, 0, 0);
+    };
+    auto dma = [&](int kt, unsigned so, int q0) {          // pieces q0 .. q0+3 of tile kt (0-3: A, 4-7: B)
+        if (dbg == 5) kt = kt0;                              // diagnostic: every tile re-reads the first one (cache hits)
+        char* sa = smem + so;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (q0 == 0) dma_piece(rsA, sa, q, wave, va[q], (unsigned)kt * ka);
+            else dma_piece(rsB, sa + 32768, q, wave, vb[q], (unsigned)kt * kb);
+        }
+    };
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 1> I1;
+    typedef std::integral_constant<int, 2> I2;
+    typedef std::integral_constant<int, 3> I3;
+    constexpr int NR = BTR ? 8 : 6;                          // LDS read instructions per k-step
+    typedef std::integral_constant<int, NR> CN;
+    dma(kt0, 0, 0);
+    dma(kt0, 0, 4);
+    if (kt0 + 1 < kt1) {
+        dma(kt0 + 1, STAGE, 0);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    rd(I0{}, I0{}, 0u);
+    unsigned so = 0;
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const bool has1 = kt + 1 < kt1, has2 = kt + 2 < kt1;
+        const unsigned so1 = so ^ (unsigned)STAGE;
+        rd(I1{}, I1{}, so); settle(I0{}, CN{}); mma(I0{});
+        if (has1) dma(kt + 1, so1, 4);
+        rd(I0{}, I2{}, so); settle(I1{}, CN{}); mma(I1{});
+        rd(I1{}, I3{}, so); settle(I0{}, CN{}); mma(I0{});
+        settle(I1{}, I0{});                                  // lgkmcnt(0): every read of this stage has landed
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (has1) rd(I0{}, I0{}, so1);
+        mma(I1{});
+        if (has2) dma(kt + 2, so, 0);
+        so = so1;
+    }
+}
+
 // diagnostic (dbg == 4): per-phase cycle sums of the epilogue, wave 0 lane 0 of every block (tools/kbench)
 __device__ unsigned long long g_gemm_stamps[8];
 extern "C" void hs_debug_gemm_stamps(unsigned long long* out, int reset) {
@@ -387,6 +485,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmP p) {
         }
     };
     STAMP(0);     // setup
+    if constexpr (BIG) {
+        big_mainloop<BTR>(acc, smem, row0, col0, wave, lane, rsA, rsB, va, vb, ka, kb, kt0, kt1, p.dbg);
+    } else {
     // ring: prefetch distance D = NSTAGE-1 tiles.  At step kt: wait until tile kt has landed (D-1 newer tiles may stay
     // in flight: counted vmcnt), barrier, then issue tile kt+D into the stage every wave finished reading before
     // that barrier (the one consumed at step kt-1).
@@ -416,6 +517,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmP p) {
         }
         ktile_step<ATR, BTR, BIG>(acc, a_l, b_l, nxt, row0, col0, wave, lane, rsA, rsB, va, vb, sa, sb, issue);
         st = (D == 2) ? (st == 2 ? 0 : st + 1) : (st ^ 1);
+    }
     }
     // ---- epilogue through LDS: each wave parks a 64x64 fp32 piece of its tile in its own 17 KiB slice of the (now
     // idle) ring and reads it back row-wise, so global stores/atomics and the bias/resid/aux loads are 128-256-B row
@@ -740,7 +842,7 @@ extern "C" int hs_gemm(const hs_gemm_args* a, int prec, void* stream) {
         p.tiles_m = (a->M + 255) / 256;
         const long big_blocks = (long)p.tiles_m * ((a->N + 255) / 256) * zdim;
         const char* force = getenv("HS_GEMM_TILE");   // "big" / "small": tools/bench_gemm.py A/B runs
-        const bool big = force ? (force[0] == 'b') : (a->layout != HS_GEMM_TN && big_blocks >= 230);
+        const bool big = !(a->K & 63) && (force ? (force[0] == 'b') : (a->layout != HS_GEMM_TN && big_blocks >= 230));
         p.tiles_n = (a->N + (big ? 255 : 127)) / (big ? 256 : 128);
         dim3 grid(p.tiles_m * p.tiles_n * zdim, 1, 1);
         // epilogue specialisations (compile-time flags); anything else runs the generic kernel (EF = -1)
