@@ -72,6 +72,11 @@ SIGNATURES = {
     "hs_l2norm_fwd": [_vp, _vp, _i, _i, _f, _vp],
     "hs_l2norm_bwd": [_vp, _vp, _vp, _i, _i, _f, _vp],
     "hs_adamw": [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _f, _i, _vp],
+    "hs_prep_hu_window": [_vp, _i, _vp, _i, _i, _i, C.c_double, C.c_double, C.c_double, C.c_double, _vp],
+    "hs_prep_resample": [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, C.c_float, C.c_float, _vp],
+    "hs_prep_minmax": [_vp, C.c_int64, _vp, _vp],
+    "hs_prep_foreground_bbox": [_vp, _i, _i, _i, C.c_float, _vp, _vp],
+    "hs_prep_augment": [_vp, _vp, _i, _i, _i, _i, _i, _i, C.c_float, C.c_float, _vp],
     "hs_clip_ce": [_vp, _vp, _vp, _i, _vp],
     "hs_scale": [_vp, _vp, _f, _i64, _vp],
     "hs_prof_enable": [_i],

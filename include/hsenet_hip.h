@@ -174,6 +174,24 @@ int hs_clip_ce(const float* logits, float* dlogits, float* loss, int n, void* st
 /* y = alpha * x (fp32): the synthetic bench loss gradient dL/dy = y * 2/numel of L = mean(y^2) */
 int hs_scale(const float* x, float* y, float alpha, int64_t n, void* stream);
 
+/* ---- N2: CT volume preprocessing in front of the path (Data/data_processing/CT-RATE/
+ * CT-RATE_nii_to_3D_volume_npy_file.py:25-124) and the train-time augmentation (LaMed/src/dataset/multi_dataset.py:148-158).
+ * hs_prep_hu_window: out[d][h][w] (float64) = clamp(slope*raw[h][w][d] + intercept, lo, hi), raw (H,W,D) float32/float64.
+ * hs_prep_resample: trilinear, align_corners=False (torch F.interpolate(size=..)), of the window [c0, c0+c) of a
+ *   (iD,iH,iW) volume to (oD,oH,oW) float32; every tap is mapped v -> (v - sub)/den first (min-max fused; 0, 1 = none);
+ *   float64 input is interpolated in float64 (resize_array on the f64 tensor), float32 input in float32 (MONAI Resize).
+ * hs_prep_minmax: out2 = {min, max}, caller initialises {+inf, -inf}.  hs_prep_foreground_bbox: box6 = {min d,h,w,
+ *   max d,h,w} of {x > thresh} (MONAI CropForeground with its default select_fn), caller initialises {D,H,W,-1,-1,-1}.
+ * hs_prep_augment: np.rot90(rot_k, axes=(H,W)) -> flips (bit0 D, bit1 H, bit2 W) -> *scale -> +shift on (C,D,H,W). */
+int hs_prep_hu_window(const void* raw, int raw_is_f64, double* out, int H, int W, int D, double slope, double intercept,
+                      double lo, double hi, void* stream);
+int hs_prep_resample(const void* in, int in_is_f64, float* out, int iD, int iH, int iW, int cd0, int ch0, int cw0, int cD,
+                     int cH, int cW, int oD, int oH, int oW, float sub, float den, void* stream);
+int hs_prep_minmax(const float* x, int64_t n, float* out2, void* stream);
+int hs_prep_foreground_bbox(const float* x, int D, int H, int W, float thresh, int* box6, void* stream);
+int hs_prep_augment(const float* in, float* out, int C, int D, int H, int W, int rot_k, int flip_mask, float scale, float shift,
+                    void* stream);
+
 /* ---- measurement: per-kernel-class timing with HIP events on the launch stream (bench.py roofline leg).
  * hs_prof_enable(1) clears and starts recording, (0) stops.  hs_prof_read synchronises on the recorded events
  * (the only synchronising call in the library) and returns launches, summed duration, and the algorithmic
