@@ -2,7 +2,7 @@
 hbm_bytes_per_launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024   (FETCH_SIZE/WRITE_SIZE are in KiB; FETCH_SIZE x2 on gfx950)."""
 import csv, glob, json, sys, collections
 out, batch = sys.argv[1], int(sys.argv[2])
-CLASS = {"attn_fwd_bf16_kernel": "attn_fwd", "attn_bwd_dkdv_kernel": "attn_bwd_dkdv", "attn_bwd_dq_kernel": "attn_bwd_dq",
+CLASS = {"attn_fwd_fast_kernel": "attn_fwd", "attn_bwd_dkdv2_w4_kernel": "attn_bwd_dkdv", "attn_bwd_dq2_kernel": "attn_bwd_dq",
          "gemm_bf16_kernel<false, false": "gemm_nt", "gemm_bf16_kernel<false, true": "gemm_nn", "gemm_bf16_kernel<true, true": "gemm_tn",
          "layernorm_bwd_kernel": "layernorm_bwd", "layernorm_fwd_kernel": "layernorm_fwd"}
 vals = collections.defaultdict(lambda: collections.defaultdict(list))
