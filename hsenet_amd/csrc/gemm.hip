@@ -73,12 +73,17 @@ __device__ __forceinline__ void gelu_parts(float x, float& cdf, float& pdf_x) {
 // dma_voff(): the per-lane byte offset of piece j at k0 = 0, HS_OOB_OFF for rows/cols outside the matrix.  Full
 // K-tiles then only add a wave-uniform scalar offset (kt * kstep bytes); a partial last K-tile recomputes the
 // offsets with the k bound (dma_voff with K) so the descriptor's range check zero-fills the k tail.
-template <bool TR>
+// image R16 (rows of 128 B read as 16x16x32 operands: lane = row & 15, chunk = 4*step + (lane >> 4)): chunk c of row r sits
+// at c ^ ((r >> 1) & 7).  A ds_read_b128 lane group holds every row of the 16 once, 8 of each parity; the two rows of a
+// 256-B bank row differ in parity, rows of equal parity and equal chunk differ in (r >> 1), and the group's two chunk
+// values differ in bit 0 while their row sets {0-3,12-15} / {4-11} never differ by 1 in (r >> 1): conflict-free.
+__device__ __forceinline__ int swzR16(int r) { return (r >> 1) & 7; }
+template <bool TR, bool M16 = false>
 __device__ __forceinline__ unsigned dma_voff(int j, int dim0, int DIM, int k0, int K, long ld, int wave, int lane) {
     const int piece = j * 8 + wave;
     if (!TR) {
         const int row = piece * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ swzR(row);
+        const int c = (lane & 7) ^ (M16 ? swzR16(row) : swzR(row));
         const int gi = dim0 + row, gk = k0 + c * 8;
         return (gi < DIM && gk < K) ? (unsigned)(((long)gi * ld + gk) * 2) : HS_OOB_OFF;
     } else {
@@ -389,6 +394,96 @@ __device__ __forceinline__ void big_mainloop(f32x16 (&acc)[4][2], char* smem, in
     }
 }
 
+// ---- the same tile on v_mfma_f32_16x16x32_bf16 (NT) ----------------------------------------------------------------
+// Bare MFMA loops on random data run 12.5 % faster on 16x16x32 than on 32x32x16 (the chip holds a higher clock on the small
+// shape; tools/micro/mfma_shapes.cpp).  Wave tile 128x64 = 8 x 4 tiles of 16x16, two 32-deep steps per K-tile, each step in
+// two halves of 16 MFMAs: four phases per K-tile with the same pipeline as big_mainloop (reads one phase ahead, barrier
+// between phases 2 and 3).  Operand images are R16 (see swzR16); A and B fragments are one ds_read_b128 each.
+template <int CNT>
+__device__ __forceinline__ void lds_wait8g(u32x4& a, u32x4& b, u32x4& c, u32x4& d, u32x4& e, u32x4& f, u32x4& g, u32x4& i) {
+    asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(i) : "i"(CNT) : "memory");
+}
+__device__ __forceinline__ void big_mainloop16(f32x4 (&acc)[8][4], char* smem, int row0, int col0, int wave, int lane,
+                                               __amdgpu_buffer_rsrc_t rsA, __amdgpu_buffer_rsrc_t rsB, const unsigned (&va)[4],
+                                               const unsigned (&vb)[4], unsigned ka, unsigned kb, int kt0, int kt1) {
+    constexpr int STAGE = GCfg<true>::STAGE;
+    const int r = lane & 15, q = lane >> 4, f = swzR16(r);
+    unsigned ab0[2], bb0[2];
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+        ab0[st] = lds_off(smem) + (row0 + r) * 128 + (((4 * st + q) ^ f) << 4);
+        bb0[st] = lds_off(smem) + 32768 + (col0 + r) * 128 + (((4 * st + q) ^ f) << 4);
+    }
+    u32x4 fa[2][4], fb[2][4];
+    auto rdA = [&](auto set_tag, auto st_tag, auto hf_tag, unsigned so) {
+        constexpr int S = decltype(set_tag)::value, ST = decltype(st_tag)::value, HF = decltype(hf_tag)::value;
+        const unsigned a = ab0[ST] + so;
+        ldsr128<(HF * 4 + 0) * 2048>(fa[S][0], a); ldsr128<(HF * 4 + 1) * 2048>(fa[S][1], a);
+        ldsr128<(HF * 4 + 2) * 2048>(fa[S][2], a); ldsr128<(HF * 4 + 3) * 2048>(fa[S][3], a);
+    };
+    auto rdB = [&](auto set_tag, auto st_tag, unsigned so) {
+        constexpr int S = decltype(set_tag)::value, ST = decltype(st_tag)::value;
+        const unsigned b = bb0[ST] + so;
+        ldsr128<0>(fb[S][0], b); ldsr128<2048>(fb[S][1], b); ldsr128<4096>(fb[S][2], b); ldsr128<6144>(fb[S][3], b);
+    };
+    auto mma = [&](auto aset_tag, auto bset_tag, auto hf_tag) {
+        constexpr int SA = decltype(aset_tag)::value, SB = decltype(bset_tag)::value, HF = decltype(hf_tag)::value;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[HF * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(fa[SA][i]), as_frag(fb[SB][j]), acc[HF * 4 + i][j], 0, 0, 0);
+    };
+    auto dma = [&](int kt, unsigned so, int q0) {
+        char* sa = smem + so;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            if (q0 == 0) dma_piece(rsA, sa, p, wave, va[p], (unsigned)kt * ka);
+            else dma_piece(rsB, sa + 32768, p, wave, vb[p], (unsigned)kt * kb);
+        }
+    };
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 1> I1;
+    dma(kt0, 0, 0);
+    dma(kt0, 0, 4);
+    if (kt0 + 1 < kt1) {
+        dma(kt0 + 1, STAGE, 0);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    rdA(I0{}, I0{}, I0{}, 0u);
+    rdB(I0{}, I0{}, 0u);
+    unsigned so = 0;
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const bool has1 = kt + 1 < kt1, has2 = kt + 2 < kt1;
+        const unsigned so1 = so ^ (unsigned)STAGE;
+        // phase 0: (step 0, rows 0-63)
+        rdA(I1{}, I0{}, I1{}, so);
+        lds_wait8g<4>(fa[0][0], fa[0][1], fa[0][2], fa[0][3], fb[0][0], fb[0][1], fb[0][2], fb[0][3]);
+        mma(I0{}, I0{}, I0{});
+        if (has1) dma(kt + 1, so1, 4);
+        // phase 1: (step 0, rows 64-127)
+        rdA(I0{}, I1{}, I0{}, so);
+        rdB(I1{}, I1{}, so);
+        lds_wait4<8>(fa[1][0], fa[1][1], fa[1][2], fa[1][3]);
+        mma(I1{}, I0{}, I1{});
+        // phase 2: (step 1, rows 0-63)
+        rdA(I1{}, I1{}, I1{}, so);
+        lds_wait8g<4>(fa[0][0], fa[0][1], fa[0][2], fa[0][3], fb[1][0], fb[1][1], fb[1][2], fb[1][3]);
+        mma(I0{}, I1{}, I0{});
+        lds_wait4<0>(fa[1][0], fa[1][1], fa[1][2], fa[1][3]);       // every read of this stage has landed
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        // phase 3: (step 1, rows 64-127) || first fragments of the next tile
+        if (has1) { rdA(I0{}, I0{}, I0{}, so1); rdB(I0{}, I0{}, so1); }
+        mma(I1{}, I1{}, I1{});
+        if (has2) dma(kt + 2, so, 0);
+        so = so1;
+    }
+}
+
 // diagnostic (dbg == 4): per-phase cycle sums of the epilogue, wave 0 lane 0 of every block (tools/kbench)
 __device__ unsigned long long g_gemm_stamps[8];
 extern "C" void hs_debug_gemm_stamps(unsigned long long* out, int reset) {
@@ -405,8 +500,9 @@ __device__ __forceinline__ void keep4(const f32x4& v) { asm volatile("" ::"v"(v)
 // EF >= 0: the epilogue flags as a compile-time constant (the launcher checked p.flags == EF and the 8-column
 // conditions): the flag tests fold away.  Run-time flags (EF = -1) cost ~1500 cycles of branches per epilogue step --
 // 24k cycles per 256x256 tile, more than half of a K = 768 main loop.
-template <bool ATR, bool BTR, bool BIG, int EF>
+template <bool ATR, bool BTR, bool BIG, int EF, bool M16 = false>
 __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmP p) {
+    static_assert(!M16 || (BIG && !ATR && !BTR), "the 16x16x32 main loop exists for the 256x256 NT tile");
     typedef GCfg<BIG> C;
     __shared__ __attribute__((aligned(16))) char smem[C::SMEM];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -460,13 +556,18 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmP p) {
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    f32x4 acc16[M16 ? 8 : 1][4];                                // 16x16x32 form of the same 128x64 wave tile
+#pragma unroll
+    for (int i = 0; i < (M16 ? 8 : 1); ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc16[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // per-lane DMA offsets at k0 = 0 (rows/cols outside the matrix -> out-of-range offset -> zeros)
     unsigned va[4], vb[C::PB];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) va[j] = dma_voff<ATR>(j, m0, p.M, 0, 64, p.lda, wave, lane);
+    for (int j = 0; j < 4; ++j) va[j] = dma_voff<ATR, M16>(j, m0, p.M, 0, 64, p.lda, wave, lane);
 #pragma unroll
-    for (int j = 0; j < C::PB; ++j) vb[j] = dma_voff<BTR>(j, n0, p.N, 0, 64, p.ldb, wave, lane);
+    for (int j = 0; j < C::PB; ++j) vb[j] = dma_voff<BTR, M16>(j, n0, p.N, 0, 64, p.ldb, wave, lane);
     const unsigned ka = ATR ? (unsigned)(p.lda * 128) : 128u;   // bytes per K-tile step
     const unsigned kb = BTR ? (unsigned)(p.ldb * 128) : 128u;
     const int kt_full = p.K >> 6;                                 // K-tiles [0, kt_full) are complete
@@ -485,7 +586,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmP p) {
         }
     };
     STAMP(0);     // setup
-    if constexpr (BIG) {
+    if constexpr (M16) {
+        big_mainloop16(acc16, smem, row0, col0, wave, lane, rsA, rsB, va, vb, ka, kb, kt0, kt1);
+    } else if constexpr (BIG) {
         big_mainloop<BTR>(acc, smem, row0, col0, wave, lane, rsA, rsB, va, vb, ka, kb, kt0, kt1, p.dbg);
     } else {
     // ring: prefetch distance D = NSTAGE-1 tiles.  At step kt: wait until tile kt has landed (D-1 newer tiles may stay
@@ -528,6 +631,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmP p) {
     if (p.dbg == 1) {
 #pragma unroll
         for (int i = 0; i < C::MB; ++i) { keep_alive(acc[i][0]); keep_alive(acc[i][1]); }
+#pragma unroll
+        for (int i = 0; i < (M16 ? 8 : 1); ++i) { keep4(acc16[i][0]); keep4(acc16[i][1]); keep4(acc16[i][2]); keep4(acc16[i][3]); }
         return;
     }
     float* my = (float*)(smem + wave * (64 * G_EPI_LD * 4));
@@ -536,12 +641,23 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmP p) {
     const bool vec_ok = !(p.N & 3) && !(p.ldc & 3);
 #pragma unroll
     for (int half = 0; half < C::MB / 2; ++half) {
+        if constexpr (M16) {
+            // 16x16 tiles: column = lane & 15, rows 4*(lane >> 4) .. +3 in the 4 registers
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        my[(16 * ii + 4 * (lane >> 4) + r) * G_EPI_LD + 16 * j + (lane & 15)] = acc16[half * 4 + ii][j][r];
+        } else {
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) my[(mb * 32 + acc_row(r, h)) * G_EPI_LD + nb * 32 + c] = acc[half * 2 + mb][nb][r];
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -853,7 +969,13 @@ extern "C" int hs_gemm(const hs_gemm_args* a, int prec, void* stream) {
         if (big) hipLaunchKernelGGL((gemm_bf16_kernel<ATR, BTR, true, EF>), grid, dim3(512), 0, s, p);                \
         else hipLaunchKernelGGL((gemm_bf16_kernel<ATR, BTR, false, EF>), grid, dim3(512), 0, s, p);                   \
     } while (0)
-        if (a->layout == HS_GEMM_NT) {
+        const bool m16 = big && a->layout == HS_GEMM_NT && getenv("HS_GEMM_NO_M16") == nullptr;   // (env: kbench A/B)
+#define HS_LAUNCH_M16(EF) hipLaunchKernelGGL((gemm_bf16_kernel<false, false, true, EF, true>), grid, dim3(512), 0, s, p)
+        if (m16 && col8 && (f == 0 || f == (HS_EPI_BIAS | HS_EPI_RESID) || f == (HS_EPI_BIAS | HS_EPI_GELU | HS_EPI_SAVE_DGELU))) {
+            if (f == 0) HS_LAUNCH_M16(0);
+            else if (f == (HS_EPI_BIAS | HS_EPI_RESID)) HS_LAUNCH_M16(HS_EPI_BIAS | HS_EPI_RESID);
+            else HS_LAUNCH_M16(HS_EPI_BIAS | HS_EPI_GELU | HS_EPI_SAVE_DGELU);
+        } else if (a->layout == HS_GEMM_NT) {
             if (col8 && f == 0) HS_LAUNCH_E(false, false, 0);
             else if (col8 && f == (HS_EPI_BIAS | HS_EPI_RESID)) HS_LAUNCH_E(false, false, HS_EPI_BIAS | HS_EPI_RESID);
             else if (col8 && f == (HS_EPI_BIAS | HS_EPI_GELU | HS_EPI_SAVE_DGELU)) HS_LAUNCH_E(false, false, HS_EPI_BIAS | HS_EPI_GELU | HS_EPI_SAVE_DGELU);
@@ -867,6 +989,7 @@ extern "C" int hs_gemm(const hs_gemm_args* a, int prec, void* stream) {
             else hipLaunchKernelGGL((gemm_bf16_kernel<true, true, false, -1>), grid, dim3(512), 0, s, p);
         }
 #undef HS_LAUNCH_E
+#undef HS_LAUNCH_M16
     } else {
         p.tiles_m = (a->M + 63) / 64;
         dim3 grid(p.tiles_m * ((a->N + 63) / 64), 1, zdim);

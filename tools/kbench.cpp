@@ -217,6 +217,17 @@ int main(int argc, char** argv) {
             int rc = gemm(&a, HS_PREC_BF16, 0);
             if (rc) { printf("%s rc=%d\n", s.name, rc); continue; }
             CK(hipDeviceSynchronize());
+            if (getenv("HS_GEMM_AB") && !tn) {       // A/B: the same GEMM with the 16x16x32 main loop toggled (HS_GEMM_NO_M16) must agree (both accumulate in f32)
+                void* out2 = dev_zero((size_t)s.m * s.n * 2);
+                hs_gemm_args a2 = a; a2.out_bf16 = out2;
+                const bool had = getenv("HS_GEMM_NO_M16") != nullptr;
+                if (had) unsetenv("HS_GEMM_NO_M16"); else setenv("HS_GEMM_NO_M16", "1", 1);
+                gemm(&a2, HS_PREC_BF16, 0); CK(hipDeviceSynchronize());
+                if (had) setenv("HS_GEMM_NO_M16", "1", 1); else unsetenv("HS_GEMM_NO_M16");
+                Cmp c = cmp_bf16(out, out2, (size_t)s.m * s.n);
+                printf("    M16 on/off: rel %.3e maxabs %.3e\n", c.rel, c.maxabs);
+                CK(hipFree(out2));
+            }
             const double us = time_us([&] { gemm(&a, HS_PREC_BF16, 0); }, reps);
             printf("%-16s M=%6d N=%5d K=%6d: %8.1f us  %7.1f TFLOP/s\n", s.name, s.m, s.n, s.k, us, 2.0 * s.m * s.n * s.k / us / 1e6);
             if (getenv("HS_GEMM_DBG") && atoi(getenv("HS_GEMM_DBG")) == 4) {
