@@ -296,6 +296,9 @@ __device__ __forceinline__ void ktile_step(f32x16 (&acc)[GCfg<BIG>::MB][2], cons
     }
 }
 
+// diagnostic cycle sums (dbg == 4), see hs_debug_gemm_stamps
+__device__ unsigned long long g_gemm_stamps[8];
+
 // ---- main loop of the 256x256 tile, software-pipelined by hand -----------------------------------------------------
 // Left to hipcc, the fragment reads of this tile are issued just in time (4 ds_read_b128, lgkmcnt(0), 4 MFMAs, 2 reads,
 // wait, 2 MFMAs, ...): three exposed LDS round trips per 8 MFMAs, ~55 % of the matrix rate.  Here every LDS read is an
@@ -405,8 +408,9 @@ __device__ __forceinline__ void lds_wait8g(u32x4& a, u32x4& b, u32x4& c, u32x4& 
 }
 __device__ __forceinline__ void big_mainloop16(f32x4 (&acc)[8][4], char* smem, int row0, int col0, int wave, int lane,
                                                __amdgpu_buffer_rsrc_t rsA, __amdgpu_buffer_rsrc_t rsB, const unsigned (&va)[4],
-                                               const unsigned (&vb)[4], unsigned ka, unsigned kb, int kt0, int kt1) {
+                                               const unsigned (&vb)[4], unsigned ka, unsigned kb, int kt0, int kt1, int dbg) {
     constexpr int STAGE = GCfg<true>::STAGE;
+    unsigned long long t_sync = 0, t_lds = 0, t_vm = 0;
     const int r = lane & 15, q = lane >> 4, f = swzR16(r);
     unsigned ab0[2], bb0[2];
 #pragma unroll
@@ -473,19 +477,23 @@ __device__ __forceinline__ void big_mainloop16(f32x4 (&acc)[8][4], char* smem, i
         rdA(I1{}, I1{}, I1{}, so);
         lds_wait8g<4>(fa[0][0], fa[0][1], fa[0][2], fa[0][3], fb[1][0], fb[1][1], fb[1][2], fb[1][3]);
         mma(I0{}, I1{}, I0{});
+        unsigned long long t0_ = dbg == 4 ? __builtin_amdgcn_s_memtime() : 0ull;
         lds_wait4<0>(fa[1][0], fa[1][1], fa[1][2], fa[1][3]);       // every read of this stage has landed
+        unsigned long long t1_ = dbg == 4 ? __builtin_amdgcn_s_memtime() : 0ull;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned long long t15_ = dbg == 4 ? __builtin_amdgcn_s_memtime() : 0ull;
         __builtin_amdgcn_s_barrier();
+        if (dbg == 4) { const unsigned long long t2_ = __builtin_amdgcn_s_memtime(); t_lds += t1_ - t0_; t_sync += t2_ - t15_; t_vm += t15_ - t1_; }
         // phase 3: (step 1, rows 64-127) || first fragments of the next tile
         if (has1) { rdA(I0{}, I0{}, I0{}, so1); rdB(I0{}, I0{}, so1); }
         mma(I1{}, I1{}, I1{});
         if (has2) dma(kt + 2, so, 0);
         so = so1;
     }
+    if (dbg == 4 && threadIdx.x == 0) { atomicAdd(&g_gemm_stamps[5], t_sync); atomicAdd(&g_gemm_stamps[6], t_lds); atomicAdd(&g_gemm_stamps[7], t_vm); }
 }
 
 // diagnostic (dbg == 4): per-phase cycle sums of the epilogue, wave 0 lane 0 of every block (tools/kbench)
-__device__ unsigned long long g_gemm_stamps[8];
 extern "C" void hs_debug_gemm_stamps(unsigned long long* out, int reset) {
     if (out) (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gemm_stamps), sizeof(g_gemm_stamps));
     if (reset) { unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_stamps), z, sizeof(z)); }
@@ -587,7 +595,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmP p) {
     };
     STAMP(0);     // setup
     if constexpr (M16) {
-        big_mainloop16(acc16, smem, row0, col0, wave, lane, rsA, rsB, va, vb, ka, kb, kt0, kt1);
+        big_mainloop16(acc16, smem, row0, col0, wave, lane, rsA, rsB, va, vb, ka, kb, kt0, kt1, p.dbg);
     } else if constexpr (BIG) {
         big_mainloop<BTR>(acc, smem, row0, col0, wave, lane, rsA, rsB, va, vb, ka, kb, kt0, kt1, p.dbg);
     } else {

@@ -238,7 +238,7 @@ int main(int argc, char** argv) {
                 gemm(&a, HS_PREC_BF16, 0); CK(hipDeviceSynchronize());
                 st(v, 0);
                 const double nb = (double)((s.m + 255) / 256) * ((s.n + 255) / 256);
-                printf("    cycles/block (wave 0): setup %.0f | main loop %.0f | barrier %.0f | staging %.0f | readback+math+stores %.0f\n", v[0] / nb, v[1] / nb, v[2] / nb, v[3] / nb, v[4] / nb);
+                printf("    cycles/block (wave 0): setup %.0f | main loop %.0f (barrier wait %.0f, vmcnt wait %.0f, last-read wait %.0f) | barrier %.0f | staging %.0f | readback+math+stores %.0f\n", v[0] / nb, v[1] / nb, v[5] / nb, v[7] / nb, v[6] / nb, v[2] / nb, v[3] / nb, v[4] / nb);
             }
             fflush(stdout);
             CK(hipFree(A)); CK(hipFree(Bm)); CK(hipFree(out));
