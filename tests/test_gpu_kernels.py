@@ -404,3 +404,62 @@ def test_clip_head_vs_oracle(dev, n):
     assert rel(lpi, s2.detach() * img2.detach() @ txt2.detach().t()) < 1e-5 and torch.equal(lpt, lpi.t())
     assert rel(tokens.grad, t2.grad) < 1e-4 and rel(txt.grad, txt2.grad) < 1e-4
     assert rel(proj.weight.grad, p2.weight.grad) < 1e-4 and rel(scale.grad, s2.grad) < 1e-4
+
+
+# ---- size-independent properties at the full 256^3 geometry (N = 4097, 12 heads) --------------------------------------
+# the fp64 reference is too slow at this size; these hold for ANY exact softmax attention and are checked on the kernels
+@pytest.mark.gpu
+def test_attn_full_size_properties(dev):
+    from hsenet_amd import functional as Fn, _lib as L
+    B, H, N, D = 2, 12, 4097, 768
+    g = torch.Generator(device="cpu").manual_seed(77)
+    qkv = (torch.randn(B, N, 3 * D, generator=g) * 1.2).to(dev).bfloat16()
+    o, lse = Fn.attn_fwd(qkv, H, L.PREC_BF16)
+    assert torch.isfinite(o.float()).all() and torch.isfinite(lse).all()
+    # (1) the output is a convex combination of the values: per (batch, head, channel) it lies inside the value range
+    v = qkv[..., 2 * D:].float()
+    assert (o.float() <= v.amax(1, keepdim=True) + 1e-2).all() and (o.float() >= v.amin(1, keepdim=True) - 1e-2).all()
+    # (2) permuting the keys/values (same permutation, every batch and head) changes nothing: softmax has no key order
+    perm = torch.randperm(N, generator=g).to(dev)
+    qkv_p = qkv.clone()
+    qkv_p[..., D:] = qkv[:, perm][..., D:]
+    o_p, lse_p = Fn.attn_fwd(qkv_p, H, L.PREC_BF16)
+    assert rel(o_p.float(), o.float()) < 4e-3                    # bf16 P and O rounding, different summation order
+    assert (lse_p - lse).abs().max() < 1e-4
+    # (3) linear in V: o(2 v) = 2 o(v) exactly (a power of two commutes with every rounding)
+    qkv_2 = qkv.clone()
+    qkv_2[..., 2 * D:] = qkv[..., 2 * D:] * 2
+    o_2, _ = Fn.attn_fwd(qkv_2, H, L.PREC_BF16)
+    assert torch.equal(o_2.float(), 2 * o.float())
+    # (4) shifting every score of a row by a constant (k -> k + c q_hat is not constant; use q -> q, k -> k, add to lse only):
+    #     lse rows are >= the largest score and <= largest score + ln N
+    q, k = qkv[..., :D].float().view(B, N, H, 64), qkv[..., D:2 * D].float().view(B, N, H, 64)
+    rows = torch.tensor([0, 1, 2048, 4096], device=dev)
+    s = torch.einsum("bqhd,bkhd->bhqk", q[:, rows], k) * 0.125
+    smax = s.amax(-1)
+    got = lse[:, :, rows]
+    assert (got >= smax - 2e-2).all() and (got <= smax + torch.log(torch.tensor(float(N))) + 2e-2).all()
+
+
+@pytest.mark.gpu
+def test_attn_bwd_full_size_properties(dev):
+    from hsenet_amd import functional as Fn, _lib as L
+    B, H, N, D = 1, 12, 4097, 768
+    g = torch.Generator(device="cpu").manual_seed(78)
+    qkv = (torch.randn(B, N, 3 * D, generator=g) * 1.1).to(dev).bfloat16()
+    d_o = torch.randn(B, N, D, generator=g).to(dev).bfloat16()
+    o, lse = Fn.attn_fwd(qkv, H, L.PREC_BF16)
+    dqkv = Fn.attn_bwd(qkv, o, d_o, lse, H)
+    assert torch.isfinite(dqkv.float()).all()
+    # (1) linear in dO: a power-of-two scale commutes with every rounding in the backward
+    dqkv2 = Fn.attn_bwd(qkv, o, (d_o.float() * 2).bfloat16(), lse, H)
+    assert torch.equal(dqkv2.float(), 2 * dqkv.float())
+    # (2) dV = P^T dO, so the column sums of dV over the keys equal the column sums of dO over the queries (rows of P sum to 1)
+    dv = dqkv[..., 2 * D:].float().sum(1)
+    assert rel(dv, d_o.float().sum(1)) < 1e-2
+    # (3) softmax backward: sum_k dS[q,k] = 0, hence sum_k dK[k,:] = sum_q (sum_k dS[q,k]) ... = 0 only through q; check the
+    #     identity that needs no reference: q . dq = k . dk summed over everything (both equal sum_{q,k} dS S / scale)
+    qf, kf = qkv[..., :D].float(), qkv[..., D:2 * D].float()
+    lhs = (qf * dqkv[..., :D].float()).sum()
+    rhs = (kf * dqkv[..., D:2 * D].float()).sum()
+    assert abs(float(lhs - rhs)) < 2e-2 * max(abs(float(lhs)), abs(float(rhs)), 1.0)
