@@ -1254,6 +1254,235 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv2_w8_kernel(const bf16_t*
     attn_bwd_dkdv2_body<8>(qkv, d_o, ws, dqkv, B, N, H, kmul, dk_mul);
 }
 
+// ------------------------------------------------------------------------------------------------------
+// dK, dV v3 (diagnostic variant, g_hs_dbg[2] == 3): 4 waves x 64 keys, ONE wave per SIMD with the whole register file.
+// Every Q / dO fragment (row reads for S, dP; transposed reads for dV, dK) feeds TWO MFMAs (key blocks 0 and 1), halving
+// the LDS traffic of the 32-keys-per-wave kernel; dK^T, dV^T (128 registers) live in AGPRs and are only touched by asm
+// MFMAs ("+a"); latency is hidden by a software pipeline instead of a second wave:
+//     per 32-query block j:   S/dP(j) MFMAs (16)  ||  exp2 / multiply / pack of block j-1 (VALU)
+//                             dV/dK(j-1) MFMAs (16, asm, accumulate in AGPRs)
+// LDS: 4-stage ring, prefetch distance 2; block j-1's transposed fragments are read from the previous tile's stage after
+// the tile barrier, hence 4 stages.  Stage 3 is zero-filled at start so that the pipeline's phantom block -1
+// (P = exp2(-inf) = 0, dS = 0) multiplies zeros, not LDS garbage.
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void mfma8_acc(f32x16& dv00, f32x16& dv01, f32x16& dk00, f32x16& dk01, f32x16& dv10, f32x16& dv11,
+                                          f32x16& dk10, f32x16& dk11, u32x4 fo0, u32x4 fo1, u32x4 fq0, u32x4 fq1, bf16x8 p0,
+                                          bf16x8 ds0, bf16x8 p1, bf16x8 ds1) {
+    // s_nop 1: the packed operands may have just been written by the VALU (hipcc pads no hazards inside asm)
+    asm volatile("s_nop 1\n\t"
+                 "v_mfma_f32_32x32x16_bf16 %0, %8, %12, %0\n\t"
+                 "v_mfma_f32_32x32x16_bf16 %1, %9, %12, %1\n\t"
+                 "v_mfma_f32_32x32x16_bf16 %2, %10, %13, %2\n\t"
+                 "v_mfma_f32_32x32x16_bf16 %3, %11, %13, %3\n\t"
+                 "v_mfma_f32_32x32x16_bf16 %4, %8, %14, %4\n\t"
+                 "v_mfma_f32_32x32x16_bf16 %5, %9, %14, %5\n\t"
+                 "v_mfma_f32_32x32x16_bf16 %6, %10, %15, %6\n\t"
+                 "v_mfma_f32_32x32x16_bf16 %7, %11, %15, %7"
+                 : "+a"(dv00), "+a"(dv01), "+a"(dk00), "+a"(dk01), "+a"(dv10), "+a"(dv11), "+a"(dk10), "+a"(dk11)
+                 : "v"(fo0), "v"(fo1), "v"(fq0), "v"(fq1), "v"(p0), "v"(ds0), "v"(p1), "v"(ds1));
+}
+__device__ __forceinline__ void acc_settle(f32x16& a, f32x16& b, f32x16& c, f32x16& d, f32x16& e, f32x16& f, f32x16& g, f32x16& i) {
+    // the last asm MFMAs' results must have left the matrix pipe before compiler code reads the accumulators
+    asm volatile("s_nop 15\n\ts_nop 15" : "+a"(a), "+a"(b), "+a"(c), "+a"(d), "+a"(e), "+a"(f), "+a"(g), "+a"(i));
+}
+
+__global__ __launch_bounds__(256, 1) void attn_bwd_dkdv3_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
+                                                               const float* __restrict__ ws, bf16_t* __restrict__ dqkv, int B,
+                                                               int N, int H, float kmul, float dk_mul) {
+    constexpr int STG = 16896, NST = 4;
+    __shared__ __attribute__((aligned(16))) char smem[NST * STG];
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int blk, head, b;
+    attn_block_coords((N + 255) >> 8, H, blk, head, b);
+    const int k0 = blk * 256 + wave * 64;
+    const int Dm = H * 64, D3 = 3 * Dm;
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(qkv + (long)b * N * D3, (size_t)N * D3 * 2);
+    const __amdgpu_buffer_rsrc_t rsd = make_rsrc(d_o + (long)b * N * Dm, (size_t)N * Dm * 2);
+    const __amdgpu_buffer_rsrc_t rst_ = make_rsrc(ws + ((wave & 1) == 0 ? (long)B * H * N : 0) + ((long)b * H + head) * N, (size_t)N * 4);
+    const int nt = (N + 63) >> 6;
+    unsigned vq[2], vd[2], vql[2], vdl[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = (wave * 2 + j) * 8 + (lane >> 3);
+        const int ch = (lane & 7) ^ swzR(row);
+        vq[j] = (unsigned)(((long)row * D3 + head * 64 + ch * 8) * 2);
+        vd[j] = (unsigned)(((long)row * Dm + head * 64 + ch * 8) * 2);
+        const bool in = (nt - 1) * 64 + row < N;
+        vql[j] = in ? vq[j] : HS_OOB_OFF;
+        vdl[j] = in ? vd[j] : HS_OOB_OFF;
+    }
+    const unsigned vs = (unsigned)lane * 4u, vsl = (nt - 1) * 64 + lane < N ? vs : HS_OOB_OFF;
+    const unsigned qtile = (unsigned)(64 * D3 * 2), dtile = (unsigned)(64 * Dm * 2);
+    // branch-free: a tile past the end (t >= nt) is "loaded" with out-of-range offsets (zero fill into a dead stage), and
+    // every wave issues 5 pieces per tile (waves 2, 3 repeat the row-constant pieces of waves 0, 1: same bytes, same place),
+    // so that one vmcnt count serves every wave and the loop body has no control flow around its MFMAs
+    auto issue = [&](int t) {
+        const bool last = t == nt - 1, dead = t >= nt;
+        const unsigned so_q = dead ? 0u : (unsigned)t * qtile, so_d = dead ? 0u : (unsigned)t * dtile, so_s = dead ? 0u : (unsigned)t * 256u;
+        char* sb = smem + (t & 3) * STG;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            char* dst = sb + (wave * 2 + j) * 1024;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (LDS_PTR(void))dst, 16, dead ? HS_OOB_OFF : (last ? vql[j] : vq[j]), so_q, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsd, (LDS_PTR(void))(dst + 8192), 16, dead ? HS_OOB_OFF : (last ? vdl[j] : vd[j]), so_d, 0, 0);
+        }
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rst_, (LDS_PTR(void))(sb + 16384 + (wave & 1) * 256), 4, dead ? HS_OOB_OFF : (last ? vsl : vs), so_s, 0, 0);
+    };
+    {   // zero stage 3 (the phantom tile -1): 16 KiB of images by 256 threads
+        const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *(u32x4*)(smem + 3 * STG + (i * 256 + tid) * 16) = z;
+    }
+    issue(0);
+    issue(1);
+
+    bf16x8 kf[2][4], vf[2][4];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        const int key = k0 + kb * 32 + c;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const unsigned off = key < N ? (unsigned)(((long)key * D3 + Dm + head * 64 + ks * 16 + 8 * h) * 2) : HS_OOB_OFF;
+            kf[kb][ks] = scale_frag(buf_load16(rs, off), kmul);
+            vf[kb][ks] = __builtin_bit_cast(bf16x8, buf_load16(rs, key < N ? off + Dm * 2 : HS_OOB_OFF));
+        }
+    }
+    unsigned rb0[4], tb0[2][2];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) rb0[ks] = lds_addr(smem) + offR(c, 2 * ks + h);
+    {
+        const int g = lane >> 4, p = lane & 3, q = (lane >> 2) & 3;
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+            const int col = db * 32 + 16 * (g & 1) + 4 * p;
+            tb0[db][0] = lds_addr(smem) + offR(4 * h + q, col >> 3) + 8 * (p & 1);
+            tb0[db][1] = lds_addr(smem) + offR(4 * h + q + 8, col >> 3) + 8 * (p & 1);
+        }
+    }
+    const unsigned sb0 = lds_addr(smem) + 16384 + 16 * h;
+
+    f32x16 dv00 = zero16(), dv01 = zero16(), dk00 = zero16(), dk01 = zero16(), dv10 = zero16(), dv11 = zero16(), dk10 = zero16(), dk11 = zero16();
+    f32x16 sp[2] = {splat16(NEG_INF), splat16(NEG_INF)}, dpp[2] = {zero16(), zero16()};
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 1> I1;
+    u32x4 c1[8], ra[4];                     // the NEXT block's row constants and first row fragments, in flight across block seams
+    // first reads of 32-query block QB of the tile at stage offset so: row constants (8) + row fragments of k-steps 0, 1 (4)
+    auto first_reads = [&](auto qb_tag, unsigned so) {
+        constexpr int QB = decltype(qb_tag)::value;
+        const unsigned sbase = sb0 + so;
+        ldsr128<QB * 128>(c1[0], sbase); ldsr128<QB * 128 + 32>(c1[1], sbase); ldsr128<QB * 128 + 64>(c1[2], sbase); ldsr128<QB * 128 + 96>(c1[3], sbase);
+        ldsr128<QB * 128 + 256>(c1[4], sbase); ldsr128<QB * 128 + 288>(c1[5], sbase); ldsr128<QB * 128 + 320>(c1[6], sbase); ldsr128<QB * 128 + 352>(c1[7], sbase);
+        ldsr128<QB * 4096>(ra[0], rb0[0] + so); ldsr128<QB * 4096 + 8192>(ra[1], rb0[0] + so);
+        ldsr128<QB * 4096>(ra[2], rb0[1] + so); ldsr128<QB * 4096 + 8192>(ra[3], rb0[1] + so);
+    };
+    // one 32-query block (its first reads are already in flight); `seam` runs between the two dV/dK MFMA groups of the
+    // previous block and issues the next block's first reads (after the tile barrier when the next block opens a tile)
+    auto qblock = [&](auto qb_tag, unsigned so, auto pq_tag, unsigned po, auto&& seam) {
+        constexpr int QB = decltype(qb_tag)::value, PQ = decltype(pq_tag)::value;
+        u32x4 rb_[4], ta[4], tc[4];
+        f32x16 s[2], dp[2];
+        lds_wait8<4>(c1[0], c1[1], c1[2], c1[3], c1[4], c1[5], c1[6], c1[7]);
+        const f32x16 cl = cat16(c1[0], c1[1], c1[2], c1[3]), cd = cat16(c1[4], c1[5], c1[6], c1[7]);
+        ldsr128<QB * 4096>(rb_[0], rb0[2] + so); ldsr128<QB * 4096 + 8192>(rb_[1], rb0[2] + so);
+        ldsr128<QB * 4096>(rb_[2], rb0[3] + so); ldsr128<QB * 4096 + 8192>(rb_[3], rb0[3] + so);                       // [8]
+        lds_wait4<4>(ra[0], ra[1], ra[2], ra[3]);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ra[0]), kf[kb][0], cl, 0, 0, 0);
+            dp[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ra[1]), vf[kb][0], cd, 0, 0, 0);
+        }
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ra[2]), kf[kb][1], s[kb], 0, 0, 0);
+            dp[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ra[3]), vf[kb][1], dp[kb], 0, 0, 0);
+        }
+        {
+            const unsigned t00 = tb0[0][0] + po, t01 = tb0[0][1] + po, t10 = tb0[1][0] + po, t11 = tb0[1][1] + po;
+            trR_issue<PQ * 4096 + 8192>(ta[0], t00, t01); trR_issue<PQ * 4096 + 8192>(ta[1], t10, t11);
+            trR_issue<PQ * 4096>(ta[2], t00, t01); trR_issue<PQ * 4096>(ta[3], t10, t11);                             // [12]
+        }
+        lds_wait4<8>(rb_[0], rb_[1], rb_[2], rb_[3]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, rb_[2 * i]), kf[kb][2 + i], s[kb], 0, 0, 0);
+                dp[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, rb_[2 * i + 1]), vf[kb][2 + i], dp[kb], 0, 0, 0);
+            }
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __builtin_amdgcn_exp2f(sp[kb][r]);
+                sp[kb][r] = p;
+                dpp[kb][r] = p * dpp[kb][r];
+            }
+        lds_wait4<0>(ta[0], ta[1], ta[2], ta[3]);
+        {
+            const unsigned t00 = tb0[0][0] + po, t01 = tb0[0][1] + po, t10 = tb0[1][0] + po, t11 = tb0[1][1] + po;
+            trR_issue<PQ * 4096 + 2048 + 8192>(tc[0], t00, t01); trR_issue<PQ * 4096 + 2048 + 8192>(tc[1], t10, t11);
+            trR_issue<PQ * 4096 + 2048>(tc[2], t00, t01); trR_issue<PQ * 4096 + 2048>(tc[3], t10, t11);               // [8]
+        }
+        mfma8_acc(dv00, dv01, dk00, dk01, dv10, dv11, dk10, dk11, ta[0], ta[1], ta[2], ta[3], pack8(sp[0], 0), pack8(dpp[0], 0),
+                  pack8(sp[1], 0), pack8(dpp[1], 0));
+        lds_wait4<0>(tc[0], tc[1], tc[2], tc[3]);
+        seam();                                                       // next block's first reads fly under the 8 MFMAs below
+        mfma8_acc(dv00, dv01, dk00, dk01, dv10, dv11, dk10, dk11, tc[0], tc[1], tc[2], tc[3], pack8(sp[0], 1), pack8(dpp[0], 1),
+                  pack8(sp[1], 1), pack8(dpp[1], 1));
+        sp[0] = s[0]; sp[1] = s[1]; dpp[0] = dp[0]; dpp[1] = dp[1];
+    };
+    auto tile_sync = [&](int t) {            // tile t has landed for every wave; then tile t+2's DMA goes into the stage tile t-2 left
+        asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        issue(t + 2);
+    };
+    tile_sync(0);
+    first_reads(I0{}, 0u);
+    for (int t = 0; t < nt; ++t) {
+        const unsigned so = (unsigned)(t & 3) * STG, po = (unsigned)((t + 3) & 3) * STG, no = (unsigned)((t + 1) & 3) * STG;
+        qblock(I0{}, so, I1{}, po, [&] { first_reads(I1{}, so); });          // queries 0..31   || finishes 32..63 of tile t-1
+        // (after the last tile the seam syncs on and reads a dead, zero-filled stage: harmless, and keeps the body branch-free)
+        qblock(I1{}, so, I0{}, so, [&] { tile_sync(t + 1); first_reads(I0{}, no); });   // queries 32..63 || finishes 0..31 of tile t
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_wait8<0>(c1[0], c1[1], c1[2], c1[3], c1[4], c1[5], c1[6], c1[7]);
+    {   // drain: the last block's softmax-side math and its dV / dK products
+        u32x4 ta[4], tc[4];
+        const unsigned po = (unsigned)((nt - 1) & 3) * STG;
+        const unsigned t00 = tb0[0][0] + po, t01 = tb0[0][1] + po, t10 = tb0[1][0] + po, t11 = tb0[1][1] + po;
+        trR_issue<4096 + 8192>(ta[0], t00, t01); trR_issue<4096 + 8192>(ta[1], t10, t11);
+        trR_issue<4096>(ta[2], t00, t01); trR_issue<4096>(ta[3], t10, t11);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __builtin_amdgcn_exp2f(sp[kb][r]);
+                sp[kb][r] = p;
+                dpp[kb][r] = p * dpp[kb][r];
+            }
+        lds_wait4<0>(ta[0], ta[1], ta[2], ta[3]);
+        trR_issue<4096 + 2048 + 8192>(tc[0], t00, t01); trR_issue<4096 + 2048 + 8192>(tc[1], t10, t11);
+        trR_issue<4096 + 2048>(tc[2], t00, t01); trR_issue<4096 + 2048>(tc[3], t10, t11);
+        mfma8_acc(dv00, dv01, dk00, dk01, dv10, dv11, dk10, dk11, ta[0], ta[1], ta[2], ta[3], pack8(sp[0], 0), pack8(dpp[0], 0),
+                  pack8(sp[1], 0), pack8(dpp[1], 0));
+        lds_wait4<0>(tc[0], tc[1], tc[2], tc[3]);
+        mfma8_acc(dv00, dv01, dk00, dk01, dv10, dv11, dk10, dk11, tc[0], tc[1], tc[2], tc[3], pack8(sp[0], 1), pack8(dpp[0], 1),
+                  pack8(sp[1], 1), pack8(dpp[1], 1));
+    }
+    acc_settle(dv00, dv01, dk00, dk01, dv10, dv11, dk10, dk11);
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        const int key = k0 + kb * 32 + c;
+        if (key < N) {
+            bf16_t* row = dqkv + ((long)b * N + key) * D3 + head * 64;
+            f32x16 dk_[2] = {kb ? dk10 : dk00, kb ? dk11 : dk01}, dv_[2] = {kb ? dv10 : dv00, kb ? dv11 : dv01};
+            store_dT(row + Dm, dk_, dk_mul, h);
+            store_dT(row + 2 * Dm, dv_, 1.0f, h);
+        }
+    }
+}
+
 extern "C" int hs_attn_fwd(const void* qkv, void* o, float* lse, int B, int N, int H, int dh, int prec, int flags, void* stream) {
     if (!qkv || !o) return HS_ERR_ARG;
     if (dh != 64 || B < 1 || N < 1 || H < 1) return HS_ERR_SHAPE;
@@ -1322,6 +1551,9 @@ extern "C" int hs_attn_bwd(const void* qkv, const void* o, const void* d_o, cons
         if (vk_ == 9)
             hipLaunchKernelGGL(attn_bwd_dkdv_kernel, grid, dim3(256), 0, s, (const bf16_t*)qkv, (const bf16_t*)d_o, lse, delta_v1,
                                (bf16_t*)dqkv, N, H, c2, dk_mul);
+        else if (vk_ == 3)
+            hipLaunchKernelGGL(attn_bwd_dkdv3_kernel, grid2, dim3(256), 0, s, (const bf16_t*)qkv, (const bf16_t*)d_o, nstat,
+                               (bf16_t*)dqkv, B, N, H, c2, dk_mul);
         else if (vk_ == 1)
             hipLaunchKernelGGL(attn_bwd_dkdv2_w8_kernel, grid2, dim3(512), 0, s, (const bf16_t*)qkv, (const bf16_t*)d_o, nstat,
                                (bf16_t*)dqkv, B, N, H, c2, dk_mul);
