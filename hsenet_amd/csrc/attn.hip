@@ -1286,10 +1286,20 @@ __device__ __forceinline__ void acc_settle(f32x16& a, f32x16& b, f32x16& c, f32x
     asm volatile("s_nop 15\n\ts_nop 15" : "+a"(a), "+a"(b), "+a"(c), "+a"(d), "+a"(e), "+a"(f), "+a"(g), "+a"(i));
 }
 
+// diagnostic cycle sums of dkdv3 (wave 0 of every block): 0 tail of previous block (last 8 MFMAs + seam bookkeeping) | 1 wait row constants |
+// 2 wait row fragments | 3 first 8 S/dP MFMAs + tr issue | 4 last 8 S/dP MFMAs + exp/mul | 5 wait transposed fragments | 6 first dV/dK
+// group | 7 seam (tile barrier + DMA + first reads)
+__device__ unsigned long long g_attn_stamps[8];
+extern "C" void hs_debug_attn_stamps(unsigned long long* out, int reset) {
+    if (out) (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_attn_stamps), sizeof(g_attn_stamps));
+    if (reset) { unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_attn_stamps), z, sizeof(z)); }
+}
 __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv3_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
                                                                const float* __restrict__ ws, bf16_t* __restrict__ dqkv, int B,
-                                                               int N, int H, float kmul, float dk_mul) {
+                                                               int N, int H, float kmul, float dk_mul, int stamp) {
     constexpr int STG = 16896, NST = 4;
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = stamp ? __builtin_amdgcn_s_memtime() : 0ull;
+#define TST(i) do { if (stamp) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tacc[i] += t_ - tprev; tprev = t_; } } while (0)
     __shared__ __attribute__((aligned(16))) char smem[NST * STG];
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1382,11 +1392,14 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv3_kernel(const bf16_t* __
         constexpr int QB = decltype(qb_tag)::value, PQ = decltype(pq_tag)::value;
         u32x4 rb_[4], ta[4], tc[4];
         f32x16 s[2], dp[2];
+        TST(0);
         lds_wait8<4>(c1[0], c1[1], c1[2], c1[3], c1[4], c1[5], c1[6], c1[7]);
+        TST(1);
         const f32x16 cl = cat16(c1[0], c1[1], c1[2], c1[3]), cd = cat16(c1[4], c1[5], c1[6], c1[7]);
         ldsr128<QB * 4096>(rb_[0], rb0[2] + so); ldsr128<QB * 4096 + 8192>(rb_[1], rb0[2] + so);
         ldsr128<QB * 4096>(rb_[2], rb0[3] + so); ldsr128<QB * 4096 + 8192>(rb_[3], rb0[3] + so);                       // [8]
         lds_wait4<4>(ra[0], ra[1], ra[2], ra[3]);
+        TST(2);
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ra[0]), kf[kb][0], cl, 0, 0, 0);
@@ -1402,7 +1415,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv3_kernel(const bf16_t* __
             trR_issue<PQ * 4096 + 8192>(ta[0], t00, t01); trR_issue<PQ * 4096 + 8192>(ta[1], t10, t11);
             trR_issue<PQ * 4096>(ta[2], t00, t01); trR_issue<PQ * 4096>(ta[3], t10, t11);                             // [12]
         }
+        TST(3);
         lds_wait4<8>(rb_[0], rb_[1], rb_[2], rb_[3]);
+        TST(2);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1418,7 +1433,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv3_kernel(const bf16_t* __
                 sp[kb][r] = p;
                 dpp[kb][r] = p * dpp[kb][r];
             }
+        TST(4);
         lds_wait4<0>(ta[0], ta[1], ta[2], ta[3]);
+        TST(5);
         {
             const unsigned t00 = tb0[0][0] + po, t01 = tb0[0][1] + po, t10 = tb0[1][0] + po, t11 = tb0[1][1] + po;
             trR_issue<PQ * 4096 + 2048 + 8192>(tc[0], t00, t01); trR_issue<PQ * 4096 + 2048 + 8192>(tc[1], t10, t11);
@@ -1426,8 +1443,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv3_kernel(const bf16_t* __
         }
         mfma8_acc(dv00, dv01, dk00, dk01, dv10, dv11, dk10, dk11, ta[0], ta[1], ta[2], ta[3], pack8(sp[0], 0), pack8(dpp[0], 0),
                   pack8(sp[1], 0), pack8(dpp[1], 0));
+        TST(6);
         lds_wait4<0>(tc[0], tc[1], tc[2], tc[3]);
-        seam();                                                       // next block's first reads fly under the 8 MFMAs below
+        TST(5);
+        seam();
+        TST(7);                                                       // next block's first reads fly under the 8 MFMAs below
         mfma8_acc(dv00, dv01, dk00, dk01, dv10, dv11, dk10, dk11, tc[0], tc[1], tc[2], tc[3], pack8(sp[0], 1), pack8(dpp[0], 1),
                   pack8(sp[1], 1), pack8(dpp[1], 1));
         sp[0] = s[0]; sp[1] = s[1]; dpp[0] = dp[0]; dpp[1] = dp[1];
@@ -1470,6 +1490,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv3_kernel(const bf16_t* __
         mfma8_acc(dv00, dv01, dk00, dk01, dv10, dv11, dk10, dk11, tc[0], tc[1], tc[2], tc[3], pack8(sp[0], 1), pack8(dpp[0], 1),
                   pack8(sp[1], 1), pack8(dpp[1], 1));
     }
+    if (stamp && tid == 0) { for (int i = 0; i < 8; ++i) atomicAdd(&g_attn_stamps[i], tacc[i]); }
     acc_settle(dv00, dv01, dk00, dk01, dv10, dv11, dk10, dk11);
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
@@ -1553,7 +1574,7 @@ extern "C" int hs_attn_bwd(const void* qkv, const void* o, const void* d_o, cons
                                (bf16_t*)dqkv, N, H, c2, dk_mul);
         else if (vk_ == 3)
             hipLaunchKernelGGL(attn_bwd_dkdv3_kernel, grid2, dim3(256), 0, s, (const bf16_t*)qkv, (const bf16_t*)d_o, nstat,
-                               (bf16_t*)dqkv, B, N, H, c2, dk_mul);
+                               (bf16_t*)dqkv, B, N, H, c2, dk_mul, g_hs_dbg[4]);
         else if (vk_ == 1)
             hipLaunchKernelGGL(attn_bwd_dkdv2_w8_kernel, grid2, dim3(512), 0, s, (const bf16_t*)qkv, (const bf16_t*)d_o, nstat,
                                (bf16_t*)dqkv, B, N, H, c2, dk_mul);
