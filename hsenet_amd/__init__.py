@@ -13,3 +13,4 @@ from .clip import encode_image_cls, image_text_contrastive_learning  # noqa: F40
 __all__ = ["ViT_stage1", "ViT_stage2", "ViT3DTower_dual_encoders", "regular_attention", "build_vision_tower",
            "VisualPacker_3d_phi_v3", "resolution_attention_v3", "build_mm_projector", "encode_images",
            "encode_image_cls", "image_text_contrastive_learning", "set_precision", "get_precision"]
+from .trunk2d import BiomedClipTrunk, slice_features  # noqa: F401,E402

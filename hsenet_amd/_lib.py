@@ -39,7 +39,7 @@ class GemmArgs(C.Structure):
 
 class VitDesc(C.Structure):
     _fields_ = [("B", C.c_int), ("N", C.c_int), ("d", C.c_int), ("H", C.c_int), ("mlp", C.c_int), ("L", C.c_int),
-                ("prec", C.c_int), ("save_for_bwd", C.c_int)]
+                ("prec", C.c_int), ("save_for_bwd", C.c_int), ("ln_eps", C.c_float), ("qkv_bias", C.c_void_p)]
 
 
 _vp, _i, _f, _i64, _sz = C.c_void_p, C.c_int, C.c_float, C.c_int64, C.c_size_t

@@ -16,7 +16,7 @@
 namespace {
 
 struct Layout {
-    size_t wbf, xmid, h1, h2, qkv, o, lse, z, a, stats, fstats, dx, dh, dxb, dob, dz, dqkv, delta, total;
+    size_t wbf, xmid, h1, h2, qkv, o, lse, z, a, stats, fstats, dx, dh, dxb, dob, dz, dqkv, delta, qb, total;
     size_t per_w;  // bf16 weight elements per layer
 };
 
@@ -49,6 +49,7 @@ Layout make_layout(const hs_vit_desc& c) {
     L.dz = take(bwd ? M * mlp * 2 : 0);
     L.dqkv = take(bwd ? M * 3 * d * 2 : 0);
     L.delta = take(bwd ? (size_t)c.B * c.H * c.N * 4 * 2 : 0);   // hs_attn_bwd scratch: -delta | -lse*log2e
+    L.qb = take(c.qkv_bias ? (size_t)3 * d * 4 : 0);               // one layer's qkv bias with its q third pre-scaled
     L.total = off;
     return L;
 }
@@ -59,6 +60,8 @@ int check_desc(const hs_vit_desc* c) {
     if (c->d != c->H * 64) return HS_ERR_SHAPE;  // attention kernels are specialised for head_dim 64
     if ((c->d & 7) || (c->mlp & 7) || c->d > 1024) return HS_ERR_SHAPE;
     if (c->prec != HS_PREC_BF16 && c->prec != HS_PREC_F32) return HS_ERR_ARG;
+    if (c->ln_eps < 0.f) return HS_ERR_ARG;
+    if (c->qkv_bias && c->save_for_bwd) return HS_ERR_ARG;          // the biased projection is forward-only
     return HS_OK;
 }
 
@@ -115,6 +118,7 @@ extern "C" int hs_vit_blocks_fwd(const hs_vit_desc* desc, const float* x0, const
     const size_t Md = (size_t)M * d;
     const bool bf = c.prec == HS_PREC_BF16;
     const size_t es = bf ? 2 : 4;
+    const float eps = c.ln_eps > 0.f ? c.ln_eps : 1e-5f;
 
     if (bf) {
         for (int l = 0; l < c.L; ++l) {
@@ -147,20 +151,30 @@ extern "C" int hs_vit_blocks_fwd(const hs_vit_desc* desc, const float* x0, const
         } else {
             wqkv = p[P_WQKV]; wo = p[P_WO]; w1 = p[P_W1]; w2 = p[P_W2];
         }
-        RC(hs_layernorm_fwd(xin, nullptr, p[P_N1W], p[P_N1B], bf ? nullptr : (float*)h1, bf ? h1 : nullptr, st, st + M, M, d, 1e-5f, stream));
+        RC(hs_layernorm_fwd(xin, nullptr, p[P_N1W], p[P_N1B], bf ? nullptr : (float*)h1, bf ? h1 : nullptr, st, st + M, M, d, eps, stream));
         // bf16: the q third leaves the projection already multiplied by dh^-0.5 * log2(e) (one rounding), which is what the
         // attention kernels' exp2-based softmax consumes (HS_ATTN_Q_PRESCALED); the f32 parity path keeps raw q
-        RC(gemm(c.prec, HS_GEMM_NT, h1, wqkv, M, 3 * d, d, d, d, bf ? nullptr : (float*)qkv, bf ? qkv : nullptr, 3 * d, nullptr, nullptr,
-                nullptr, nullptr, 0, 1, stream, nullptr, bf ? d : 0, kQScale));
+        const float* qbias = nullptr;
+        if (c.qkv_bias) {           // timm-style biased projection: the pre-scale of the q third applies to its bias too
+            qbias = c.qkv_bias[l];
+            if (bf) {
+                float* qb = (float*)(w + L.qb);
+                RC(hs_scale(qbias, qb, kQScale, d, stream));
+                RC(hs_scale(qbias + d, qb + d, 1.0f, (int64_t)2 * d, stream));
+                qbias = qb;
+            }
+        }
+        RC(gemm(c.prec, HS_GEMM_NT, h1, wqkv, M, 3 * d, d, d, d, bf ? nullptr : (float*)qkv, bf ? qkv : nullptr, 3 * d, qbias, nullptr,
+                nullptr, nullptr, qbias ? HS_EPI_BIAS : 0, 1, stream, nullptr, bf ? d : 0, kQScale));
         RC(hs_attn_fwd(qkv, o, lse, c.B, c.N, c.H, 64, c.prec, bf ? HS_ATTN_Q_PRESCALED : 0, stream));
         RC(gemm(c.prec, HS_GEMM_NT, o, wo, M, d, d, d, d, xmid, nullptr, d, p[P_BO], xin, nullptr, nullptr, HS_EPI_BIAS | HS_EPI_RESID, 1, stream));
-        RC(hs_layernorm_fwd(xmid, nullptr, p[P_N2W], p[P_N2B], bf ? nullptr : (float*)h2, bf ? h2 : nullptr, st + 2 * M, st + 3 * M, M, d, 1e-5f, stream));
+        RC(hs_layernorm_fwd(xmid, nullptr, p[P_N2W], p[P_N2B], bf ? nullptr : (float*)h2, bf ? h2 : nullptr, st + 2 * M, st + 3 * M, M, d, eps, stream));
         RC(gemm(c.prec, HS_GEMM_NT, h2, w1, M, mlp, d, d, d, bf ? nullptr : (float*)a, bf ? a : nullptr, mlp, p[P_B1], nullptr, nullptr,
                 c.save_for_bwd ? z : nullptr, HS_EPI_BIAS | HS_EPI_GELU | HS_EPI_SAVE_DGELU, 1, stream));
         RC(gemm(c.prec, HS_GEMM_NT, a, w2, M, d, mlp, mlp, mlp, xout, nullptr, d, p[P_B2], xmid, nullptr, nullptr, HS_EPI_BIAS | HS_EPI_RESID, 1, stream));
     }
     float* fs = (float*)(w + L.fstats);
-    RC(hs_layernorm_fwd(hidden + (size_t)(c.L - 1) * Md, nullptr, np[0], np[1], y, nullptr, fs, fs + M, M, d, 1e-5f, stream));
+    RC(hs_layernorm_fwd(hidden + (size_t)(c.L - 1) * Md, nullptr, np[0], np[1], y, nullptr, fs, fs + M, M, d, eps, stream));
     return HS_OK;
 }
 
@@ -169,7 +183,7 @@ extern "C" int hs_vit_blocks_bwd(const hs_vit_desc* desc, const float* x0, const
                                  size_t ws_bytes, int l_hi, int l_lo, void* stream) {
     RC(check_desc(desc));
     const hs_vit_desc& c = *desc;
-    if (c.prec != HS_PREC_BF16 || !c.save_for_bwd) return HS_ERR_ARG;
+    if (c.prec != HS_PREC_BF16 || !c.save_for_bwd || c.qkv_bias) return HS_ERR_ARG;
     if (!x0 || !lp || !np || !lg || !hidden || !ws) return HS_ERR_ARG;
     if (l_lo < 0 || l_hi > c.L || l_lo >= l_hi) return HS_ERR_SHAPE;
     if (l_hi == c.L && (!dy || !ng)) return HS_ERR_ARG;

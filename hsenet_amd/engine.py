@@ -73,7 +73,7 @@ class FlatEncoder:
         self.Np, self.Pd, self.d = pe.n_patches, pe.patch_dim, model.hidden_size
         self.N = self.Np + 1
         self.Ln = len(model.blocks)
-        self.desc = L.VitDesc(batch, self.N, self.d, model.num_heads, model.mlp_dim, self.Ln, L.PREC_BF16, 1)
+        self.desc = L.VitDesc(batch, self.N, self.d, model.num_heads, model.mlp_dim, self.Ln, L.PREC_BF16, 1, 0.0, None)
         nbytes = L.load().hs_vit_workspace_bytes(C.byref(self.desc))
         if nbytes == 0:
             raise L.HsError("unsupported encoder geometry")

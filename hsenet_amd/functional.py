@@ -454,6 +454,34 @@ def _ptr_array(tensors: Sequence[torch.Tensor]):
     return arr
 
 
+def blocks_forward_inference(x0, H, mlp, prec, params, ln_eps=0.0, qkv_bias=None):
+    """Forward-only run of the fused block stack with the options the 2-D trunk needs (LayerNorm eps, biased qkv
+    projection: hs_vit_desc.ln_eps / .qkv_bias).  params: L*11 block tensors in the driver's order + norm.weight, norm.bias."""
+    x0 = _f32(x0).contiguous()
+    params = [p.contiguous() for p in params]
+    _need(x0, *params)
+    B, N, d = x0.shape
+    Ln = (len(params) - 2) // 11
+    qb = None
+    if qkv_bias is not None:
+        qkv_bias = [b.contiguous() for b in qkv_bias]
+        _need(*qkv_bias)
+        if len(qkv_bias) != Ln:
+            raise L.HsError("one qkv bias per layer expected")
+        qb = _ptr_array(qkv_bias)
+    desc = L.VitDesc(B, N, d, H, mlp, Ln, prec, 0, float(ln_eps), C.cast(qb, C.c_void_p) if qb is not None else None)
+    nbytes = L.load().hs_vit_workspace_bytes(C.byref(desc))
+    if nbytes == 0:
+        raise L.HsError(f"unsupported encoder geometry B={B} N={N} d={d} H={H} mlp={mlp} L={Ln}")
+    ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=x0.device)
+    off = (-ws.data_ptr()) % 256
+    y = torch.empty_like(x0)
+    hidden = torch.empty(Ln, B, N, d, dtype=torch.float32, device=x0.device)
+    L.call("hs_vit_blocks_fwd", C.byref(desc), x0.data_ptr(), _ptr_array(params[:-2]), _ptr_array(params[-2:]), y.data_ptr(),
+           hidden.data_ptr(), ws.data_ptr() + off, nbytes, _s())
+    return y
+
+
 class BlocksFn(torch.autograd.Function):
     """The 12 x TransformerBlock hot loop + final norm (vit.py:464-467 / 352-355) as ONE fused enqueue.
 
@@ -472,7 +500,7 @@ class BlocksFn(torch.autograd.Function):
         # ctx.needs_input_grad ignores torch.no_grad())
         if need_grad and prec != L.PREC_BF16:
             raise L.HsError("the fused block stack differentiates in bf16 mode only (f32 is the forward parity mode)")
-        desc = L.VitDesc(B, N, d, H, mlp, Ln, prec, int(need_grad))
+        desc = L.VitDesc(B, N, d, H, mlp, Ln, prec, int(need_grad), 0.0, None)
         nbytes = L.load().hs_vit_workspace_bytes(C.byref(desc))
         if nbytes == 0:
             raise L.HsError(f"unsupported encoder geometry B={B} N={N} d={d} H={H} mlp={mlp} L={Ln}")

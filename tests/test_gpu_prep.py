@@ -75,3 +75,34 @@ def test_draws_follow_the_reference_probabilities():
     assert 0.45 < np.mean([d[0] > 0 for d in draws]) < 0.55
     assert 0.07 < np.mean([bool(d[1] & 1) for d in draws]) < 0.13
     assert all(0.9 <= d[2] <= 1.1 and -0.1 <= d[3] <= 0.1 for d in draws)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec,tol", [("f32", 2e-5), ("bf16", 2e-2)])
+def test_trunk2d_and_slice_features(dev, prec, tol):
+    """N4: the 2-D branch (resize to 32x224x224 + frozen BiomedCLIP-shaped ViT trunk) against its CPU restatement."""
+    import hsenet_amd as H
+    from oracle import trunk2d_cpu as T
+    torch.manual_seed(3)
+    ref = T.Trunk(depth=2).eval()
+    with torch.no_grad():
+        for p in ref.parameters():
+            p.copy_(torch.randn_like(p) * 0.03)
+        ref.norm.weight.add_(1.0)
+        for b in ref.blocks:
+            b.norm1.weight.add_(1.0)
+            b.norm2.weight.add_(1.0)
+    mine = H.BiomedClipTrunk(depth=2)
+    mine.load_state_dict(ref.state_dict())
+    mine = mine.to(dev)
+    vol = torch.rand(1, 1, 20, 72, 64)
+    with torch.no_grad():
+        want = T.slice_features(vol, ref, slices=4)
+    H.set_precision(prec)
+    try:
+        got = H.slice_features(vol.to(dev), mine, slices=4).cpu()
+    finally:
+        H.set_precision("bf16")
+    assert got.shape == want.shape == (1, 4, 768)
+    err = float((got - want).norm() / want.norm())
+    assert err < tol, err

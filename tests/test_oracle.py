@@ -176,3 +176,54 @@ def test_clip_loss_head():
     lab = torch.arange(4)
     ref = 0.5 * (torch.nn.functional.cross_entropy(logits, lab) + torch.nn.functional.cross_entropy(logits.t(), lab))
     assert abs(float(loss - ref)) < 1e-6
+
+
+def test_trunk2d_restatement_matches_huggingface_vit():
+    """N4: the timm-ViT restatement (oracle/trunk2d_cpu.py) against transformers' ViTModel, weights mapped across."""
+    from transformers import ViTConfig, ViTModel
+    from oracle import trunk2d_cpu as T
+    torch.manual_seed(0)
+    cfg = ViTConfig(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=512, image_size=64, patch_size=16,
+                    num_channels=3, qkv_bias=True, layer_norm_eps=1e-6, hidden_act="gelu", hidden_dropout_prob=0.0,
+                    attention_probs_dropout_prob=0.0)
+    hf = ViTModel(cfg, add_pooling_layer=False).eval()
+    mine = T.Trunk(img_size=64, patch_size=16, embed_dim=128, depth=2, num_heads=2).eval()
+    with torch.no_grad():
+        for p in mine.parameters():
+            p.copy_(torch.randn_like(p) * 0.05)
+        mine.norm.weight.add_(1.0)
+        for b in mine.blocks:
+            b.norm1.weight.add_(1.0)
+            b.norm2.weight.add_(1.0)
+        e = hf.embeddings
+        e.cls_token.copy_(mine.cls_token)
+        e.position_embeddings.copy_(mine.pos_embed)
+        e.patch_embeddings.projection.weight.copy_(mine.patch_embed.proj.weight)
+        e.patch_embeddings.projection.bias.copy_(mine.patch_embed.proj.bias)
+        d = 128
+        for lb, hb in zip(mine.blocks, hf.layers):          # transformers 5.x layout: layers.i.attention.{q,k,v,o}_proj, mlp.fc1/fc2
+            hb.layernorm_before.load_state_dict(lb.norm1.state_dict())
+            hb.layernorm_after.load_state_dict(lb.norm2.state_dict())
+            att = hb.attention
+            for i, lin in enumerate((att.q_proj, att.k_proj, att.v_proj)):
+                lin.weight.copy_(lb.attn.qkv.weight[i * d:(i + 1) * d])
+                lin.bias.copy_(lb.attn.qkv.bias[i * d:(i + 1) * d])
+            att.o_proj.load_state_dict(lb.attn.proj.state_dict())
+            hb.mlp.fc1.load_state_dict(lb.mlp.fc1.state_dict())
+            hb.mlp.fc2.load_state_dict(lb.mlp.fc2.state_dict())
+        hf.layernorm.load_state_dict(mine.norm.state_dict())
+        x = torch.randn(3, 3, 64, 64)
+        ref = hf(pixel_values=x).last_hidden_state[:, 0]
+        got = mine(x)
+    assert (got - ref).abs().max() < 2e-5, (got - ref).abs().max()
+
+
+def test_trunk2d_state_dict_is_timm_ordered():
+    import hsenet_amd as H
+    keys = list(H.BiomedClipTrunk(depth=1).state_dict())
+    assert keys == ["cls_token", "pos_embed", "patch_embed.proj.weight", "patch_embed.proj.bias", "blocks.0.norm1.weight",
+                    "blocks.0.norm1.bias", "blocks.0.attn.qkv.weight", "blocks.0.attn.qkv.bias", "blocks.0.attn.proj.weight",
+                    "blocks.0.attn.proj.bias", "blocks.0.norm2.weight", "blocks.0.norm2.bias", "blocks.0.mlp.fc1.weight",
+                    "blocks.0.mlp.fc1.bias", "blocks.0.mlp.fc2.weight", "blocks.0.mlp.fc2.bias", "norm.weight", "norm.bias"]
+    from oracle import trunk2d_cpu as T
+    assert list(T.Trunk(depth=1).state_dict()) == keys
