@@ -42,7 +42,7 @@ class VitDesc(C.Structure):
                 ("prec", C.c_int), ("save_for_bwd", C.c_int), ("ln_eps", C.c_float), ("qkv_bias", C.c_void_p)]
 
 
-_vp, _i, _f, _i64, _sz = C.c_void_p, C.c_int, C.c_float, C.c_int64, C.c_size_t
+_vp, _i, _f, _i64, _sz, _u64 = C.c_void_p, C.c_int, C.c_float, C.c_int64, C.c_size_t, C.c_uint64
 
 # name -> argtypes (restype int unless listed in _RESTYPE); mirrors include/hsenet_hip.h one to one
 SIGNATURES = {
@@ -56,14 +56,15 @@ SIGNATURES = {
     "hs_layernorm_bwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "hs_attn_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "hs_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
-    "hs_cross_attn_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
-    "hs_cross_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "hs_cross_attn_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _u64, _u64, _vp],
+    "hs_cross_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _u64, _u64, _vp],
+    "hs_dropout": [_vp, _vp, _i64, _f, _u64, _u64, _vp],
     "hs_rowdot_sigmoid_fwd": [_vp, _vp, _vp, _vp, _i, _i, _vp],
     "hs_rowdot_sigmoid_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "hs_pool3d_fwd": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "hs_pool3d_bwd": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
-    "hs_window_attn_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
-    "hs_window_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "hs_window_attn_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _u64, _u64, _vp],
+    "hs_window_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _u64, _u64, _vp],
     "hs_colsum": [_vp, _i, _vp, _i, _i, _i64, _vp],
     "hs_cast_bf16": [_vp, _vp, _i64, _vp],
     "hs_cast_f32": [_vp, _vp, _i64, _vp],

@@ -105,6 +105,27 @@ __device__ __forceinline__ void lds_wait6(u32x4& a, u32x4& b, u32x4& c, u32x4& d
     asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f) : "i"(CNT) : "memory");
 }
 
+// ---- Philox4x32-10 (counter-based RNG for train-mode dropout: the mask is a pure function of (seed, element index)) ----
+struct Philox4 { unsigned x, y, z, w; };
+__device__ __forceinline__ Philox4 philox4x32_10(unsigned long long seed, unsigned long long ctr) {
+    unsigned c0 = (unsigned)ctr, c1 = (unsigned)(ctr >> 32), c2 = 0u, c3 = 0u;
+    unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return Philox4{c0, c1, c2, c3};
+}
+// keep-scale of element i under dropout probability p: 1/(1-p) with probability 1-p, else 0
+__device__ __forceinline__ float dropout_scale(unsigned long long seed, unsigned long long offset, unsigned long long i, float p) {
+    const Philox4 r = philox4x32_10(seed, offset + (i >> 2));
+    const unsigned u = (i & 3) == 0 ? r.x : (i & 3) == 1 ? r.y : (i & 3) == 2 ? r.z : r.w;
+    return (float)(u >> 8) * (1.0f / 16777216.0f) >= p ? 1.0f / (1.0f - p) : 0.0f;
+}
+
 // per-kernel-class profiling (prof.hip); ids mirror hs_prof_name()
 enum { HS_PROF_GEMM_NT = 0, HS_PROF_GEMM_NN, HS_PROF_GEMM_TN, HS_PROF_ATTN_FWD, HS_PROF_ATTN_DELTA, HS_PROF_ATTN_DKDV,
        HS_PROF_ATTN_DQ, HS_PROF_LN_FWD, HS_PROF_LN_BWD, HS_PROF_COLSUM, HS_PROF_CAST, HS_PROF_PATCHIFY, HS_PROF_OTHER,

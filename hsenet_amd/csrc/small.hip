@@ -205,24 +205,58 @@ static int launch_f32_gemm(int layout, const float* A, const float* Bm, float* C
     return hs_gemm(&g, HS_PREC_F32, stream);
 }
 
+// y[i] = x[i] * keep(i) / (1 - p): elementwise dropout whose mask is a pure function of (seed, offset, i) -- the backward pass
+// applies the same call to the gradient (in place allowed)
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, long n, float p,
+                                                      unsigned long long seed, unsigned long long offset) {
+    const long g = (long)blockIdx.x * 256 + threadIdx.x;       // one Philox call = 4 consecutive elements
+    if (g * 4 >= n) return;
+    const Philox4 r = philox4x32_10(seed, offset + (unsigned long long)g);
+    const unsigned u[4] = {r.x, r.y, r.z, r.w};
+    const float inv = 1.0f / (1.0f - p);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (g * 4 + e < n) y[g * 4 + e] = (float)(u[e] >> 8) * (1.0f / 16777216.0f) >= p ? x[g * 4 + e] * inv : 0.f;
+}
+extern "C" int hs_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, uint64_t offset, void* stream) {
+    if (!x || !y) return HS_ERR_ARG;
+    if (n < 1) return HS_ERR_SHAPE;
+    if (!(p >= 0.f && p < 1.f)) return HS_ERR_ARG;
+    ProfScope prof(HS_PROF_OTHER, stream, 0, (double)n * 8);
+    hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)(((n + 3) / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, (long)n, p,
+                       (unsigned long long)seed, (unsigned long long)offset);
+    HS_CHECK_LAUNCH();
+    return HS_OK;
+}
+
 // K5 core as exact-f32 MFMA GEMMs + a 32-wide row softmax (tiny FLOPs: 4*nq*nk*d per volume).
-extern "C" int hs_cross_attn_fwd(const float* q, const float* k, const float* v, float* out, float* p, int B, int nq, int nk,
-                                 int d, void* stream) {
+// pd (optional, with drop_p > 0): receives dropout(P) -- the map the reference returns in train mode -- and out = pd V.
+extern "C" int hs_cross_attn_fwd(const float* q, const float* k, const float* v, float* out, float* p, float* pd, int B, int nq,
+                                 int nk, int d, float drop_p, uint64_t seed, uint64_t offset, void* stream) {
     if (!q || !k || !v || !out || !p) return HS_ERR_ARG;
     if (B < 1 || nq < 1 || nk < 4 || nk > 64 || (nk & 3) || (d & 3)) return HS_ERR_SHAPE;
+    if (!(drop_p >= 0.f && drop_p < 1.f) || (drop_p > 0.f && !pd)) return HS_ERR_ARG;
     const float alpha = 1.0f / sqrtf((float)d);
     int rc = launch_f32_gemm(HS_GEMM_NT, q, k, p, nq, nk, d, d, d, nk, B, (long)nq * d, (long)nk * d, (long)nq * nk, alpha, 0, 1, stream);
     if (rc) return rc;
     const long rows = (long)B * nq;
     hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p, rows, nk);
     HS_CHECK_LAUNCH();
+    const float* pu = p;
+    if (drop_p > 0.f) {
+        if ((rc = hs_dropout(p, pd, rows * nk, drop_p, seed, offset, stream))) return rc;
+        pu = pd;
+    }
     // out = P V : A = P [nq][nk], B = V stored [K=nk][N=d]
-    return launch_f32_gemm(HS_GEMM_NN, p, v, out, nq, d, nk, nk, d, d, B, (long)nq * nk, (long)nk * d, (long)nq * d, 1.0f, 0, 1, stream);
+    return launch_f32_gemm(HS_GEMM_NN, pu, v, out, nq, d, nk, nk, d, d, B, (long)nq * nk, (long)nk * d, (long)nq * d, 1.0f, 0, 1, stream);
 }
 // ws: fp32 scratch [B][nq][nk].  dq written; dk, dv written (not accumulated).
-extern "C" int hs_cross_attn_bwd(const float* q, const float* k, const float* v, const float* p, const float* dout, float* dq,
-                                 float* dk, float* dv, float* ws, int B, int nq, int nk, int d, void* stream) {
+// pd / drop_p / seed / offset: as given to the forward call (pd = NULL, drop_p = 0 in eval mode)
+extern "C" int hs_cross_attn_bwd(const float* q, const float* k, const float* v, const float* p, const float* pd, const float* dout,
+                                 float* dq, float* dk, float* dv, float* ws, int B, int nq, int nk, int d, float drop_p, uint64_t seed,
+                                 uint64_t offset, void* stream) {
     if (!q || !k || !v || !p || !dout || !dq || !dk || !dv || !ws) return HS_ERR_ARG;
+    if (!(drop_p >= 0.f && drop_p < 1.f) || (drop_p > 0.f && !pd)) return HS_ERR_ARG;
     if (B < 1 || nq < 4 || (nq & 3) || nk < 4 || nk > 64 || (nk & 3) || (d & 3)) return HS_ERR_SHAPE;
     const float alpha = 1.0f / sqrtf((float)d);
     const long sq = (long)nq * d, sk = (long)nk * d, sp = (long)nq * nk;
@@ -230,12 +264,13 @@ extern "C" int hs_cross_attn_bwd(const float* q, const float* k, const float* v,
     int rc = launch_f32_gemm(HS_GEMM_NT, dout, v, ws, nq, nk, d, d, d, nk, B, sq, sk, sp, 1.0f, 0, 1, stream);
     if (rc) return rc;
     const long rows = (long)B * nq;
+    if (drop_p > 0.f && (rc = hs_dropout(ws, ws, rows * nk, drop_p, seed, offset, stream))) return rc;     // dP = mask(dP_dropped)
     hipLaunchKernelGGL(softmax_rows_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p, ws, rows, nk);
     HS_CHECK_LAUNCH();
     // dQ = dS K * alpha ;  dK = dS^T Q * alpha ; dV = P^T dOut
     if ((rc = launch_f32_gemm(HS_GEMM_NN, ws, k, dq, nq, d, nk, nk, d, d, B, sp, sk, sq, alpha, 0, 1, stream))) return rc;
     if ((rc = launch_f32_gemm(HS_GEMM_TN, ws, q, dk, nk, d, nq, nk, d, d, B, sp, sq, sk, alpha, 0, 1, stream))) return rc;
-    return launch_f32_gemm(HS_GEMM_TN, p, dout, dv, nk, d, nq, nk, d, d, B, sp, sq, sk, 1.0f, 0, 1, stream);
+    return launch_f32_gemm(HS_GEMM_TN, drop_p > 0.f ? pd : p, dout, dv, nk, d, nq, nk, d, d, B, sp, sq, sk, 1.0f, 0, 1, stream);
 }
 
 // patch_score_proj + Sigmoid (vit.py:338-339): one wave per row
@@ -371,7 +406,8 @@ __global__ __launch_bounds__(256) void pool3d_bwd_kernel(const float* __restrict
 template <bool BWD>
 __global__ __launch_bounds__(256) void window_attn_kernel(const float* __restrict__ q, const float* __restrict__ kv,
                                                           const float* __restrict__ dout, float* __restrict__ out,
-                                                          float* __restrict__ dq, float* __restrict__ dkv, int B, Win w, int d) {
+                                                          float* __restrict__ dq, float* __restrict__ dkv, int B, Win w, int d,
+                                                          float drop_p, unsigned long long seed, unsigned long long offset) {
     const int lane = threadIdx.x & 63;
     const long bc = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (bc >= (long)B * w.cells) return;
@@ -413,6 +449,9 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const float* __restric
     const float m = wave_max(sc);
     const float e = lane < w.nwin ? __expf(sc - m) : 0.f;
     const float p = e / wave_sum(e);
+    // train mode: dropout on the attention probabilities (spatial_pooling_projector.py:13-14); lane j = child j
+    const float mk = drop_p > 0.f ? dropout_scale(seed, offset, (unsigned long long)bc * 64 + lane, drop_p) : 1.0f;
+    if (BWD) dpl *= mk;                 // dP = dP_dropped * mask / (1 - p)
     if (!BWD) {
         f32x4 acc[WA_MAXCH];
 #pragma unroll
@@ -420,7 +459,7 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const float* __restric
 #pragma unroll
             for (int e2 = 0; e2 < 4; ++e2) acc[i][e2] = 0.f;
         for (int j = 0; j < w.nwin; ++j) {
-            const float pj = __shfl(p, j, 64);
+            const float pj = __shfl(p * mk, j, 64);
             const float* vr = kvb + (long)child_token(w, cell, j) * 2 * d + d;
 #pragma unroll
             for (int i = 0; i < WA_MAXCH; ++i) {
@@ -443,7 +482,7 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const float* __restric
             for (int e2 = 0; e2 < 4; ++e2) acc[i][e2] = 0.f;
         float* dkvb = dkv + (long)b * w.tokens * 2 * d;
         for (int j = 0; j < w.nwin; ++j) {
-            const float dsj = __shfl(ds, j, 64) * alpha, pj = __shfl(p, j, 64);
+            const float dsj = __shfl(ds, j, 64) * alpha, pj = __shfl(p * mk, j, 64);
             const long tok = child_token(w, cell, j);
             const float* kr = kvb + tok * 2 * d;
             float* dkr = dkvb + tok * 2 * d;
@@ -493,29 +532,33 @@ extern "C" int hs_pool3d_bwd(const float* dlr, float* dhr, int B, int gd, int gh
     return HS_OK;
 }
 extern "C" int hs_window_attn_fwd(const float* q, const float* kv, float* out, int B, int gd, int gh, int gw, int kd, int kh,
-                                  int kw, int d, void* stream) {
+                                  int kw, int d, float drop_p, uint64_t seed, uint64_t offset, void* stream) {
     if (!q || !kv || !out) return HS_ERR_ARG;
+    if (!(drop_p >= 0.f && drop_p < 1.f)) return HS_ERR_ARG;
     int rc = win_check(B, gd, gh, gw, kd, kh, kw, d);
     if (rc) return rc;
     if (d > WA_MAXCH * 256) return HS_ERR_SHAPE;
     const Win w = make_win(gd, gh, gw, kd, kh, kw);
     const long waves = (long)B * w.cells;
     hipLaunchKernelGGL(window_attn_kernel<false>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, q, kv,
-                       (const float*)nullptr, out, (float*)nullptr, (float*)nullptr, B, w, d);
+                       (const float*)nullptr, out, (float*)nullptr, (float*)nullptr, B, w, d, drop_p, (unsigned long long)seed,
+                       (unsigned long long)offset);
     HS_CHECK_LAUNCH();
     return HS_OK;
 }
 // dkv rows of tokens outside every window (grid not divisible by the kernel) are NOT written: caller zeroes dkv then.
 extern "C" int hs_window_attn_bwd(const float* q, const float* kv, const float* dout, float* dq, float* dkv, int B, int gd,
-                                  int gh, int gw, int kd, int kh, int kw, int d, void* stream) {
+                                  int gh, int gw, int kd, int kh, int kw, int d, float drop_p, uint64_t seed, uint64_t offset,
+                                  void* stream) {
     if (!q || !kv || !dout || !dq || !dkv) return HS_ERR_ARG;
+    if (!(drop_p >= 0.f && drop_p < 1.f)) return HS_ERR_ARG;
     int rc = win_check(B, gd, gh, gw, kd, kh, kw, d);
     if (rc) return rc;
     if (d > WA_MAXCH * 256) return HS_ERR_SHAPE;
     const Win w = make_win(gd, gh, gw, kd, kh, kw);
     const long waves = (long)B * w.cells;
     hipLaunchKernelGGL(window_attn_kernel<true>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, q, kv, dout,
-                       (float*)nullptr, dq, dkv, B, w, d);
+                       (float*)nullptr, dq, dkv, B, w, d, drop_p, (unsigned long long)seed, (unsigned long long)offset);
     HS_CHECK_LAUNCH();
     return HS_OK;
 }

@@ -131,8 +131,15 @@ class regular_attention(nn.Module):
         q = Fn.LinearFn.apply(Query, self.Wq.weight, self.Wq.bias, prec)
         k = Fn.LinearFn.apply(Key, self.Wk.weight, self.Wk.bias, prec)
         v = Fn.LinearFn.apply(Value, self.Wv.weight, self.Wv.bias, prec)
-        x, self.attn = Fn.CrossAttnFn.apply(q, k, v)
+        # The reference hard-codes Dropout(0.1) on the probabilities and on the pre-residual output (vit.py:46-47, 58, 62) and
+        # they fire whenever the module is in train() -- also for the "frozen" tower during MLLM finetuning.  Same here:
+        # Philox masks keyed by torch's generator (torch.manual_seed replays them); eval() gives the deterministic function.
+        train = self.training
+        pa, po = (self.dropout.p, self.dropout_2.p) if train else (0.0, 0.0)
+        x, self.attn = Fn.CrossAttnFn.apply(q, k, v, pa, *(Fn.draw_dropout_seed() if pa > 0 else (0, 0)))
         x = Fn.LinearFn.apply(x, self.output_linear.weight, self.output_linear.bias, prec)
+        if po > 0:
+            x = Fn.DropoutFn.apply(x, po, *Fn.draw_dropout_seed())
         x = Fn.LayerNormFn.apply(q, x, self.norm.weight, self.norm.bias, self.norm.eps)
         return x, self.attn
 

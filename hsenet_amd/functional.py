@@ -340,33 +340,68 @@ class AssembleFn(torch.autograd.Function):
         return dpe, dpos, dcls, dscore
 
 
-class CrossAttnFn(torch.autograd.Function):
-    """attention(query, key, value) of regular_attention (vit.py:25-33), eval mode: returns (P V, P)."""
+def draw_dropout_seed():
+    """(seed, offset) for one dropout site of one forward call, from torch's default CPU generator (so ``torch.manual_seed``
+    replays the masks).  The mask itself is Philox4x32-10 inside the kernels: a pure function of (seed, offset, element)."""
+    v = torch.randint(0, 2 ** 62, (2,), dtype=torch.int64)
+    return int(v[0]), int(v[1]) & 0xFFFFFFFF
+
+
+class DropoutFn(torch.autograd.Function):
+    """nn.Dropout(p) in train mode with a replayable Philox mask (hs_dropout); identity is handled by the caller."""
 
     @staticmethod
-    def forward(ctx, q, k, v):
+    def forward(ctx, x, p, seed, offset):
+        x = _f32(x).contiguous()
+        _need(x)
+        y = torch.empty_like(x)
+        L.call("hs_dropout", x.data_ptr(), y.data_ptr(), x.numel(), float(p), seed, offset, _s())
+        ctx.args = (float(p), seed, offset)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        p, seed, offset = ctx.args
+        dy = _f32(dy).contiguous()
+        dx = torch.empty_like(dy)
+        L.call("hs_dropout", dy.data_ptr(), dx.data_ptr(), dy.numel(), p, seed, offset, _s())
+        return dx, None, None, None
+
+
+class CrossAttnFn(torch.autograd.Function):
+    """attention(query, key, value) of regular_attention (vit.py:25-33): returns (dropout(P) V, dropout(P)); drop_p = 0 in
+    eval mode (then the second output is P itself)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, drop_p=0.0, seed=0, offset=0):
         q, k, v = (_f32(t).contiguous() for t in (q, k, v))
         _need(q, k, v)
         B, nq, d = q.shape
         nk = k.shape[1]
         out = torch.empty_like(q)
         p = torch.empty(B, nq, nk, dtype=torch.float32, device=q.device)
-        L.call("hs_cross_attn_fwd", q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), p.data_ptr(), B, nq, nk, d, _s())
-        ctx.save_for_backward(q, k, v, p)
-        ctx.mark_non_differentiable(p)
-        return out, p
+        pd = torch.empty_like(p) if drop_p > 0 else None
+        L.call("hs_cross_attn_fwd", q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), p.data_ptr(), _p(pd), B, nq, nk, d,
+               float(drop_p), seed, offset, _s())
+        ctx.save_for_backward(q, k, v, p, *([pd] if pd is not None else []))
+        ctx.drop = (float(drop_p), seed, offset)
+        ret = pd if pd is not None else p
+        ctx.mark_non_differentiable(ret)
+        return out, ret
 
     @staticmethod
     def backward(ctx, dout, _dp):
-        q, k, v, p = ctx.saved_tensors
+        q, k, v, p, *rest = ctx.saved_tensors
+        pd = rest[0] if rest else None
+        drop_p, seed, offset = ctx.drop
         dout = _f32(dout).contiguous()
         B, nq, d = q.shape
         nk = k.shape[1]
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         ws = torch.empty_like(p)
-        L.call("hs_cross_attn_bwd", q.data_ptr(), k.data_ptr(), v.data_ptr(), p.data_ptr(), dout.data_ptr(), dq.data_ptr(), dk.data_ptr(),
-               dv.data_ptr(), ws.data_ptr(), B, nq, nk, d, _s())
-        return dq, dk, dv
+        L.call("hs_cross_attn_bwd", q.data_ptr(), k.data_ptr(), v.data_ptr(), p.data_ptr(), _p(pd), dout.data_ptr(), dq.data_ptr(),
+               dk.data_ptr(), dv.data_ptr(), ws.data_ptr(), B, nq, nk, d, drop_p, seed, offset, _s())
+        return dq, dk, dv, None, None, None
 
 
 class RowdotSigmoidFn(torch.autograd.Function):
@@ -421,18 +456,20 @@ class Pool3dFn(torch.autograd.Function):
 
 
 class WindowAttnFn(torch.autograd.Function):
-    """1 query per LR cell vs its kd*kh*kw HR children (spatial_pooling_projector.py:68-76), eval mode.
+    """1 query per LR cell vs its kd*kh*kw HR children (spatial_pooling_projector.py:68-76); drop_p > 0 = train-mode dropout on
+    the probabilities (Philox mask, replayed in backward).
     q [B,cells,d]; kv [B,tokens,2d] (k|v)."""
 
     @staticmethod
-    def forward(ctx, q, kv, grid, kernel):
+    def forward(ctx, q, kv, grid, kernel, drop_p=0.0, seed=0, offset=0):
         q, kv = _f32(q).contiguous(), _f32(kv).contiguous()
         _need(q, kv)
         B, cells, d = q.shape
         out = torch.empty_like(q)
-        L.call("hs_window_attn_fwd", q.data_ptr(), kv.data_ptr(), out.data_ptr(), B, *grid, *kernel, d, _s())
+        L.call("hs_window_attn_fwd", q.data_ptr(), kv.data_ptr(), out.data_ptr(), B, *grid, *kernel, d, float(drop_p), seed, offset, _s())
         ctx.save_for_backward(q, kv)
         ctx.geom = (tuple(grid), tuple(kernel))
+        ctx.drop = (float(drop_p), seed, offset)
         return out
 
     @staticmethod
@@ -443,8 +480,9 @@ class WindowAttnFn(torch.autograd.Function):
         B, cells, d = q.shape
         dq = torch.empty_like(q)
         dkv = torch.zeros_like(kv)
-        L.call("hs_window_attn_bwd", q.data_ptr(), kv.data_ptr(), dout.data_ptr(), dq.data_ptr(), dkv.data_ptr(), B, *grid, *kernel, d, _s())
-        return dq, dkv, None, None
+        L.call("hs_window_attn_bwd", q.data_ptr(), kv.data_ptr(), dout.data_ptr(), dq.data_ptr(), dkv.data_ptr(), B, *grid, *kernel, d,
+               *ctx.drop, _s())
+        return dq, dkv, None, None, None, None, None
 
 
 def _ptr_array(tensors: Sequence[torch.Tensor]):

@@ -43,8 +43,13 @@ class resolution_attention_v3(nn.Module):
         wkv = torch.cat([self.Wk.weight, self.Wv.weight], dim=0)
         bkv = torch.cat([self.Wk.bias, self.Wv.bias], dim=0)
         kv = Fn.LinearFn.apply(HR_image.contiguous().view(B, gd * gh * gw, d), wkv, bkv, prec)
-        x = Fn.WindowAttnFn.apply(q, kv, (gd, gh, gw), kernel)
+        # hard-coded Dropout(0.1) x2 of the reference, active in train() (spatial_pooling_projector.py:13-14, 58-59, 82)
+        train = self.training
+        pa, po = (self.dropout.p, self.dropout_2.p) if train else (0.0, 0.0)
+        x = Fn.WindowAttnFn.apply(q, kv, (gd, gh, gw), kernel, pa, *(Fn.draw_dropout_seed() if pa > 0 else (0, 0)))
         x = Fn.LinearFn.apply(x, self.output_linear.weight, self.output_linear.bias, prec)
+        if po > 0:
+            x = Fn.DropoutFn.apply(x, po, *Fn.draw_dropout_seed())
         return Fn.LayerNormFn.apply(q, x, self.norm.weight, self.norm.bias, self.norm.eps)
 
 

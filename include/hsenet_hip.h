@@ -123,13 +123,17 @@ int hs_attn_bwd(const void* qkv, const void* o, const void* d_o, const float* ls
 /* ---- K5: slice-guided scoring core of regular_attention (vit.py:25-33,57-60): single head, d_k = d,
  * P = softmax(q k^T / sqrt(d)) over nk keys (nk <= 64, nk % 4 == 0), out = P v.  q: [B][nq][d] fp32;
  * k, v: [B][nk][d] fp32.  p: [B][nq][nk] fp32, REQUIRED (the attention map the reference returns; saved for bwd).
- * Runs as exact-f32 MFMA GEMMs + a row softmax (4*nq*nk*d FLOPs: negligible).  Eval-mode (dropout off) — see
- * DESIGN.md "Dropout". */
-int hs_cross_attn_fwd(const float* q, const float* k, const float* v, float* out, float* p, int B, int nq, int nk,
-                      int d, void* stream);
-/* backward: dq, dk, dv written.  ws: fp32 scratch [B][nq][nk].  nq % 4 == 0. */
-int hs_cross_attn_bwd(const float* q, const float* k, const float* v, const float* p, const float* dout, float* dq,
-                      float* dk, float* dv, float* ws, int B, int nq, int nk, int d, void* stream);
+ * Runs as exact-f32 MFMA GEMMs + a row softmax (4*nq*nk*d FLOPs: negligible).  drop_p = 0, pd = NULL: eval mode. */
+int hs_cross_attn_fwd(const float* q, const float* k, const float* v, float* out, float* p, float* pd, int B, int nq, int nk,
+                      int d, float drop_p, uint64_t seed, uint64_t offset, void* stream);
+/* ws: fp32 scratch [B][nq][nk].  Train mode (module in train(): the reference's hard-coded Dropout(0.1) on the probabilities,
+ * vit.py:46): drop_p > 0 with a Philox mask that is a pure function of (seed, offset, element index); pd receives
+ * dropout(P) (what the reference returns) and out = pd V; the backward call takes the same pd / drop_p / seed / offset. */
+int hs_cross_attn_bwd(const float* q, const float* k, const float* v, const float* p, const float* pd, const float* dout,
+                      float* dq, float* dk, float* dv, float* ws, int B, int nq, int nk, int d, float drop_p, uint64_t seed,
+                      uint64_t offset, void* stream);
+/* y = x * keep / (1 - p), mask = Philox4x32-10(seed, offset + i/4): elementwise dropout; apply the same call to the gradient. */
+int hs_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, uint64_t offset, void* stream);
 /* score[r] = sigmoid(<x[r,:], w> + b)   (patch_score_proj + Sigmoid, vit.py:338-339).  x fp32 [rows][d]. */
 int hs_rowdot_sigmoid_fwd(const float* x, const float* w, const float* b, float* score, int rows, int d, void* stream);
 /* dx[r,:] = dscore[r]*s(1-s)*w ; dw += sum_r ..*x[r,:] ; db += sum_r ..   (dw/db accumulate atomically) */
@@ -145,9 +149,9 @@ int hs_pool3d_bwd(const float* dlr, float* dhr, int B, int gd, int gh, int gw, i
 /* one query per cell vs its children: out[b,cell,:] = sum_j softmax_j(<q,k_j>/sqrt(d)) v_j.
  * q: [B][cells][d]; kv: [B][gd*gh*gw][2*d] fp32 (k | v per token, as one fused Wk|Wv GEMM emits it). */
 int hs_window_attn_fwd(const float* q, const float* kv, float* out, int B, int gd, int gh, int gw, int kd, int kh,
-                       int kw, int d, void* stream);
+                       int kw, int d, float drop_p, uint64_t seed, uint64_t offset, void* stream);
 int hs_window_attn_bwd(const float* q, const float* kv, const float* dout, float* dq, float* dkv, int B, int gd,
-                       int gh, int gw, int kd, int kh, int kw, int d, void* stream);
+                       int gh, int gw, int kd, int kh, int kw, int d, float drop_p, uint64_t seed, uint64_t offset, void* stream);
 
 /* ---- K7/K8: small fused element/reduction kernels ------------------------------------------------------- */
 /* out[n] (+)= sum_m x[m][n]  (bias gradients).  x bf16 (is_bf16) or fp32.  accumulates atomically (caller zeroes). */

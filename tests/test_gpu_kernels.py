@@ -463,3 +463,84 @@ def test_attn_bwd_full_size_properties(dev):
     lhs = (qf * dqkv[..., :D].float()).sum()
     rhs = (kf * dqkv[..., D:2 * D].float()).sum()
     assert abs(float(lhs - rhs)) < 2e-2 * max(abs(float(lhs)), abs(float(rhs)), 1.0)
+
+
+# ---- train-mode dropout (the reference's hard-coded Dropout(0.1) sites): statistics, seed replay, forward/backward consistency ----
+@pytest.mark.gpu
+def test_dropout_kernel_statistics_and_replay(dev):
+    from hsenet_amd import functional as Fn
+    x = torch.ones(1 << 20, device=dev)
+    y1 = Fn.DropoutFn.apply(x, 0.1, 1234, 7)
+    y2 = Fn.DropoutFn.apply(x, 0.1, 1234, 7)
+    y3 = Fn.DropoutFn.apply(x, 0.1, 1235, 7)
+    assert torch.equal(y1, y2) and not torch.equal(y1, y3)                  # a pure function of (seed, offset, index)
+    keep = (y1 != 0).float().mean().item()
+    assert abs(keep - 0.9) < 2e-3                                            # 1e6 Bernoulli(0.9) draws: sigma = 3e-4
+    assert torch.allclose(y1[y1 != 0], torch.tensor(1 / 0.9, device=dev))
+    assert abs(y1.mean().item() - 1.0) < 3e-3                                # unbiased
+    # neighbouring elements are independent (a counter RNG must not repeat within a 4-element Philox block)
+    a, b = (y1[0::2] != 0).float(), (y1[1::2] != 0).float()
+    assert abs(((a - a.mean()) * (b - b.mean())).mean().item()) < 2e-3
+
+
+@pytest.mark.gpu
+def test_train_mode_dropout_sites(dev):
+    """regular_attention / resolution_attention_v3 in train(): seed-replayable, unbiased around the eval output, and the
+    backward uses the forward's masks (checked against finite differences of the SAME masked function)."""
+    import hsenet_amd as H
+    torch.manual_seed(0)
+    ra = H.regular_attention().to(dev)
+    q, kv = torch.randn(2, 64, 768, device=dev), torch.randn(2, 32, 768, device=dev)
+    ra.eval()
+    y_eval, p_eval = ra(q, kv, kv)
+    ra.train()
+    torch.manual_seed(5); y_a, p_a = ra(q, kv, kv)
+    torch.manual_seed(5); y_b, p_b = ra(q, kv, kv)
+    torch.manual_seed(6); y_c, _ = ra(q, kv, kv)
+    assert torch.equal(y_a, y_b) and torch.equal(p_a, p_b) and not torch.equal(y_a, y_c)
+    assert not torch.equal(y_a, y_eval)
+    assert abs((p_a == 0).float().mean().item() - 0.1) < 0.02                # ~4096 probabilities, 10 % dropped
+    assert torch.allclose(p_a[p_a != 0], (p_eval / 0.9)[p_a != 0], rtol=1e-5, atol=1e-7)
+    # packer side
+    pa = H.resolution_attention_v3().to(dev)
+    hr = torch.randn(1, 4, 8, 8, 768, device=dev)
+    lr = hr.view(1, 4, 2, 4, 2, 4, 768).mean((3, 5))
+    pa.train()
+    torch.manual_seed(9); z1 = pa(lr, hr, (1, 4, 4))
+    torch.manual_seed(9); z2 = pa(lr, hr, (1, 4, 4))
+    pa.eval()
+    z0 = pa(lr, hr, (1, 4, 4))
+    assert torch.equal(z1, z2) and not torch.equal(z1, z0)
+
+
+@pytest.mark.gpu
+def test_dropout_backward_uses_forward_mask(dev):
+    from hsenet_amd import functional as Fn
+    g = torch.Generator(device="cpu").manual_seed(3)
+    q = torch.randn(1, 8, 64, generator=g).to(dev).requires_grad_()
+    k = torch.randn(1, 16, 64, generator=g).to(dev).requires_grad_()
+    v = torch.randn(1, 16, 64, generator=g).to(dev).requires_grad_()
+    w = torch.randn(1, 8, 64, generator=g).to(dev)
+    out, pd = Fn.CrossAttnFn.apply(q, k, v, 0.25, 77, 3)
+    (out * w).sum().backward()
+    # the same masked function in torch: mask recovered from the returned dropped map
+    qd, kd, vd = (t.detach().double().requires_grad_() for t in (q, k, v))
+    p = torch.softmax(qd @ kd.transpose(1, 2) / 8.0, -1)
+    mask = (pd != 0).double() / 0.75
+    ref = (p * mask) @ vd
+    (ref * w.double()).sum().backward()
+    assert rel(out, ref.detach()) < 1e-5
+    for a, b in ((q.grad, qd.grad), (k.grad, kd.grad), (v.grad, vd.grad)):
+        assert rel(a, b) < 1e-4, rel(a, b)
+    # window attention: mask is internal -> compare the analytic gradient with a central difference of the masked forward
+    qw = torch.randn(1, 2, 64, generator=g).to(dev)
+    kvw = torch.randn(1, 32, 128, generator=g).to(dev)
+    ww = torch.randn(1, 2, 64, generator=g).to(dev)
+    qg = qw.clone().requires_grad_()
+    o = Fn.WindowAttnFn.apply(qg, kvw, (2, 4, 4), (1, 4, 4), 0.25, 99, 1)
+    (o * ww).sum().backward()
+    eps = 1e-2
+    d = torch.zeros_like(qw); d[0, 1, 5] = eps
+    f = lambda t: (Fn.WindowAttnFn.apply(t, kvw, (2, 4, 4), (1, 4, 4), 0.25, 99, 1) * ww).sum().item()
+    fd = (f(qw + d) - f(qw - d)) / (2 * eps)
+    assert abs(fd - qg.grad[0, 1, 5].item()) < 2e-3 * max(1.0, abs(fd)), (fd, qg.grad[0, 1, 5].item())

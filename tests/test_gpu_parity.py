@@ -35,7 +35,7 @@ def _load(mod, ref_module, seed, dev):
     from oracle import ref_cpu as R
     sd = R.seeded_state_dict(ref_module, seed)
     mod.load_state_dict(sd)
-    return mod.to(dev)
+    return mod.to(dev).eval()         # eval like the reference side: the hard-coded Dropout(0.1) sites are train-mode only
 
 
 @pytest.mark.parametrize("prec,tol", [("f32", TOL_F32), ("bf16", TOL_BF16)])
@@ -202,7 +202,7 @@ def test_backward_vs_oracle(dev):
         yr, _ = ref(*args)
         w = torch.from_numpy(np.random.default_rng(205).standard_normal(tuple(yr.shape), dtype=np.float32))
         (yr * w).sum().backward()
-        m = cls_h(**kw)
+        m = cls_h(**kw).eval()
         m.load_state_dict(sd)
         m = m.to(dev)
         y, _ = m(*[a.to(dev) for a in args])
@@ -226,7 +226,7 @@ def test_packer_backward_vs_oracle(dev):
     yr = ref(xr)
     w = torch.from_numpy(np.random.default_rng(213).standard_normal(tuple(yr.shape), dtype=np.float32))
     (yr * w).sum().backward()
-    m = H.VisualPacker_3d_phi_v3(*args)
+    m = H.VisualPacker_3d_phi_v3(*args).eval()
     m.load_state_dict(sd)
     m = m.to(dev)
     xd = x.to(dev).requires_grad_()
@@ -262,9 +262,9 @@ def test_config2_dual_256_with_packers(dev, prec, tol):
         yr = R.encode_images(tower_r, p1r, p2r, x, s)
         H.set_precision(prec)
         try:
-            tower = H.build_vision_tower(Cfg(img, patch))
+            tower = H.build_vision_tower(Cfg(img, patch)).eval()
             tower.load_state_dict(sd_t)
-            p1, p2 = H.VisualPacker_3d_phi_v3(*args, **pk), H.VisualPacker_3d_phi_v3(*args, **pk)
+            p1, p2 = H.VisualPacker_3d_phi_v3(*args, **pk).eval(), H.VisualPacker_3d_phi_v3(*args, **pk).eval()
             p1.load_state_dict(sd1), p2.load_state_dict(sd2)
             assert p1.proj_out_num == 128
             y = H.encode_images(tower.to(dev), p1.to(dev), p2.to(dev), x.to(dev), s.to(dev))
@@ -295,7 +295,7 @@ def test_config3_clip_step_vs_oracle(dev):
     img_r = R.clip_encode_image(ref, proj_r, x, s)[:, 0]
     loss_r = R.clip_contrastive_loss(img_r, txt, torch.tensor(scale))
     loss_r.backward()
-    m = H.ViT_stage2(**kw)
+    m = H.ViT_stage2(**kw).eval()
     m.load_state_dict(sd)
     m = m.to(dev)
     proj = torch.nn.Linear(768, 768)
