@@ -19,6 +19,7 @@ struct GemmP {
     const float* bias; const float* resid; const void* aux; void* aux_out; float* colsum;
     float alpha; int flags; int split_k; int tiles_m, tiles_n;
     int scale_cols; float scale_alpha;     // columns n < scale_cols carry the extra factor scale_alpha
+    int nt;                                // streaming (nontemporal) output stores, see hs_gemm
     int dbg;                               // diagnostic (tools/kbench): 1 = skip the epilogue, 2 = one K-tile only
 };
 
@@ -78,13 +79,16 @@ __device__ __forceinline__ void gelu_parts(float x, float& cdf, float& pdf_x) {
 // 256-B bank row differ in parity, rows of equal parity and equal chunk differ in (r >> 1), and the group's two chunk
 // values differ in bit 0 while their row sets {0-3,12-15} / {4-11} never differ by 1 in (r >> 1): conflict-free.
 __device__ __forceinline__ int swzR16(int r) { return (r >> 1) & 7; }
-template <bool TR, bool M16 = false>
+// PERMN (B image of the 16x16x32 form, see big_mainloop16): image row [j1 j0 q1 q0 r1 r0] of a wave's 64 holds matrix row
+// [j1 q1 q0 j0 r1 r0], so that the lane of the transposed accumulator owns 8 CONSECUTIVE output columns.
+__device__ __forceinline__ int permN(int row) { return (row & ~0x1c) | ((row & 0x0c) << 1) | ((row & 0x10) >> 2); }
+template <bool TR, bool M16 = false, bool PERMN = false>
 __device__ __forceinline__ unsigned dma_voff(int j, int dim0, int DIM, int k0, int K, long ld, int wave, int lane) {
     const int piece = j * 8 + wave;
     if (!TR) {
         const int row = piece * 8 + (lane >> 3);
         const int c = (lane & 7) ^ (M16 ? swzR16(row) : swzR(row));
-        const int gi = dim0 + row, gk = k0 + c * 8;
+        const int gi = dim0 + (PERMN ? permN(row) : row), gk = k0 + c * 8;
         return (gi < DIM && gk < K) ? (unsigned)(((long)gi * ld + gk) * 2) : HS_OOB_OFF;
     } else {
         const int sub = piece >> 4;                 // 128-wide sub-image (16 pieces each)
@@ -436,7 +440,7 @@ __device__ __forceinline__ void big_mainloop16(f32x4 (&acc)[8][4], char* smem, i
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                acc[HF * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(fa[SA][i]), as_frag(fb[SB][j]), acc[HF * 4 + i][j], 0, 0, 0);
+                acc[HF * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(fb[SB][j]), as_frag(fa[SA][i]), acc[HF * 4 + i][j], 0, 0, 0);
     };
     auto dma = [&](int kt, unsigned so, int q0) {
         char* sa = smem + so;
@@ -498,7 +502,13 @@ extern "C" void hs_debug_gemm_stamps(unsigned long long* out, int reset) {
     if (out) (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gemm_stamps), sizeof(g_gemm_stamps));
     if (reset) { unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_stamps), z, sizeof(z)); }
 }
-#define STAMP(i) do { if (p.dbg == 4) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0) atomicAdd(&g_gemm_stamps[i], t_ - t_prev); t_prev = t_; } } while (0)
+// diagnostic (dbg == 22): per-block timeline {start, main loop end, epilogue end, HW_ID | XCC_ID << 32} for tools/kbench
+__device__ unsigned long long g_gemm_trace[4 * 4096];
+extern "C" void hs_debug_gemm_trace(unsigned long long* out, int nblocks) {
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gemm_trace), sizeof(unsigned long long) * 4 * (nblocks < 4096 ? nblocks : 4096));
+}
+#define TRACE(i) do { if (p.dbg == 22 && threadIdx.x == 0 && blockIdx.x < 4096) g_gemm_trace[blockIdx.x * 4 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define STAMP(i) do { if (p.dbg == 4 || p.dbg == 7) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0) atomicAdd(&g_gemm_stamps[i], t_ - t_prev); t_prev = t_; } } while (0)
 
 // (asm with register constraints lives in __device__ helpers, never directly in a templated __global__ body: hipcc's
 // host pass then silently drops the kernel's launch stub)
@@ -556,7 +566,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmP p) {
         if (kt0 >= kt1) return;
     }
     if (p.dbg == 2) kt1 = kt0 + 1;
-    unsigned long long t_prev = p.dbg == 4 ? __builtin_amdgcn_s_memtime() : 0ull;
+    unsigned long long t_prev = (p.dbg == 4 || p.dbg == 7) ? __builtin_amdgcn_s_memtime() : 0ull;
     f32x16 acc[C::MB][2];
 #pragma unroll
     for (int i = 0; i < C::MB; ++i)
@@ -575,7 +585,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmP p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) va[j] = dma_voff<ATR, M16>(j, m0, p.M, 0, 64, p.lda, wave, lane);
 #pragma unroll
-    for (int j = 0; j < C::PB; ++j) vb[j] = dma_voff<BTR, M16>(j, n0, p.N, 0, 64, p.ldb, wave, lane);
+    for (int j = 0; j < C::PB; ++j) vb[j] = dma_voff<BTR, M16, M16>(j, n0, p.N, 0, 64, p.ldb, wave, lane);
     const unsigned ka = ATR ? (unsigned)(p.lda * 128) : 128u;   // bytes per K-tile step
     const unsigned kb = BTR ? (unsigned)(p.ldb * 128) : 128u;
     const int kt_full = p.K >> 6;                                 // K-tiles [0, kt_full) are complete
@@ -594,8 +604,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmP p) {
         }
     };
     STAMP(0);     // setup
+    TRACE(0);
+    if (p.dbg == 22 && threadIdx.x == 0 && blockIdx.x < 4096)
+        g_gemm_trace[blockIdx.x * 4 + 3] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
     if constexpr (M16) {
-        big_mainloop16(acc16, smem, row0, col0, wave, lane, rsA, rsB, va, vb, ka, kb, kt0, kt1, p.dbg);
+        big_mainloop16(acc16, smem, row0, col0, wave, lane, rsA, rsB, va, vb, ka, kb, kt0, kt1, p.dbg == 7 ? 4 : p.dbg);
     } else if constexpr (BIG) {
         big_mainloop<BTR>(acc, smem, row0, col0, wave, lane, rsA, rsB, va, vb, ka, kb, kt0, kt1, p.dbg);
     } else {
@@ -634,6 +647,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmP p) {
     // idle) ring and reads it back row-wise, so global stores/atomics and the bias/resid/aux loads are 128-256-B row
     // segments instead of one 4-8-B piece per row (which cost more than the K=768 main loop).
     STAMP(1);     // main loop
+    TRACE(1);
     __builtin_amdgcn_s_barrier();     // every wave is done reading the operand stages
     STAMP(2);     // post-loop barrier
     if (p.dbg == 1) {
@@ -643,29 +657,88 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmP p) {
         for (int i = 0; i < (M16 ? 8 : 1); ++i) { keep4(acc16[i][0]); keep4(acc16[i][1]); keep4(acc16[i][2]); keep4(acc16[i][3]); }
         return;
     }
+    if constexpr (M16) {
+        // ---- 16x16x32 form: the MFMAs ran with the operands SWAPPED (D' = B-tile x A-tile), so a lane holds, for output row
+        // m = 16 i + (lane & 15), the columns 16 j + 4 (lane >> 4) + r of the B IMAGE -- which permN laid out so that tiles
+        // 2jp, 2jp+1 together are the 8 consecutive matrix columns 32 jp + 8 (lane >> 4) .. +7.  The epilogue therefore runs
+        // straight out of the accumulators: no LDS round trip (writing and re-reading the 256-KiB fp32 tile was ~4k of the
+        // ~9k epilogue cycles per tile), each store instruction = 16 rows x 64 B (bf16) or 2 x (16 rows x 128 B) (fp32).
+        static_assert(EF >= 0, "the 16x16x32 kernels are launched with compile-time epilogue flags");
+        constexpr int flags = EF;
+        const int l15 = lane & 15, q = lane >> 4;
+        const bool want_res = (flags & HS_EPI_RESID) != 0;
+        int ncol[2];
+        bool n_in[2];
+        f32x4 bias_lo[2], bias_hi[2];
+        float alpha_n[2];
+#pragma unroll
+        for (int jp = 0; jp < 2; ++jp) {
+            ncol[jp] = n0 + col0 + 32 * jp + 8 * q;
+            n_in[jp] = ncol[jp] < p.N;
+            alpha_n[jp] = ncol[jp] < p.scale_cols ? p.alpha * p.scale_alpha : p.alpha;
+            bias_lo[jp] = f32x4{0.f, 0.f, 0.f, 0.f};
+            bias_hi[jp] = bias_lo[jp];
+            if ((flags & HS_EPI_BIAS) && n_in[jp]) { bias_lo[jp] = *(const f32x4*)(p.bias + ncol[jp]); bias_hi[jp] = *(const f32x4*)(p.bias + ncol[jp] + 4); }
+        }
+        // groups of 4 steps (two 16-row tiles x two column halves): all loads in flight -> all math -> all stores (see epi_math)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 vlo[4], vhi[4];
+            u32x4 zb[4];
+            bool in[4];
+            long idx[4];
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const int i = 2 * g + (st >> 1), jp = st & 1;
+                const int m = m0 + row0 + 16 * i + l15;
+                in[st] = m < p.M && n_in[jp];
+                idx[st] = cz + (long)m * p.ldc + ncol[jp];
+                vlo[st] = f32x4{0.f, 0.f, 0.f, 0.f};
+                vhi[st] = vlo[st];
+                if (want_res && in[st]) { vlo[st] = *(const f32x4*)(p.resid + idx[st]); vhi[st] = *(const f32x4*)(p.resid + idx[st] + 4); }
+            }
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const int i = 2 * g + (st >> 1), jp = st & 1;
+                u32x2 k0 = {0u, 0u}, k1 = {0u, 0u};
+                vlo[st] = epi_math(p, flags, 0, acc16[i][2 * jp], vlo[st], u32x2{0u, 0u}, bias_lo[jp], alpha_n[jp], &k0);
+                vhi[st] = epi_math(p, flags, 0, acc16[i][2 * jp + 1], vhi[st], u32x2{0u, 0u}, bias_hi[jp], alpha_n[jp], &k1);
+                zb[st] = u32x4{k0[0], k0[1], k1[0], k1[1]};
+            }
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                if (!in[st]) continue;
+                if (p.dbg == 3 || p.dbg == 7) { keep4(vlo[st]); keep4(vhi[st]); continue; }
+                u32x4 o;
+                o[0] = pack2bf(vlo[st][0], vlo[st][1]); o[1] = pack2bf(vlo[st][2], vlo[st][3]);
+                o[2] = pack2bf(vhi[st][0], vhi[st][1]); o[3] = pack2bf(vhi[st][2], vhi[st][3]);
+                if (p.nt) {
+                    if ((flags & HS_EPI_GELU) && p.aux_out) __builtin_nontemporal_store(zb[st], (u32x4*)((bf16_t*)p.aux_out + idx[st]));
+                    if (p.out_f32) { __builtin_nontemporal_store(vlo[st], (f32x4*)(p.out_f32 + idx[st])); __builtin_nontemporal_store(vhi[st], (f32x4*)(p.out_f32 + idx[st] + 4)); }
+                    if (p.out_bf16) __builtin_nontemporal_store(o, (u32x4*)((bf16_t*)p.out_bf16 + idx[st]));
+                } else {
+                    if ((flags & HS_EPI_GELU) && p.aux_out) *(u32x4*)((bf16_t*)p.aux_out + idx[st]) = zb[st];
+                    if (p.out_f32) { *(f32x4*)(p.out_f32 + idx[st]) = vlo[st]; *(f32x4*)(p.out_f32 + idx[st] + 4) = vhi[st]; }
+                    if (p.out_bf16) *(u32x4*)((bf16_t*)p.out_bf16 + idx[st]) = o;
+                }
+            }
+        }
+        STAMP(4);
+        TRACE(2);
+        return;
+    }
     float* my = (float*)(smem + wave * (64 * G_EPI_LD * 4));
     const int h = lane >> 5, c = lane & 31;
     const int flags = EF >= 0 ? EF : p.flags;
     const bool vec_ok = !(p.N & 3) && !(p.ldc & 3);
 #pragma unroll
     for (int half = 0; half < C::MB / 2; ++half) {
-        if constexpr (M16) {
-            // 16x16 tiles: column = lane & 15, rows 4*(lane >> 4) .. +3 in the 4 registers
-#pragma unroll
-            for (int ii = 0; ii < 4; ++ii)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        my[(16 * ii + 4 * (lane >> 4) + r) * G_EPI_LD + 16 * j + (lane & 15)] = acc16[half * 4 + ii][j][r];
-        } else {
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) my[(mb * 32 + acc_row(r, h)) * G_EPI_LD + nb * 32 + c] = acc[half * 2 + mb][nb][r];
-        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -723,15 +796,19 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmP p) {
                     }
 #pragma clang loop unroll(full)
                     for (int i = 0; i < GS; ++i)
-                        if (in[i] && p.dbg == 3) { keep4(vlo[i]); keep4(vhi[i]); }
+                        if (in[i] && (p.dbg == 3 || p.dbg == 7)) { keep4(vlo[i]); keep4(vhi[i]); }
                         else if (in[i]) {
-                            if ((flags & HS_EPI_GELU) && p.aux_out) *(u32x4*)((bf16_t*)p.aux_out + idx[i]) = zb[i];
-                            if (p.out_f32) { *(f32x4*)(p.out_f32 + idx[i]) = vlo[i]; *(f32x4*)(p.out_f32 + idx[i] + 4) = vhi[i]; }
-                            if (p.out_bf16) {
-                                u32x4 o;
-                                o[0] = pack2bf(vlo[i][0], vlo[i][1]); o[1] = pack2bf(vlo[i][2], vlo[i][3]);
-                                o[2] = pack2bf(vhi[i][0], vhi[i][1]); o[3] = pack2bf(vhi[i][2], vhi[i][3]);
-                                *(u32x4*)((bf16_t*)p.out_bf16 + idx[i]) = o;
+                            u32x4 o;
+                            o[0] = pack2bf(vlo[i][0], vlo[i][1]); o[1] = pack2bf(vlo[i][2], vlo[i][3]);
+                            o[2] = pack2bf(vhi[i][0], vhi[i][1]); o[3] = pack2bf(vhi[i][2], vhi[i][3]);
+                            if (p.nt) {
+                                if ((flags & HS_EPI_GELU) && p.aux_out) __builtin_nontemporal_store(zb[i], (u32x4*)((bf16_t*)p.aux_out + idx[i]));
+                                if (p.out_f32) { __builtin_nontemporal_store(vlo[i], (f32x4*)(p.out_f32 + idx[i])); __builtin_nontemporal_store(vhi[i], (f32x4*)(p.out_f32 + idx[i] + 4)); }
+                                if (p.out_bf16) __builtin_nontemporal_store(o, (u32x4*)((bf16_t*)p.out_bf16 + idx[i]));
+                            } else {
+                                if ((flags & HS_EPI_GELU) && p.aux_out) *(u32x4*)((bf16_t*)p.aux_out + idx[i]) = zb[i];
+                                if (p.out_f32) { *(f32x4*)(p.out_f32 + idx[i]) = vlo[i]; *(f32x4*)(p.out_f32 + idx[i] + 4) = vhi[i]; }
+                                if (p.out_bf16) *(u32x4*)((bf16_t*)p.out_bf16 + idx[i]) = o;
                             }
                         }
                 }
@@ -820,6 +897,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmP p) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
     }
+    TRACE(2);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -955,6 +1033,15 @@ extern "C" int hs_gemm(const hs_gemm_args* a, int prec, void* stream) {
     p.aux_out = a->aux_out; p.colsum = a->colsum_out; p.alpha = a->alpha; p.flags = a->flags; p.split_k = a->split_k;
     p.scale_cols = a->scale_cols; p.scale_alpha = a->scale_cols_alpha;
     p.dbg = g_hs_dbg[3];
+    // Output stores of a GEMM whose result cannot stay in the caches anyway are issued as streaming (nontemporal) stores:
+    // ordinary stores park 128 KiB of dirty lines per tile in the XCD's 4-MiB L2 -- 32 tiles per round = the whole L2 --
+    // evicting the operand panels the other blocks are about to hit (measured on the 81940-row ViT-B shapes: main-loop vmcnt
+    // wait 7.4k -> 3.8k cycles per tile, qkv/fc1 -6 % end to end; streaming LOADS of the A panel made them 3-8 % slower).
+    {
+        const double out_bytes = (double)a->M * a->N * a->batch * ((a->out_f32 ? 4 : 0) + (a->out_bf16 ? 2 : 0) + (a->aux_out ? 2 : 0));
+        static const bool no_nt = getenv("HS_GEMM_NO_NT") != nullptr;    // tools/kbench A/B runs
+        p.nt = out_bytes >= 64.0 * 1048576.0 && !(a->flags & HS_EPI_ATOMIC) && !no_nt;
+    }
     hipStream_t s = (hipStream_t)stream;
     const int zdim = a->split_k > 1 ? a->split_k : a->batch;
     const double mnk = (double)a->M * a->N * a->K * a->batch;
@@ -977,7 +1064,7 @@ extern "C" int hs_gemm(const hs_gemm_args* a, int prec, void* stream) {
         if (big) hipLaunchKernelGGL((gemm_bf16_kernel<ATR, BTR, true, EF>), grid, dim3(512), 0, s, p);                \
         else hipLaunchKernelGGL((gemm_bf16_kernel<ATR, BTR, false, EF>), grid, dim3(512), 0, s, p);                   \
     } while (0)
-        const bool m16 = big && a->layout == HS_GEMM_NT && getenv("HS_GEMM_NO_M16") == nullptr;   // (env: kbench A/B)
+        const bool m16 = big && a->layout == HS_GEMM_NT && !a->colsum_out && getenv("HS_GEMM_NO_M16") == nullptr;   // (env: kbench A/B)
 #define HS_LAUNCH_M16(EF) hipLaunchKernelGGL((gemm_bf16_kernel<false, false, true, EF, true>), grid, dim3(512), 0, s, p)
         if (m16 && col8 && (f == 0 || f == (HS_EPI_BIAS | HS_EPI_RESID) || f == (HS_EPI_BIAS | HS_EPI_GELU | HS_EPI_SAVE_DGELU))) {
             if (f == 0) HS_LAUNCH_M16(0);

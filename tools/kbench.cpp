@@ -241,7 +241,7 @@ int main(int argc, char** argv) {
             }
             const double us = time_us([&] { gemm(&a, HS_PREC_BF16, 0); }, reps);
             printf("%-16s M=%6d N=%5d K=%6d: %8.1f us  %7.1f TFLOP/s\n", s.name, s.m, s.n, s.k, us, 2.0 * s.m * s.n * s.k / us / 1e6);
-            if (getenv("HS_GEMM_DBG") && atoi(getenv("HS_GEMM_DBG")) == 4) {
+            if (getenv("HS_GEMM_DBG") && (atoi(getenv("HS_GEMM_DBG")) == 4 || atoi(getenv("HS_GEMM_DBG")) >= 7)) {
                 typedef void (*st_t)(unsigned long long*, int);
                 auto st = sym<st_t>("hs_debug_gemm_stamps");
                 unsigned long long v[8];
@@ -250,6 +250,22 @@ int main(int argc, char** argv) {
                 st(v, 0);
                 const double nb = (double)((s.m + 255) / 256) * ((s.n + 255) / 256);
                 printf("    cycles/block (wave 0): setup %.0f | main loop %.0f (barrier wait %.0f, vmcnt wait %.0f, last-read wait %.0f) | barrier %.0f | staging %.0f | readback+math+stores %.0f\n", v[0] / nb, v[1] / nb, v[5] / nb, v[7] / nb, v[6] / nb, v[2] / nb, v[3] / nb, v[4] / nb);
+            }
+            if (getenv("HS_GEMM_DBG") && atoi(getenv("HS_GEMM_DBG")) == 22) {
+                typedef void (*tr_t)(unsigned long long*, int);
+                auto tr = sym<tr_t>("hs_debug_gemm_trace");
+                const int nb = std::min(4096, ((s.m + 255) / 256) * ((s.n + 255) / 256));
+                std::vector<unsigned long long> v(4 * (size_t)nb);
+                gemm(&a, HS_PREC_BF16, 0); CK(hipDeviceSynchronize());
+                tr(v.data(), nb);
+                const char* path = getenv("HS_TRACE_OUT") ? getenv("HS_TRACE_OUT") : "gpurun_out/gemm_trace.csv";
+                FILE* f = fopen(path, "w");
+                if (f) {
+                    fprintf(f, "block,start,main_end,epi_end,hw_id,xcc_id\n");
+                    for (int b = 0; b < nb; ++b) fprintf(f, "%d,%llu,%llu,%llu,%llu,%llu\n", b, v[4 * b], v[4 * b + 1], v[4 * b + 2], v[4 * b + 3] & 0xffffffffull, v[4 * b + 3] >> 32);
+                    fclose(f);
+                    printf("    timeline of %d blocks -> %s\n", nb, path);
+                }
             }
             fflush(stdout);
             CK(hipFree(A)); CK(hipFree(Bm)); CK(hipFree(out));
