@@ -20,6 +20,7 @@ struct GemmP {
     float alpha; int flags; int split_k; int tiles_m, tiles_n;
     int scale_cols; float scale_alpha;     // columns n < scale_cols carry the extra factor scale_alpha
     int nt;                                // streaming (nontemporal) output stores, see hs_gemm
+    int nblocks;                           // tiles_m * tiles_n * zdim (the persistent kernel walks them with stride gridDim.x)
     int dbg;                               // diagnostic (tools/kbench): 1 = skip the epilogue, 2 = one K-tile only
 };
 
@@ -515,6 +516,90 @@ extern "C" void hs_debug_gemm_trace(unsigned long long* out, int nblocks) {
 __device__ __forceinline__ void keep_alive(const f32x16& v) { asm volatile("" ::"v"(v)); }
 __device__ __forceinline__ void keep4(const f32x4& v) { asm volatile("" ::"v"(v)); }
 
+// virtual block b of nb -> (row tile, column tile, slice): see the comment on the XCD-aware order in gemm_bf16_kernel
+__device__ __forceinline__ void tile_order(int b, int nb, int tiles_m, int tiles_n, int& tm, int& tn, int& z) {
+    const int q = nb >> 3, r = nb & 7, x = b & 7;
+    int v = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+    const int tiles = tiles_m * tiles_n;
+    z = v / tiles;
+    v -= z * tiles;
+    const int GM = tiles_n >= 8 ? 4 : (tiles_n >= 4 ? 8 : 16);
+    const int per_group = GM * tiles_n;
+    const int g = v / per_group, w = v - g * per_group;
+    const int gm = min(GM, tiles_m - g * GM);
+    tm = g * GM + w % gm;
+    tn = w / gm;
+}
+
+template <int EF>
+__device__ __forceinline__ void epilogue16(const GemmP& p, const f32x4 (&acc16)[8][4], int mw, int nw, long cz, int lane) {
+    // ---- 16x16x32 form: the MFMAs ran with the operands SWAPPED (D' = B-tile x A-tile), so a lane holds, for output row
+    // m = 16 i + (lane & 15), the columns 16 j + 4 (lane >> 4) + r of the B IMAGE -- which permN laid out so that tiles
+    // 2jp, 2jp+1 together are the 8 consecutive matrix columns 32 jp + 8 (lane >> 4) .. +7.  The epilogue therefore runs
+    // straight out of the accumulators: no LDS round trip (writing and re-reading the 256-KiB fp32 tile was ~4k of the
+    // ~9k epilogue cycles per tile), each store instruction = 16 rows x 64 B (bf16) or 2 x (16 rows x 128 B) (fp32).
+static_assert(EF >= 0, "the 16x16x32 kernels are launched with compile-time epilogue flags");
+    constexpr int flags = EF;
+    const int l15 = lane & 15, q = lane >> 4;
+    const bool want_res = (flags & HS_EPI_RESID) != 0;
+    int ncol[2];
+    bool n_in[2];
+    f32x4 bias_lo[2], bias_hi[2];
+    float alpha_n[2];
+#pragma unroll
+    for (int jp = 0; jp < 2; ++jp) {
+        ncol[jp] = nw + 32 * jp + 8 * q;
+        n_in[jp] = ncol[jp] < p.N;
+        alpha_n[jp] = ncol[jp] < p.scale_cols ? p.alpha * p.scale_alpha : p.alpha;
+        bias_lo[jp] = f32x4{0.f, 0.f, 0.f, 0.f};
+        bias_hi[jp] = bias_lo[jp];
+        if ((flags & HS_EPI_BIAS) && n_in[jp]) { bias_lo[jp] = *(const f32x4*)(p.bias + ncol[jp]); bias_hi[jp] = *(const f32x4*)(p.bias + ncol[jp] + 4); }
+    }
+    // groups of 4 steps (two 16-row tiles x two column halves): all loads in flight -> all math -> all stores (see epi_math)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        f32x4 vlo[4], vhi[4];
+        u32x4 zb[4];
+        bool in[4];
+        long idx[4];
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            const int i = 2 * g + (st >> 1), jp = st & 1;
+            const int m = mw + 16 * i + l15;
+            in[st] = m < p.M && n_in[jp];
+            idx[st] = cz + (long)m * p.ldc + ncol[jp];
+            vlo[st] = f32x4{0.f, 0.f, 0.f, 0.f};
+            vhi[st] = vlo[st];
+            if (want_res && in[st]) { vlo[st] = *(const f32x4*)(p.resid + idx[st]); vhi[st] = *(const f32x4*)(p.resid + idx[st] + 4); }
+        }
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            const int i = 2 * g + (st >> 1), jp = st & 1;
+            u32x2 k0 = {0u, 0u}, k1 = {0u, 0u};
+            vlo[st] = epi_math(p, flags, 0, acc16[i][2 * jp], vlo[st], u32x2{0u, 0u}, bias_lo[jp], alpha_n[jp], &k0);
+            vhi[st] = epi_math(p, flags, 0, acc16[i][2 * jp + 1], vhi[st], u32x2{0u, 0u}, bias_hi[jp], alpha_n[jp], &k1);
+            zb[st] = u32x4{k0[0], k0[1], k1[0], k1[1]};
+        }
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            if (!in[st]) continue;
+            if (p.dbg == 3 || p.dbg == 7) { keep4(vlo[st]); keep4(vhi[st]); continue; }
+            u32x4 o;
+            o[0] = pack2bf(vlo[st][0], vlo[st][1]); o[1] = pack2bf(vlo[st][2], vlo[st][3]);
+            o[2] = pack2bf(vhi[st][0], vhi[st][1]); o[3] = pack2bf(vhi[st][2], vhi[st][3]);
+            if (p.nt) {
+                if ((flags & HS_EPI_GELU) && p.aux_out) __builtin_nontemporal_store(zb[st], (u32x4*)((bf16_t*)p.aux_out + idx[st]));
+                if (p.out_f32) { __builtin_nontemporal_store(vlo[st], (f32x4*)(p.out_f32 + idx[st])); __builtin_nontemporal_store(vhi[st], (f32x4*)(p.out_f32 + idx[st] + 4)); }
+                if (p.out_bf16) __builtin_nontemporal_store(o, (u32x4*)((bf16_t*)p.out_bf16 + idx[st]));
+            } else {
+                if ((flags & HS_EPI_GELU) && p.aux_out) *(u32x4*)((bf16_t*)p.aux_out + idx[st]) = zb[st];
+                if (p.out_f32) { *(f32x4*)(p.out_f32 + idx[st]) = vlo[st]; *(f32x4*)(p.out_f32 + idx[st] + 4) = vhi[st]; }
+                if (p.out_bf16) *(u32x4*)((bf16_t*)p.out_bf16 + idx[st]) = o;
+            }
+        }
+    }
+}
+
 // EF >= 0: the epilogue flags as a compile-time constant (the launcher checked p.flags == EF and the 8-column
 // conditions): the flag tests fold away.  Run-time flags (EF = -1) cost ~1500 cycles of branches per epilogue step --
 // 24k cycles per 256x256 tile, more than half of a K = 768 main loop.
@@ -535,20 +620,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmP p) {
     // all column tiles, column-major inside a group (GM wider when there are few column tiles, so weight tiles are
     // shared by more blocks).  Placement only affects speed, never results.
     int tm, tn, z;
-    {
-        const int nb = gridDim.x, b = blockIdx.x;
-        const int q = nb >> 3, r = nb & 7, x = b & 7;
-        int v = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
-        const int tiles = p.tiles_m * p.tiles_n;
-        z = v / tiles;
-        v -= z * tiles;
-        const int GM = p.tiles_n >= 8 ? 4 : (p.tiles_n >= 4 ? 8 : 16);
-        const int per_group = GM * p.tiles_n;
-        const int g = v / per_group, w = v - g * per_group;
-        const int gm = min(GM, p.tiles_m - g * GM);
-        tm = g * GM + w % gm;
-        tn = w / gm;
-    }
+    tile_order(blockIdx.x, gridDim.x, p.tiles_m, p.tiles_n, tm, tn, z);
     const int m0 = tm * 256, n0 = tn * C::BN;
     const int bz = p.split_k > 1 ? 0 : z;
     const bf16_t* A = (const bf16_t*)p.A + bz * p.sA;
@@ -658,71 +730,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmP p) {
         return;
     }
     if constexpr (M16) {
-        // ---- 16x16x32 form: the MFMAs ran with the operands SWAPPED (D' = B-tile x A-tile), so a lane holds, for output row
-        // m = 16 i + (lane & 15), the columns 16 j + 4 (lane >> 4) + r of the B IMAGE -- which permN laid out so that tiles
-        // 2jp, 2jp+1 together are the 8 consecutive matrix columns 32 jp + 8 (lane >> 4) .. +7.  The epilogue therefore runs
-        // straight out of the accumulators: no LDS round trip (writing and re-reading the 256-KiB fp32 tile was ~4k of the
-        // ~9k epilogue cycles per tile), each store instruction = 16 rows x 64 B (bf16) or 2 x (16 rows x 128 B) (fp32).
-        static_assert(EF >= 0, "the 16x16x32 kernels are launched with compile-time epilogue flags");
-        constexpr int flags = EF;
-        const int l15 = lane & 15, q = lane >> 4;
-        const bool want_res = (flags & HS_EPI_RESID) != 0;
-        int ncol[2];
-        bool n_in[2];
-        f32x4 bias_lo[2], bias_hi[2];
-        float alpha_n[2];
-#pragma unroll
-        for (int jp = 0; jp < 2; ++jp) {
-            ncol[jp] = n0 + col0 + 32 * jp + 8 * q;
-            n_in[jp] = ncol[jp] < p.N;
-            alpha_n[jp] = ncol[jp] < p.scale_cols ? p.alpha * p.scale_alpha : p.alpha;
-            bias_lo[jp] = f32x4{0.f, 0.f, 0.f, 0.f};
-            bias_hi[jp] = bias_lo[jp];
-            if ((flags & HS_EPI_BIAS) && n_in[jp]) { bias_lo[jp] = *(const f32x4*)(p.bias + ncol[jp]); bias_hi[jp] = *(const f32x4*)(p.bias + ncol[jp] + 4); }
-        }
-        // groups of 4 steps (two 16-row tiles x two column halves): all loads in flight -> all math -> all stores (see epi_math)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            f32x4 vlo[4], vhi[4];
-            u32x4 zb[4];
-            bool in[4];
-            long idx[4];
-#pragma unroll
-            for (int st = 0; st < 4; ++st) {
-                const int i = 2 * g + (st >> 1), jp = st & 1;
-                const int m = m0 + row0 + 16 * i + l15;
-                in[st] = m < p.M && n_in[jp];
-                idx[st] = cz + (long)m * p.ldc + ncol[jp];
-                vlo[st] = f32x4{0.f, 0.f, 0.f, 0.f};
-                vhi[st] = vlo[st];
-                if (want_res && in[st]) { vlo[st] = *(const f32x4*)(p.resid + idx[st]); vhi[st] = *(const f32x4*)(p.resid + idx[st] + 4); }
-            }
-#pragma unroll
-            for (int st = 0; st < 4; ++st) {
-                const int i = 2 * g + (st >> 1), jp = st & 1;
-                u32x2 k0 = {0u, 0u}, k1 = {0u, 0u};
-                vlo[st] = epi_math(p, flags, 0, acc16[i][2 * jp], vlo[st], u32x2{0u, 0u}, bias_lo[jp], alpha_n[jp], &k0);
-                vhi[st] = epi_math(p, flags, 0, acc16[i][2 * jp + 1], vhi[st], u32x2{0u, 0u}, bias_hi[jp], alpha_n[jp], &k1);
-                zb[st] = u32x4{k0[0], k0[1], k1[0], k1[1]};
-            }
-#pragma unroll
-            for (int st = 0; st < 4; ++st) {
-                if (!in[st]) continue;
-                if (p.dbg == 3 || p.dbg == 7) { keep4(vlo[st]); keep4(vhi[st]); continue; }
-                u32x4 o;
-                o[0] = pack2bf(vlo[st][0], vlo[st][1]); o[1] = pack2bf(vlo[st][2], vlo[st][3]);
-                o[2] = pack2bf(vhi[st][0], vhi[st][1]); o[3] = pack2bf(vhi[st][2], vhi[st][3]);
-                if (p.nt) {
-                    if ((flags & HS_EPI_GELU) && p.aux_out) __builtin_nontemporal_store(zb[st], (u32x4*)((bf16_t*)p.aux_out + idx[st]));
-                    if (p.out_f32) { __builtin_nontemporal_store(vlo[st], (f32x4*)(p.out_f32 + idx[st])); __builtin_nontemporal_store(vhi[st], (f32x4*)(p.out_f32 + idx[st] + 4)); }
-                    if (p.out_bf16) __builtin_nontemporal_store(o, (u32x4*)((bf16_t*)p.out_bf16 + idx[st]));
-                } else {
-                    if ((flags & HS_EPI_GELU) && p.aux_out) *(u32x4*)((bf16_t*)p.aux_out + idx[st]) = zb[st];
-                    if (p.out_f32) { *(f32x4*)(p.out_f32 + idx[st]) = vlo[st]; *(f32x4*)(p.out_f32 + idx[st] + 4) = vhi[st]; }
-                    if (p.out_bf16) *(u32x4*)((bf16_t*)p.out_bf16 + idx[st]) = o;
-                }
-            }
-        }
+        epilogue16<EF>(p, acc16, m0 + row0, n0 + col0, cz, lane);
         STAMP(4);
         TRACE(2);
         return;
@@ -901,6 +909,184 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmP p) {
 }
 
 // ------------------------------------------------------------------------------------------------------
+// Persistent form of the 256x256 NT 16x16x32 kernel.  One block per CU walks the virtual block order with stride
+// gridDim.x (the same XCD-aware order: at any time the chip works on the tiles the one-tile-per-block grid would).  The
+// K-tile stream never drains: the last two K-steps of a tile prefetch the NEXT tile's K-tiles 0 and 1 (the register
+// epilogue leaves the LDS ring free), the epilogue's stores are issued behind those loads and retire under the next
+// tile's first K-steps -- a block that ends instead pays the store drain, the block launch and the first DMA round
+// trip in the open (measured timeline: 5.8k + 6k of a 45.5k-cycle tile period at K = 768).
+//   per tile:  k-step 0          no DMA in phase 0 (B of K-tile 1 is already in flight); the tile barrier waits for K-tile 1
+//                                 with a COUNTED vmcnt that leaves the previous tile's stores in flight
+//              k-steps 1..KT-3    as big_mainloop16
+//              k-step KT-2        phase 3 issues A of the next tile's K-tile 0
+//              k-step KT-1        phase 0 issues B of the next tile's K-tile 0, phase 3 A and B of its K-tile 1
+// Requires K % 64 == 0, K >= 192, batch == 1 (hs_gemm picks the one-tile kernel otherwise).
+// ------------------------------------------------------------------------------------------------------
+// the phases of a k-step are hand-placed: nothing may be scheduled across their seams (without the branches of the one-tile
+// kernel the whole k-step is one basic block and hipcc shuffles the MFMAs over the waits and the barrier: -7 %)
+#define SB() __builtin_amdgcn_sched_barrier(0)
+template <int NST>
+__device__ __forceinline__ void wait_tile_counted() {
+    // the newest NST vector-memory operations (the previous tile's stores) may stay in flight
+    if (NST == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (NST == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+    else if (NST == 48) asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+template <int EF>
+__device__ __forceinline__ void nt16p_body(const GemmP& p, char* smem) {
+    constexpr int STAGE = 65536;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int row0 = (wave >> 2) * 128, col0 = (wave & 3) * 64;
+    const int KT = p.K >> 6;
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.A, (size_t)p.M * p.lda * 2);
+    const __amdgpu_buffer_rsrc_t rsB = make_rsrc(p.B, (size_t)p.N * p.ldb * 2);
+    // stores one wave issues per FULL tile (rows all inside M): what the counted wait may leave in flight
+    const int nst = (p.out_bf16 ? 16 : 0) + (p.out_f32 ? 32 : 0) + (((EF & HS_EPI_GELU) && p.aux_out) ? 16 : 0);
+
+    const int r = lane & 15, q = lane >> 4, f = swzR16(r);
+    unsigned ab0[2], bb0[2];
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+        ab0[st] = lds_off(smem) + (row0 + r) * 128 + (((4 * st + q) ^ f) << 4);
+        bb0[st] = lds_off(smem) + 32768 + (col0 + r) * 128 + (((4 * st + q) ^ f) << 4);
+    }
+    u32x4 fa[2][4], fb[2][4];
+    f32x4 acc[8][4];
+    auto rdA = [&](auto set_tag, auto st_tag, auto hf_tag, unsigned so) {
+        constexpr int S = decltype(set_tag)::value, ST = decltype(st_tag)::value, HF = decltype(hf_tag)::value;
+        const unsigned a = ab0[ST] + so;
+        ldsr128<(HF * 4 + 0) * 2048>(fa[S][0], a); ldsr128<(HF * 4 + 1) * 2048>(fa[S][1], a);
+        ldsr128<(HF * 4 + 2) * 2048>(fa[S][2], a); ldsr128<(HF * 4 + 3) * 2048>(fa[S][3], a);
+    };
+    auto rdB = [&](auto set_tag, auto st_tag, unsigned so) {
+        constexpr int S = decltype(set_tag)::value, ST = decltype(st_tag)::value;
+        const unsigned b = bb0[ST] + so;
+        ldsr128<0>(fb[S][0], b); ldsr128<2048>(fb[S][1], b); ldsr128<4096>(fb[S][2], b); ldsr128<6144>(fb[S][3], b);
+    };
+    auto mma = [&](auto aset_tag, auto bset_tag, auto hf_tag) {
+        constexpr int SA = decltype(aset_tag)::value, SB = decltype(bset_tag)::value, HF = decltype(hf_tag)::value;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[HF * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(fb[SB][j]), as_frag(fa[SA][i]), acc[HF * 4 + i][j], 0, 0, 0);
+    };
+    auto dmaA = [&](const unsigned (&v)[4], int kt, unsigned so) {
+#pragma unroll
+        for (int pc = 0; pc < 4; ++pc) dma_piece(rsA, smem + so, pc, wave, v[pc], (unsigned)kt * 128u);
+    };
+    auto dmaB = [&](const unsigned (&v)[4], int kt, unsigned so) {
+#pragma unroll
+        for (int pc = 0; pc < 4; ++pc) dma_piece(rsB, smem + so + 32768, pc, wave, v[pc], (unsigned)kt * 128u);
+    };
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 1> I1;
+    typedef std::integral_constant<int, 2> I2;
+    typedef std::integral_constant<int, 3> I3;
+
+    int bb = blockIdx.x;
+    int tm, tn, z;
+    tile_order(bb, p.nblocks, p.tiles_m, p.tiles_n, tm, tn, z);
+    unsigned va[4], vb[4], van[4], vbn[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        va[j] = dma_voff<false, true>(j, tm * 256, p.M, 0, 64, p.lda, wave, lane);
+        vb[j] = dma_voff<false, true, true>(j, tn * 256, p.N, 0, 64, p.ldb, wave, lane);
+    }
+    if (p.dbg >= 11 && p.dbg <= 14) {   // diagnostic: de-phase the blocks of an XCD (4 phases)
+        const unsigned long long t0_ = __builtin_amdgcn_s_memtime(), wait_ = (unsigned long long)((blockIdx.x >> 3) & 3) * (unsigned long long)(p.dbg - 10) * 4000ull;
+        while (__builtin_amdgcn_s_memtime() - t0_ < wait_) __builtin_amdgcn_s_sleep(16);
+    }
+    dmaA(va, 0, 0u); dmaB(vb, 0, 0u);
+    dmaA(va, 1, (unsigned)STAGE); dmaB(vb, 1, (unsigned)STAGE);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    unsigned so = 0;
+    bool counted = false;               // the tile barrier of k-step 0 may leave `nst` stores in flight
+    for (;;) {
+        if (p.dbg == 22 && threadIdx.x == 0 && bb < 4096) {
+            g_gemm_trace[bb * 4 + 0] = __builtin_amdgcn_s_memtime();
+            g_gemm_trace[bb * 4 + 3] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+        }
+        const int m0 = tm * 256, n0 = tn * 256;
+        const int bn = bb + (int)gridDim.x;
+        const bool has_next = bn < p.nblocks;
+        if (has_next) {
+            tile_order(bn, p.nblocks, p.tiles_m, p.tiles_n, tm, tn, z);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                van[j] = dma_voff<false, true>(j, tm * 256, p.M, 0, 64, p.lda, wave, lane);
+                vbn[j] = dma_voff<false, true, true>(j, tn * 256, p.N, 0, 64, p.ldb, wave, lane);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        rdA(I0{}, I0{}, I0{}, so);
+        rdB(I0{}, I0{}, so);
+        // MODE 0: first k-step of a tile, 1: middle, 2: last but one, 3: last
+        auto kstep = [&](auto mode_tag, int kt) {
+            constexpr int MODE = decltype(mode_tag)::value;
+            const unsigned so1 = so ^ (unsigned)STAGE;
+            rdA(I1{}, I0{}, I1{}, so);
+            lds_wait8g<4>(fa[0][0], fa[0][1], fa[0][2], fa[0][3], fb[0][0], fb[0][1], fb[0][2], fb[0][3]);
+            SB(); mma(I0{}, I0{}, I0{}); SB();
+            if (MODE == 1 || MODE == 2) dmaB(vb, kt + 1, so1);
+            if (MODE == 3 && has_next) dmaB(vbn, 0, so1);
+            rdA(I0{}, I1{}, I0{}, so);
+            rdB(I1{}, I1{}, so);
+            lds_wait4<8>(fa[1][0], fa[1][1], fa[1][2], fa[1][3]);
+            SB(); mma(I1{}, I0{}, I1{}); SB();
+            rdA(I1{}, I1{}, I1{}, so);
+            lds_wait8g<4>(fa[0][0], fa[0][1], fa[0][2], fa[0][3], fb[1][0], fb[1][1], fb[1][2], fb[1][3]);
+            SB(); mma(I0{}, I1{}, I0{}); SB();
+            lds_wait4<0>(fa[1][0], fa[1][1], fa[1][2], fa[1][3]);       // every read of this stage has landed
+            if (MODE == 0 && counted) {
+                if (nst == 16) wait_tile_counted<16>(); else if (nst == 32) wait_tile_counted<32>();
+                else if (nst == 48) wait_tile_counted<48>(); else wait_tile_counted<0>();
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            SB();
+            if (MODE != 3) { rdA(I0{}, I0{}, I0{}, so1); rdB(I0{}, I0{}, so1); }
+            SB(); mma(I1{}, I1{}, I1{}); SB();
+            if (MODE == 0 || MODE == 1) dmaA(va, kt + 2, so);
+            if (MODE == 2 && has_next) dmaA(van, 0, so);
+            if (MODE == 3 && has_next) { dmaA(van, 1, so); dmaB(vbn, 1, so); }
+            so = so1;
+        };
+        kstep(I0{}, 0);
+        for (int kt = 1; kt < KT - 2; ++kt) kstep(I1{}, kt);
+        kstep(I2{}, KT - 2);
+        kstep(I3{}, KT - 1);
+        if (p.dbg == 22 && threadIdx.x == 0 && bb < 4096) g_gemm_trace[bb * 4 + 1] = __builtin_amdgcn_s_memtime();
+        epilogue16<EF>(p, acc, m0 + row0, n0 + col0, 0l, lane);
+        if (p.dbg == 22 && threadIdx.x == 0 && bb < 4096) g_gemm_trace[bb * 4 + 2] = __builtin_amdgcn_s_memtime();
+        if (!has_next) break;
+        counted = m0 + 256 <= p.M && n0 + 256 <= p.N && p.dbg != 3;     // a full tile: every wave issued exactly `nst` stores
+        bb = bn;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { va[j] = van[j]; vb[j] = vbn[j]; }
+    }
+}
+__global__ __launch_bounds__(512) void gemm_nt16p_e0_kernel(GemmP p) {
+    __shared__ __attribute__((aligned(16))) char smem[131072];
+    nt16p_body<0>(p, smem);
+}
+__global__ __launch_bounds__(512) void gemm_nt16p_e9_kernel(GemmP p) {
+    __shared__ __attribute__((aligned(16))) char smem[131072];
+    nt16p_body<HS_EPI_BIAS | HS_EPI_RESID>(p, smem);
+}
+__global__ __launch_bounds__(512) void gemm_nt16p_e67_kernel(GemmP p) {
+    __shared__ __attribute__((aligned(16))) char smem[131072];
+    nt16p_body<HS_EPI_BIAS | HS_EPI_GELU | HS_EPI_SAVE_DGELU>(p, smem);
+}
+
+// ------------------------------------------------------------------------------------------------------
 // f32 (parity mode): 64x64x32 tile, 4 waves each one 32x32 block; k order inside a group of 8 is permuted
 // identically for A and B (lane half h takes k = 8s+4h+e for MFMA step e), which leaves the sum unchanged.
 // ------------------------------------------------------------------------------------------------------
@@ -1066,7 +1252,19 @@ extern "C" int hs_gemm(const hs_gemm_args* a, int prec, void* stream) {
     } while (0)
         const bool m16 = big && a->layout == HS_GEMM_NT && !a->colsum_out && getenv("HS_GEMM_NO_M16") == nullptr;   // (env: kbench A/B)
 #define HS_LAUNCH_M16(EF) hipLaunchKernelGGL((gemm_bf16_kernel<false, false, true, EF, true>), grid, dim3(512), 0, s, p)
-        if (m16 && col8 && (f == 0 || f == (HS_EPI_BIAS | HS_EPI_RESID) || f == (HS_EPI_BIAS | HS_EPI_GELU | HS_EPI_SAVE_DGELU))) {
+        p.nblocks = (int)grid.x;
+        static const int ncu = [] { int dev = 0, n = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+        // the persistent variant is a measured dead end kept for A/B runs (tools/kbench, HS_GEMM_PERSIST=1): it hides the block
+        // launch gap but the store issue of the epilogue stalls just as long
+        static const bool no_persist = getenv("HS_GEMM_PERSIST") == nullptr;
+        const bool m16_ok = m16 && col8 && (f == 0 || f == (HS_EPI_BIAS | HS_EPI_RESID) || f == (HS_EPI_BIAS | HS_EPI_GELU | HS_EPI_SAVE_DGELU));
+        if (m16_ok && zdim == 1 && a->K >= 192 && (int)grid.x > ncu && !no_persist && p.dbg != 1 && p.dbg != 2 && p.dbg != 4 && p.dbg != 7) {
+            // persistent: one block per CU, a multiple of 8 so that block b stays on XCD b % 8
+            dim3 pgrid((unsigned)(ncu & ~7), 1, 1);
+            if (f == 0) hipLaunchKernelGGL(gemm_nt16p_e0_kernel, pgrid, dim3(512), 0, s, p);
+            else if (f == (HS_EPI_BIAS | HS_EPI_RESID)) hipLaunchKernelGGL(gemm_nt16p_e9_kernel, pgrid, dim3(512), 0, s, p);
+            else hipLaunchKernelGGL(gemm_nt16p_e67_kernel, pgrid, dim3(512), 0, s, p);
+        } else if (m16_ok) {
             if (f == 0) HS_LAUNCH_M16(0);
             else if (f == (HS_EPI_BIAS | HS_EPI_RESID)) HS_LAUNCH_M16(HS_EPI_BIAS | HS_EPI_RESID);
             else HS_LAUNCH_M16(HS_EPI_BIAS | HS_EPI_GELU | HS_EPI_SAVE_DGELU);
