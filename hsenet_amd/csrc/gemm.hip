@@ -531,6 +531,16 @@ __device__ __forceinline__ void tile_order(int b, int nb, int tiles_m, int tiles
     tn = w / gm;
 }
 
+// lanes l and l ^ 8 (same 16-lane row) trade one 16-B piece: afterwards a (lanes & 15) < 8 lane holds {own a, partner's a} and the
+// others {partner's b, own b} -- see epilogue16
+__device__ __forceinline__ void half_line_swap(u32x4& a, u32x4& b, bool lo8) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const unsigned send = lo8 ? b[e] : a[e];
+        const unsigned got = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send, 0x128, 0xf, 0xf, false);   // row_ror:8
+        if (lo8) b[e] = got; else a[e] = got;
+    }
+}
 template <int EF>
 __device__ __forceinline__ void epilogue16(const GemmP& p, const f32x4 (&acc16)[8][4], int mw, int nw, long cz, int lane) {
     // ---- 16x16x32 form: the MFMAs ran with the operands SWAPPED (D' = B-tile x A-tile), so a lane holds, for output row
@@ -568,6 +578,8 @@ static_assert(EF >= 0, "the 16x16x32 kernels are launched with compile-time epil
             const int m = mw + 16 * i + l15;
             in[st] = m < p.M && n_in[jp];
             idx[st] = cz + (long)m * p.ldc + ncol[jp];
+            if (p.dbg == 9) idx[st] = (long)(blockIdx.x & 255) * 65536 + (m & 255) * 256 + (ncol[jp] & 255);   // diagnostic: 32 MiB of output, rewritten in place
+            if (p.dbg == 10) idx[st] = (long)blockIdx.x * 65536 + (m & 255) * 256 + (ncol[jp] & 255);         // diagnostic: tile-contiguous output
             vlo[st] = f32x4{0.f, 0.f, 0.f, 0.f};
             vhi[st] = vlo[st];
             if (want_res && in[st]) { vlo[st] = *(const f32x4*)(p.resid + idx[st]); vhi[st] = *(const f32x4*)(p.resid + idx[st] + 4); }
@@ -580,21 +592,54 @@ static_assert(EF >= 0, "the 16x16x32 kernels are launched with compile-time epil
             vhi[st] = epi_math(p, flags, 0, acc16[i][2 * jp + 1], vhi[st], u32x2{0u, 0u}, bias_hi[jp], alpha_n[jp], &k1);
             zb[st] = u32x4{k0[0], k0[1], k1[0], k1[1]};
         }
+        // bf16 outputs: a lane's two 16-B pieces of row l15 (column halves jp = 0, 1) are HALF lines, 16 rows x 64 B per store
+        // instruction -- streamed to memory that way they ran at half the rate of full lines (tools/micro/store_ctx: 118 vs 81 us
+        // for this GEMM's 377 MB).  Lanes l15 and l15 ^ 8 swap one piece each (DPP row_ror:8), after which instruction A holds rows
+        // 0-7 and instruction B rows 8-15 of the 16-row tile as full 128-B lines.
+        const bool lo8 = l15 < 8;
 #pragma unroll
-        for (int st = 0; st < 4; ++st) {
-            if (!in[st]) continue;
-            if (p.dbg == 3 || p.dbg == 7) { keep4(vlo[st]); keep4(vhi[st]); continue; }
-            u32x4 o;
-            o[0] = pack2bf(vlo[st][0], vlo[st][1]); o[1] = pack2bf(vlo[st][2], vlo[st][3]);
-            o[2] = pack2bf(vhi[st][0], vhi[st][1]); o[3] = pack2bf(vhi[st][2], vhi[st][3]);
-            if (p.nt) {
-                if ((flags & HS_EPI_GELU) && p.aux_out) __builtin_nontemporal_store(zb[st], (u32x4*)((bf16_t*)p.aux_out + idx[st]));
-                if (p.out_f32) { __builtin_nontemporal_store(vlo[st], (f32x4*)(p.out_f32 + idx[st])); __builtin_nontemporal_store(vhi[st], (f32x4*)(p.out_f32 + idx[st] + 4)); }
-                if (p.out_bf16) __builtin_nontemporal_store(o, (u32x4*)((bf16_t*)p.out_bf16 + idx[st]));
-            } else {
-                if ((flags & HS_EPI_GELU) && p.aux_out) *(u32x4*)((bf16_t*)p.aux_out + idx[st]) = zb[st];
-                if (p.out_f32) { *(f32x4*)(p.out_f32 + idx[st]) = vlo[st]; *(f32x4*)(p.out_f32 + idx[st] + 4) = vhi[st]; }
-                if (p.out_bf16) *(u32x4*)((bf16_t*)p.out_bf16 + idx[st]) = o;
+        for (int ii = 0; ii < 2; ++ii) {
+            const int i = 2 * g + ii, s0 = 2 * ii, s1 = 2 * ii + 1;
+            if (p.dbg == 3 || p.dbg == 7) { keep4(vlo[s0]); keep4(vhi[s0]); keep4(vlo[s1]); keep4(vhi[s1]); continue; }
+            if (p.out_f32) {   // fp32 rows are full lines already (8 columns x 4 B x 4 lanes)
+#pragma unroll
+                for (int st = s0; st <= s1; ++st)
+                    if (in[st]) {
+                        if (p.nt) { __builtin_nontemporal_store(vlo[st], (f32x4*)(p.out_f32 + idx[st])); __builtin_nontemporal_store(vhi[st], (f32x4*)(p.out_f32 + idx[st] + 4)); }
+                        else { *(f32x4*)(p.out_f32 + idx[st]) = vlo[st]; *(f32x4*)(p.out_f32 + idx[st] + 4) = vhi[st]; }
+                    }
+            }
+            const bool want_aux = (flags & HS_EPI_GELU) && p.aux_out;
+            if (p.out_bf16 || want_aux) {
+                const int mA = mw + 16 * i + (l15 & 7), mB = mA + 8, nAB = nw + 32 * (l15 >> 3) + 8 * q;
+                const bool inA = mA < p.M && nAB < p.N, inB = mB < p.M && nAB < p.N;
+                const long idxA = cz + (long)mA * p.ldc + nAB, idxB = idxA + 8 * p.ldc;
+                if (p.out_bf16) {
+                    u32x4 o0, o1;
+                    o0[0] = pack2bf(vlo[s0][0], vlo[s0][1]); o0[1] = pack2bf(vlo[s0][2], vlo[s0][3]);
+                    o0[2] = pack2bf(vhi[s0][0], vhi[s0][1]); o0[3] = pack2bf(vhi[s0][2], vhi[s0][3]);
+                    o1[0] = pack2bf(vlo[s1][0], vlo[s1][1]); o1[1] = pack2bf(vlo[s1][2], vlo[s1][3]);
+                    o1[2] = pack2bf(vhi[s1][0], vhi[s1][1]); o1[3] = pack2bf(vhi[s1][2], vhi[s1][3]);
+                    half_line_swap(o0, o1, lo8);
+                    if (p.nt) {
+                        if (inA) __builtin_nontemporal_store(o0, (u32x4*)((bf16_t*)p.out_bf16 + idxA));
+                        if (inB) __builtin_nontemporal_store(o1, (u32x4*)((bf16_t*)p.out_bf16 + idxB));
+                    } else {
+                        if (inA) *(u32x4*)((bf16_t*)p.out_bf16 + idxA) = o0;
+                        if (inB) *(u32x4*)((bf16_t*)p.out_bf16 + idxB) = o1;
+                    }
+                }
+                if (want_aux) {
+                    u32x4 z0 = zb[s0], z1 = zb[s1];
+                    half_line_swap(z0, z1, lo8);
+                    if (p.nt) {
+                        if (inA) __builtin_nontemporal_store(z0, (u32x4*)((bf16_t*)p.aux_out + idxA));
+                        if (inB) __builtin_nontemporal_store(z1, (u32x4*)((bf16_t*)p.aux_out + idxB));
+                    } else {
+                        if (inA) *(u32x4*)((bf16_t*)p.aux_out + idxA) = z0;
+                        if (inB) *(u32x4*)((bf16_t*)p.aux_out + idxB) = z1;
+                    }
+                }
             }
         }
     }
