@@ -565,24 +565,42 @@ static_assert(EF >= 0, "the 16x16x32 kernels are launched with compile-time epil
         bias_hi[jp] = bias_lo[jp];
         if ((flags & HS_EPI_BIAS) && n_in[jp]) { bias_lo[jp] = *(const f32x4*)(p.bias + ncol[jp]); bias_hi[jp] = *(const f32x4*)(p.bias + ncol[jp] + 4); }
     }
-    // groups of 4 steps (two 16-row tiles x two column halves): all loads in flight -> all math -> all stores (see epi_math)
+    // groups of 4 steps (two 16-row tiles x two column halves): all loads in flight -> all math -> all stores (see epi_math).
+    // The residual loads are software-pipelined one group ahead and UNCONDITIONAL (a row outside the matrix reads element 0
+    // and is never stored): straight-line code, so hipcc retires them with counted vmcnt instead of draining the stores too.
+    f32x4 rlo[2][4], rhi[2][4];
+    auto load_res = [&](auto g_tag) {
+        constexpr int G = decltype(g_tag)::value;
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            const int i = 2 * G + (st >> 1), jp = st & 1;
+            const int m = mw + 16 * i + l15;
+            const long ix = (m < p.M && n_in[jp]) ? cz + (long)m * p.ldc + ncol[jp] : 0l;
+            rlo[G & 1][st] = *(const f32x4*)(p.resid + ix);
+            rhi[G & 1][st] = *(const f32x4*)(p.resid + ix + 4);
+        }
+    };
+    if (want_res) load_res(std::integral_constant<int, 0>{});
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         f32x4 vlo[4], vhi[4];
         u32x4 zb[4];
         bool in[4];
         long idx[4];
+        if (want_res) {
+            if (g == 0) load_res(std::integral_constant<int, 1>{});
+            if (g == 1) load_res(std::integral_constant<int, 2>{});
+            if (g == 2) load_res(std::integral_constant<int, 3>{});
+        }
 #pragma unroll
         for (int st = 0; st < 4; ++st) {
             const int i = 2 * g + (st >> 1), jp = st & 1;
             const int m = mw + 16 * i + l15;
             in[st] = m < p.M && n_in[jp];
             idx[st] = cz + (long)m * p.ldc + ncol[jp];
-            if (p.dbg == 9) idx[st] = (long)(blockIdx.x & 255) * 65536 + (m & 255) * 256 + (ncol[jp] & 255);   // diagnostic: 32 MiB of output, rewritten in place
-            if (p.dbg == 10) idx[st] = (long)blockIdx.x * 65536 + (m & 255) * 256 + (ncol[jp] & 255);         // diagnostic: tile-contiguous output
             vlo[st] = f32x4{0.f, 0.f, 0.f, 0.f};
             vhi[st] = vlo[st];
-            if (want_res && in[st]) { vlo[st] = *(const f32x4*)(p.resid + idx[st]); vhi[st] = *(const f32x4*)(p.resid + idx[st] + 4); }
+            if (want_res) { vlo[st] = rlo[g & 1][st]; vhi[st] = rhi[g & 1][st]; }
         }
 #pragma unroll
         for (int st = 0; st < 4; ++st) {
@@ -817,7 +835,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmP p) {
                     bias_lo = *(const f32x4*)(p.bias + n);
                     bias_hi = *(const f32x4*)(p.bias + n + 4);
                 }
-                constexpr int GS = BIG ? 2 : 4;
+                // (an epilogue that LOADS -- residual, saved gelu' -- keeps 4 steps of loads in flight even on the big tile: with 2, a
+                // tile pays the HBM round trip 16 times)
+                constexpr int GS = (BIG && !(EF >= 0 && (EF & (HS_EPI_GELU_BWD | HS_EPI_RESID)))) ? 2 : 4;
                 // groups of GS steps: all loads in flight -> all math -> all stores (see epi_math).  The 256x256 tile still holds
                 // 64-128 accumulator registers here: smaller groups keep the epilogue out of scratch (a reload is a memory round trip)
 #pragma unroll 1

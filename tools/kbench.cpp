@@ -203,7 +203,10 @@ int main(int argc, char** argv) {
             {"fc2 NT", HS_GEMM_NT, M, 768, 3072, 0}, {"dgrad fc2 NN", HS_GEMM_NN, M, 3072, 768, 0}, {"dgrad fc1 NN", HS_GEMM_NN, M, 768, 3072, 0},
             {"dgrad qkv NN", HS_GEMM_NN, M, 768, 2304, 0}, {"dgrad proj NN", HS_GEMM_NN, M, 768, 768, 0},
             {"wgrad fc1 TN", HS_GEMM_TN, 3072, 768, M, 0}, {"wgrad fc2 TN", HS_GEMM_TN, 768, 3072, M, 0}, {"wgrad qkv TN", HS_GEMM_TN, 2304, 768, M, 0},
-            {"wgrad proj TN", HS_GEMM_TN, 768, 768, M, 0}, {"sq NT 4096", HS_GEMM_NT, 4096, 4096, 4096, 0}, {"sq NT 8192", HS_GEMM_NT, 8192, 8192, 8192, 0}};
+            {"wgrad proj TN", HS_GEMM_TN, 768, 768, M, 0}, {"sq NT 4096", HS_GEMM_NT, 4096, 4096, 4096, 0}, {"sq NT 8192", HS_GEMM_NT, 8192, 8192, 8192, 0},
+            // the fused epilogues of the encoder layer, as vit.hip launches them
+            {"fc1+gelu NT epi", HS_GEMM_NT, M, 3072, 768, HS_EPI_BIAS | HS_EPI_GELU | HS_EPI_SAVE_DGELU}, {"fc2+resid NT epi", HS_GEMM_NT, M, 768, 3072, HS_EPI_BIAS | HS_EPI_RESID},
+            {"proj+resid NT epi", HS_GEMM_NT, M, 768, 768, HS_EPI_BIAS | HS_EPI_RESID}, {"dgrad fc2 gelu' NN epi", HS_GEMM_NN, M, 3072, 768, HS_EPI_GELU_BWD | HS_EPI_SAVE_DGELU}};
         for (const Sh& s : shapes) {
             if (*filt && !strstr(s.name, filt)) continue;
             const bool tn = s.lay == HS_GEMM_TN;
@@ -225,10 +228,18 @@ int main(int argc, char** argv) {
                 }
                 if (getenv("HS_SPLITK")) a.split_k = atoi(getenv("HS_SPLITK"));
             } else a.out_bf16 = out;
+            void *e_bias = nullptr, *e_res = nullptr, *e_aux = nullptr;
+            if (s.flags) {
+                a.flags = s.flags;
+                if (s.flags & HS_EPI_BIAS) { e_bias = dev_zero((size_t)s.n * 4); a.bias = (const float*)e_bias; }
+                if (s.flags & HS_EPI_RESID) { e_res = dev_zero((size_t)s.m * s.n * 4); a.resid = (const float*)e_res; a.out_bf16 = nullptr; a.out_f32 = (float*)out; }
+                if (s.flags & HS_EPI_GELU) { e_aux = dev_zero((size_t)s.m * s.n * 2); a.aux_out = e_aux; }
+                if (s.flags & HS_EPI_GELU_BWD) { e_aux = dev_bf16_gauss((size_t)s.m * s.n, 0.5f); a.aux = e_aux; }
+            }
             int rc = gemm(&a, HS_PREC_BF16, 0);
             if (rc) { printf("%s rc=%d\n", s.name, rc); continue; }
             CK(hipDeviceSynchronize());
-            if (getenv("HS_GEMM_AB") && !tn) {       // A/B: the same GEMM with the 16x16x32 main loop toggled (HS_GEMM_NO_M16) must agree (both accumulate in f32)
+            if (getenv("HS_GEMM_AB") && !tn && !s.flags) {       // A/B: the same GEMM with the 16x16x32 main loop toggled (HS_GEMM_NO_M16) must agree (both accumulate in f32)
                 void* out2 = dev_zero((size_t)s.m * s.n * 2);
                 hs_gemm_args a2 = a; a2.out_bf16 = out2;
                 const bool had = getenv("HS_GEMM_NO_M16") != nullptr;
@@ -269,6 +280,9 @@ int main(int argc, char** argv) {
             }
             fflush(stdout);
             CK(hipFree(A)); CK(hipFree(Bm)); CK(hipFree(out));
+            if (e_bias) CK(hipFree(e_bias));
+            if (e_res) CK(hipFree(e_res));
+            if (e_aux) CK(hipFree(e_aux));
         }
         return 0;
     }
