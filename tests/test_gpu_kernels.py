@@ -544,3 +544,41 @@ def test_dropout_backward_uses_forward_mask(dev):
     f = lambda t: (Fn.WindowAttnFn.apply(t, kvw, (2, 4, 4), (1, 4, 4), 0.25, 99, 1) * ww).sum().item()
     fd = (f(qw + d) - f(qw - d)) / (2 * eps)
     assert abs(fd - qg.grad[0, 1, 5].item()) < 2e-3 * max(1.0, abs(fd)), (fd, qg.grad[0, 1, 5].item())
+
+
+# ---- the 256x256-tile kernels (grid >= 230 blocks): transposed-accumulator register epilogue (NT), staged epilogue (NN), ragged last
+# row tile, streaming stores on (>= 64 MiB of output) and off ----
+@pytest.mark.gpu
+def test_gemm_big_tile_paths(dev):
+    from hsenet_amd import functional as Fn, _lib as L
+    M, N, K = 16400, 1024, 192                       # 65 x 4 tiles, the last row tile holds 16 rows
+    a = rnd((M, K), 21, dev).bfloat16()
+    w = rnd((N, K), 22, dev).bfloat16()
+    bias, resid = rnd((N,), 23, dev), rnd((M, N), 24, dev)
+    acc = (a.double() @ w.double().t())
+    # NT, no flags, the first 256 columns carry an extra factor (the qkv GEMM's q third); 33 MB of output: ordinary stores
+    o16 = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev)
+    Fn.gemm(a, w, L.GEMM_NT, prec=L.PREC_BF16, out_bf16=o16, scale_cols=256, scale_cols_alpha=0.25)
+    want = acc.clone(); want[:, :256] *= 0.25
+    # one rounding of an fp32 sum: equal to the rounded fp64 result except where the summation order tips a tie (a few per million)
+    assert (o16 != want.float().bfloat16()).float().mean().item() < 1e-3 and rel(o16.float(), want) < 3e-3
+    # NT bias + residual -> fp32, 67 MB: streaming stores
+    o32 = torch.full((M, N), float("nan"), device=dev)
+    Fn.gemm(a, w, L.GEMM_NT, prec=L.PREC_BF16, out_f32=o32, bias=bias, resid=resid, flags=L.EPI_BIAS | L.EPI_RESID)
+    assert rel(o32, acc + bias.double() + resid.double()) < 1e-6
+    # NT bias + GELU, keeping gelu'(z): two bf16 outputs, 67 MB together
+    g16 = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev)
+    Fn.gemm(a, w, L.GEMM_NT, prec=L.PREC_BF16, out_bf16=o16, bias=bias, aux_out=g16, flags=L.EPI_BIAS | L.EPI_GELU | L.EPI_SAVE_DGELU)
+    z = (acc + bias.double()).float().bfloat16().float()                 # autocast: linear1 emits bf16
+    zq = z.double().requires_grad_()
+    (gq,) = torch.autograd.grad(F.gelu(zq).sum(), zq)
+    assert rel(o16.float(), F.gelu(z)) < 3e-3 and rel(g16.float(), gq) < 3e-3
+    assert not torch.isnan(o16.float()).any() and not torch.isnan(g16.float()).any()
+    # NN (dgrad): dy [M, N] @ w [N, K'] with K' = 1024 wide output needs its own operands
+    dy = rnd((M, 256), 25, dev).bfloat16()
+    w2 = rnd((256, N), 26, dev).bfloat16()                                # stored [K=256][N]
+    acc2 = dy.double() @ w2.double()
+    Fn.gemm(dy, w2, L.GEMM_NN, prec=L.PREC_BF16, out_f32=o32)
+    assert rel(o32, acc2) < 1e-6
+    Fn.gemm(dy, w2, L.GEMM_NN, prec=L.PREC_BF16, out_bf16=o16, aux=g16, flags=L.EPI_GELU_BWD | L.EPI_SAVE_DGELU)
+    assert rel(o16.float(), acc2 * g16.double()) < 3e-3
