@@ -21,7 +21,10 @@ struct GemmP {
     int scale_cols; float scale_alpha;     // columns n < scale_cols carry the extra factor scale_alpha
     int nt;                                // streaming (nontemporal) output stores, see hs_gemm
     int nblocks;                           // tiles_m * tiles_n * zdim (the persistent kernel walks them with stride gridDim.x)
-    int dbg;                               // diagnostic (tools/kbench): 1 = skip the epilogue, 2 = one K-tile only
+    // diagnostic (tools/kbench, HS_GEMM_DBG): 1 = skip the epilogue, 2 = one K-tile only, 3 = epilogue without its stores, 4 = s_memtime
+    // phase sums (hs_debug_gemm_stamps), 5 = every K-tile re-reads the first (cache hits), 7 = 3 + 4, 22 = per-block timeline
+    // (hs_debug_gemm_trace).  0 in production.
+    int dbg;
 };
 
 template <bool F32AUX>
@@ -1059,10 +1062,6 @@ __device__ __forceinline__ void nt16p_body(const GemmP& p, char* smem) {
     for (int j = 0; j < 4; ++j) {
         va[j] = dma_voff<false, true>(j, tm * 256, p.M, 0, 64, p.lda, wave, lane);
         vb[j] = dma_voff<false, true, true>(j, tn * 256, p.N, 0, 64, p.ldb, wave, lane);
-    }
-    if (p.dbg >= 11 && p.dbg <= 14) {   // diagnostic: de-phase the blocks of an XCD (4 phases)
-        const unsigned long long t0_ = __builtin_amdgcn_s_memtime(), wait_ = (unsigned long long)((blockIdx.x >> 3) & 3) * (unsigned long long)(p.dbg - 10) * 4000ull;
-        while (__builtin_amdgcn_s_memtime() - t0_ < wait_) __builtin_amdgcn_s_sleep(16);
     }
     dmaA(va, 0, 0u); dmaB(vb, 0, 0u);
     dmaA(va, 1, (unsigned)STAGE); dmaB(vb, 1, (unsigned)STAGE);
