@@ -10,6 +10,7 @@
 #include "common.h"
 #include <stdlib.h>
 #include <type_traits>
+#include <utility>
 
 struct GemmP {
     const void* A; const void* B;
@@ -104,6 +105,17 @@ __device__ __forceinline__ unsigned dma_voff(int j, int dim0, int DIM, int k0, i
 }
 __device__ __forceinline__ void dma_piece(__amdgpu_buffer_rsrc_t rs, char* lds_area, int j, int wave, unsigned voff, unsigned soff) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (LDS_PTR(void))(lds_area + (j * 8 + wave) * 1024), 16, voff, soff, 0, 0);
+}
+// the same images filled by a 4-wave block (gemm_nt16w): piece j of a wave is piece index j*4 + wave, 8 pieces per operand per wave
+template <bool PERMN>
+__device__ __forceinline__ unsigned dma_voff4(int j, int dim0, int DIM, long ld, int wave, int lane) {
+    const int row = (j * 4 + wave) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ swzR16(row);
+    const int gi = dim0 + (PERMN ? permN(row) : row);
+    return gi < DIM ? (unsigned)(((long)gi * ld + c * 8) * 2) : HS_OOB_OFF;
+}
+__device__ __forceinline__ void dma_piece4(__amdgpu_buffer_rsrc_t rs, char* lds_area, int j, int wave, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (LDS_PTR(void))(lds_area + (j * 4 + wave) * 1024), 16, voff, soff, 0, 0);
 }
 // fragment of the 32-wide block starting at `sub` (0..255) of an operand image, k-step ks
 #ifdef HS_ABLATE_TR   // ablation build only: read T images with plain row reads (wrong data, same bytes)
@@ -544,8 +556,8 @@ __device__ __forceinline__ void half_line_swap(u32x4& a, u32x4& b, bool lo8) {
         if (lo8) b[e] = got; else a[e] = got;
     }
 }
-template <int EF>
-__device__ __forceinline__ void epilogue16(const GemmP& p, const f32x4 (&acc16)[8][4], int mw, int nw, long cz, int lane) {
+template <int EF, int NJ = 4, int J0 = 0>
+__device__ __forceinline__ void epilogue16(const GemmP& p, const f32x4 (&acc16)[8][NJ], int mw, int nw, long cz, int lane) {
     // ---- 16x16x32 form: the MFMAs ran with the operands SWAPPED (D' = B-tile x A-tile), so a lane holds, for output row
     // m = 16 i + (lane & 15), the columns 16 j + 4 (lane >> 4) + r of the B IMAGE -- which permN laid out so that tiles
     // 2jp, 2jp+1 together are the 8 consecutive matrix columns 32 jp + 8 (lane >> 4) .. +7.  The epilogue therefore runs
@@ -609,8 +621,8 @@ static_assert(EF >= 0, "the 16x16x32 kernels are launched with compile-time epil
         for (int st = 0; st < 4; ++st) {
             const int i = 2 * g + (st >> 1), jp = st & 1;
             u32x2 k0 = {0u, 0u}, k1 = {0u, 0u};
-            vlo[st] = epi_math(p, flags, 0, acc16[i][2 * jp], vlo[st], u32x2{0u, 0u}, bias_lo[jp], alpha_n[jp], &k0);
-            vhi[st] = epi_math(p, flags, 0, acc16[i][2 * jp + 1], vhi[st], u32x2{0u, 0u}, bias_hi[jp], alpha_n[jp], &k1);
+            vlo[st] = epi_math(p, flags, 0, acc16[i][J0 + 2 * jp], vlo[st], u32x2{0u, 0u}, bias_lo[jp], alpha_n[jp], &k0);
+            vhi[st] = epi_math(p, flags, 0, acc16[i][J0 + 2 * jp + 1], vhi[st], u32x2{0u, 0u}, bias_hi[jp], alpha_n[jp], &k1);
             zb[st] = u32x4{k0[0], k0[1], k1[0], k1[1]};
         }
         // bf16 outputs: a lane's two 16-B pieces of row l15 (column halves jp = 0, 1) are HALF lines, 16 rows x 64 B per store
@@ -1151,6 +1163,170 @@ __global__ __launch_bounds__(512) void gemm_nt16p_e67_kernel(GemmP p) {
 }
 
 // ------------------------------------------------------------------------------------------------------
+// 256x256 NT tile on FOUR waves (2 x 2, wave tile 128x128 = 8 x 8 tiles of 16x16x32, one wave per SIMD, 256 accumulator
+// registers).  Why: with eight waves of 128x64 every K-tile costs the CU's LDS port 192 KiB of fragment reads + 64 KiB of DMA
+// writes = 2048 cycles at 128 B/clk -- exactly the 2048 MFMA cycles of the K-tile, so the eight-wave loop is LDS-bound by
+// construction (measured: 73 % MFMA-busy in the main loop).  The 128x128 wave tile reuses every fragment twice as often:
+// 128 + 64 KiB = 1536 cycles.  Same images, same swapped-operand accumulator and register epilogue as gemm_bf16_kernel<M16>.
+//   per K-tile (stage so), four phases of 32 MFMAs; a phase = wait for the reads issued one phase ago (lgkmcnt(0): they had 512
+//   MFMA cycles), issue the next phase's reads (never more than 12 in flight), MFMAs with the DMA pieces spread between them:
+//     P0 (k 0-31, rows 0-63)     reads A(k 0-31, rows 64-127)
+//     P1 (k 0-31, rows 64-127)   reads A(k 32-63, rows 0-63), B(k 32-63)
+//     P2 (k 32-63, rows 0-63)    reads A(k 32-63, rows 64-127)
+//     lgkmcnt(0), vmcnt(0), s_barrier
+//     P3 (k 32-63, rows 64-127)  reads of tile t+1: A(k 0-31, rows 0-63), B(k 0-31)   DMA: all 16 pieces of tile t+2 -> this stage
+//   (the DMA runs a full K-tile ahead; issued in P0 as in the eight-wave loop, the B pieces were late at the tile barrier)
+// ------------------------------------------------------------------------------------------------------
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+// the 256 accumulator registers of the 128x128 wave tile are pinned to AGPRs ("+a"): left to the register allocator, part of
+// them lives in VGPRs and 96 v_accvgpr copies per K-tile shuttle them back and forth
+__device__ __forceinline__ void mfma16_agpr(f32x4& c, const u32x4& b, const u32x4& a) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(b), "v"(a));
+}
+template <int EF>
+__device__ __forceinline__ void nt16w_body(const GemmP& p, char* smem) {
+    constexpr int STAGE = 65536;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int row0 = (wave >> 1) * 128, col0 = (wave & 1) * 128;
+    int tm, tn, z;
+    tile_order(blockIdx.x, gridDim.x, p.tiles_m, p.tiles_n, tm, tn, z);
+    const int m0 = tm * 256, n0 = tn * 256;
+    const bf16_t* A = (const bf16_t*)p.A + z * p.sA;
+    const bf16_t* B = (const bf16_t*)p.B + z * p.sB;
+    const long cz = z * p.sC;
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(A, (size_t)p.M * p.lda * 2);
+    const __amdgpu_buffer_rsrc_t rsB = make_rsrc(B, (size_t)p.N * p.ldb * 2);
+    const int KT = p.dbg == 2 ? 1 : (p.K >> 6);
+    if (p.dbg == 22 && tid == 0 && blockIdx.x < 4096) {
+        g_gemm_trace[blockIdx.x * 4 + 0] = __builtin_amdgcn_s_memtime();
+        g_gemm_trace[blockIdx.x * 4 + 3] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+    }
+    unsigned va[8], vb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        va[j] = dma_voff4<false>(j, m0, p.M, p.lda, wave, lane);
+        vb[j] = dma_voff4<true>(j, n0, p.N, p.ldb, wave, lane);
+    }
+    const int r = lane & 15, q = lane >> 4, f = swzR16(r);
+    unsigned ab0[2], bb0[2];
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+        ab0[st] = lds_off(smem) + (row0 + r) * 128 + (((4 * st + q) ^ f) << 4);
+        bb0[st] = lds_off(smem) + 32768 + (col0 + r) * 128 + (((4 * st + q) ^ f) << 4);
+    }
+    u32x4 fa[2][4], fb[2][8];
+    f32x4 acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto settle_all = [&]() {   // every LDS read issued so far has landed; the fragment registers are pinned below the wait
+        lds_wait8g<0>(fa[0][0], fa[0][1], fa[0][2], fa[0][3], fa[1][0], fa[1][1], fa[1][2], fa[1][3]);
+        lds_wait8g<0>(fb[0][0], fb[0][1], fb[0][2], fb[0][3], fb[0][4], fb[0][5], fb[0][6], fb[0][7]);
+        lds_wait8g<0>(fb[1][0], fb[1][1], fb[1][2], fb[1][3], fb[1][4], fb[1][5], fb[1][6], fb[1][7]);
+    };
+    // prologue: K-tile 0 -> stage 0, K-tile 1 -> stage 1
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dma_piece4(rsA, smem, j, wave, va[j], 0u);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dma_piece4(rsB, smem + 32768, j, wave, vb[j], 0u);
+    if (KT > 1) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dma_piece4(rsA, smem + STAGE, j, wave, va[j], 128u);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dma_piece4(rsB, smem + STAGE + 32768, j, wave, vb[j], 128u);
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    {
+        const unsigned a = ab0[0], b = bb0[0];
+        ldsr128<0>(fa[0][0], a); ldsr128<2048>(fa[0][1], a); ldsr128<4096>(fa[0][2], a); ldsr128<6144>(fa[0][3], a);
+        ldsr128<0>(fb[0][0], b); ldsr128<2048>(fb[0][1], b); ldsr128<4096>(fb[0][2], b); ldsr128<6144>(fb[0][3], b);
+        ldsr128<8192>(fb[0][4], b); ldsr128<10240>(fb[0][5], b); ldsr128<12288>(fb[0][6], b); ldsr128<14336>(fb[0][7], b);
+    }
+    unsigned so = 0;
+    for (int kt = 0; kt < KT; ++kt) {
+        const bool has1 = kt + 1 < KT, has2 = kt + 2 < KT;
+        const unsigned so1 = so ^ (unsigned)STAGE;
+        const unsigned k2 = (unsigned)(kt + 2) * 128u;
+        // One non-MFMA instruction behind each MFMA (the matrix pipe takes a new 16x16x32 every 16 cycles: an LDS read or a DMA piece
+        // issues in that shadow; with one wave per SIMD whatever is issued in bulk between MFMA groups is exposed).  MFMA X of a phase =
+        // A tile X / 8 of the phase's row half x B tile X % 8.
+        // P0: k 0-31, rows 0-63 (fa[0], fb[0]); reads A(k 0-31, rows 64-127) -> fa[1]
+        settle_all();
+        static_for<32>([&](auto x_tag) {
+            constexpr int X = decltype(x_tag)::value;
+            mfma16_agpr(acc[X >> 3][X & 7], fb[0][X & 7], fa[0][X >> 3]);
+            if constexpr (X < 4) ldsr128<(4 + X) * 2048>(fa[1][X], ab0[0] + so);
+            SB();
+        });
+        // P1: k 0-31, rows 64-127 (fa[1], fb[0]); reads A(k 32-63, rows 0-63) -> fa[0], B(k 32-63) -> fb[1]
+        settle_all();
+        static_for<32>([&](auto x_tag) {
+            constexpr int X = decltype(x_tag)::value;
+            mfma16_agpr(acc[4 + (X >> 3)][X & 7], fb[0][X & 7], fa[1][X >> 3]);
+            if constexpr (X < 4) ldsr128<X * 2048>(fa[0][X], ab0[1] + so);
+            else if constexpr (X < 12) ldsr128<(X - 4) * 2048>(fb[1][X - 4], bb0[1] + so);
+            SB();
+        });
+        // P2: k 32-63, rows 0-63 (fa[0], fb[1]); reads A(k 32-63, rows 64-127) -> fa[1]
+        settle_all();
+        static_for<32>([&](auto x_tag) {
+            constexpr int X = decltype(x_tag)::value;
+            mfma16_agpr(acc[X >> 3][X & 7], fb[1][X & 7], fa[0][X >> 3]);
+            if constexpr (X < 4) ldsr128<(4 + X) * 2048>(fa[1][X], ab0[1] + so);
+            SB();
+        });
+        settle_all();                                      // every read of this stage has landed
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile kt+1 has landed
+        __builtin_amdgcn_s_barrier();
+        SB();
+        // P3: k 32-63, rows 64-127 (fa[1], fb[1]); reads of tile kt+1: A(k 0-31, rows 0-63) -> fa[0], B(k 0-31) -> fb[0];
+        //     DMA: the 16 pieces of tile kt+2 -> this stage
+        static_for<32>([&](auto x_tag) {
+            constexpr int X = decltype(x_tag)::value;
+            mfma16_agpr(acc[4 + (X >> 3)][X & 7], fb[1][X & 7], fa[1][X >> 3]);
+            if constexpr (X < 4) { if (has1) ldsr128<X * 2048>(fa[0][X], ab0[0] + so1); }
+            else if constexpr (X < 12) { if (has1) ldsr128<(X - 4) * 2048>(fb[0][X - 4], bb0[0] + so1); }
+            else if constexpr (X < 20) { if (has2) dma_piece4(rsA, smem + so, X - 12, wave, va[X - 12], k2); }
+            else if constexpr (X < 28) { if (has2) dma_piece4(rsB, smem + so + 32768, X - 20, wave, vb[X - 20], k2); }
+            SB();
+        });
+        so = so1;
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // the asm MFMAs are opaque to the hazard recogniser: let the last ones retire
+    if (p.dbg == 22 && tid == 0 && blockIdx.x < 4096) g_gemm_trace[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memtime();
+    if (p.dbg == 1) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) keep4(acc[i][j]);
+        return;
+    }
+    epilogue16<EF, 8, 0>(p, acc, m0 + row0, n0 + col0, cz, lane);
+    epilogue16<EF, 8, 4>(p, acc, m0 + row0, n0 + col0 + 64, cz, lane);
+    if (p.dbg == 22 && tid == 0 && blockIdx.x < 4096) g_gemm_trace[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memtime();
+}
+__global__ __launch_bounds__(256) void gemm_nt16w_e0_kernel(GemmP p) {
+    __shared__ __attribute__((aligned(16))) char smem[131072];
+    nt16w_body<0>(p, smem);
+}
+__global__ __launch_bounds__(256) void gemm_nt16w_e9_kernel(GemmP p) {
+    __shared__ __attribute__((aligned(16))) char smem[131072];
+    nt16w_body<HS_EPI_BIAS | HS_EPI_RESID>(p, smem);
+}
+__global__ __launch_bounds__(256) void gemm_nt16w_e67_kernel(GemmP p) {
+    __shared__ __attribute__((aligned(16))) char smem[131072];
+    nt16w_body<HS_EPI_BIAS | HS_EPI_GELU | HS_EPI_SAVE_DGELU>(p, smem);
+}
+
+// ------------------------------------------------------------------------------------------------------
 // f32 (parity mode): 64x64x32 tile, 4 waves each one 32x32 block; k order inside a group of 8 is permuted
 // identically for A and B (lane half h takes k = 8s+4h+e for MFMA step e), which leaves the sum unchanged.
 // ------------------------------------------------------------------------------------------------------
@@ -1321,6 +1497,7 @@ extern "C" int hs_gemm(const hs_gemm_args* a, int prec, void* stream) {
         // the persistent variant is a measured dead end kept for A/B runs (tools/kbench, HS_GEMM_PERSIST=1): it hides the block
         // launch gap but the store issue of the epilogue stalls just as long
         static const bool no_persist = getenv("HS_GEMM_PERSIST") == nullptr;
+        const bool w4 = getenv("HS_GEMM_W4") != nullptr && p.dbg != 4 && p.dbg != 7;
         const bool m16_ok = m16 && col8 && (f == 0 || f == (HS_EPI_BIAS | HS_EPI_RESID) || f == (HS_EPI_BIAS | HS_EPI_GELU | HS_EPI_SAVE_DGELU));
         if (m16_ok && zdim == 1 && a->K >= 192 && (int)grid.x > ncu && !no_persist && p.dbg != 1 && p.dbg != 2 && p.dbg != 4 && p.dbg != 7) {
             // persistent: one block per CU, a multiple of 8 so that block b stays on XCD b % 8
@@ -1328,6 +1505,10 @@ extern "C" int hs_gemm(const hs_gemm_args* a, int prec, void* stream) {
             if (f == 0) hipLaunchKernelGGL(gemm_nt16p_e0_kernel, pgrid, dim3(512), 0, s, p);
             else if (f == (HS_EPI_BIAS | HS_EPI_RESID)) hipLaunchKernelGGL(gemm_nt16p_e9_kernel, pgrid, dim3(512), 0, s, p);
             else hipLaunchKernelGGL(gemm_nt16p_e67_kernel, pgrid, dim3(512), 0, s, p);
+        } else if (m16_ok && w4) {
+            if (f == 0) hipLaunchKernelGGL(gemm_nt16w_e0_kernel, grid, dim3(256), 0, s, p);
+            else if (f == (HS_EPI_BIAS | HS_EPI_RESID)) hipLaunchKernelGGL(gemm_nt16w_e9_kernel, grid, dim3(256), 0, s, p);
+            else hipLaunchKernelGGL(gemm_nt16w_e67_kernel, grid, dim3(256), 0, s, p);
         } else if (m16_ok) {
             if (f == 0) HS_LAUNCH_M16(0);
             else if (f == (HS_EPI_BIAS | HS_EPI_RESID)) HS_LAUNCH_M16(HS_EPI_BIAS | HS_EPI_RESID);
