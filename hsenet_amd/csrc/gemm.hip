@@ -1474,12 +1474,14 @@ extern "C" int hs_gemm(const hs_gemm_args* a, int prec, void* stream) {
     ProfScope prof(HS_PROF_GEMM_NT + a->layout, stream, 2.0 * mnk,
                    ((double)a->M * a->K + (double)a->N * a->K) * a->batch * esz + (double)a->M * a->N * a->batch * (a->out_f32 ? 4 : 2));
     if (prec == HS_PREC_BF16) {
-        // tile choice: the 256x256 tile does twice the MFMA work per barrier / DMA piece / LDS read; use it when the
-        // grid still fills the chip (>= ~0.9 round of 256 CUs), else the 256x128 tile
+        // tile choice: the 256x256 tile does twice the MFMA work per barrier / DMA piece / LDS read.  Measured on the layer's shapes
+        // at 1-4 volumes (4097-16388 rows): it wins by 4-28 % as soon as the 256x128 tile would need a second round of the chip's CUs
+        // (more than ncu/2 big tiles), and loses by 30-37 % below that (one round of half-size tiles)
         p.tiles_m = (a->M + 255) / 256;
         const long big_blocks = (long)p.tiles_m * ((a->N + 255) / 256) * zdim;
         const char* force = getenv("HS_GEMM_TILE");   // "big" / "small": tools/bench_gemm.py A/B runs
-        const bool big = !(a->K & 63) && (force ? (force[0] == 'b') : (a->layout != HS_GEMM_TN && big_blocks >= 230));
+        static const int ncu = [] { int dev = 0, n = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+        const bool big = !(a->K & 63) && (force ? (force[0] == 'b') : (a->layout != HS_GEMM_TN && 2 * big_blocks > ncu));
         p.tiles_n = (a->N + (big ? 255 : 127)) / (big ? 256 : 128);
         dim3 grid(p.tiles_m * p.tiles_n * zdim, 1, 1);
         // epilogue specialisations (compile-time flags); anything else runs the generic kernel (EF = -1)
@@ -1493,7 +1495,6 @@ extern "C" int hs_gemm(const hs_gemm_args* a, int prec, void* stream) {
         const bool m16 = big && a->layout == HS_GEMM_NT && !a->colsum_out && getenv("HS_GEMM_NO_M16") == nullptr;   // (env: kbench A/B)
 #define HS_LAUNCH_M16(EF) hipLaunchKernelGGL((gemm_bf16_kernel<false, false, true, EF, true>), grid, dim3(512), 0, s, p)
         p.nblocks = (int)grid.x;
-        static const int ncu = [] { int dev = 0, n = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
         // the persistent variant is a measured dead end kept for A/B runs (tools/kbench, HS_GEMM_PERSIST=1): it hides the block
         // launch gap but the store issue of the epilogue stalls just as long
         static const bool no_persist = getenv("HS_GEMM_PERSIST") == nullptr;
