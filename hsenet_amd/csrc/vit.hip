@@ -12,6 +12,9 @@
 //   x' = xm + a W2^T + b2                                gemm NT, epilogue bias+residual -> fp32 (= hidden[l])
 // The residual stream (x, xm) is fp32 throughout, as under the reference's autocast policy.
 #include "common.h"
+#include <vector>
+
+int hs_cast_bf16_multi(const float* const* src, void* const* dst, const int64_t* n, int count, void* stream);   // small.hip
 
 namespace {
 
@@ -120,15 +123,19 @@ extern "C" int hs_vit_blocks_fwd(const hs_vit_desc* desc, const float* x0, const
     const size_t es = bf ? 2 : 4;
     const float eps = c.ln_eps > 0.f ? c.ln_eps : 1e-5f;
 
-    if (bf) {
+    if (bf) {   // bf16 copies of the four weight matrices of every layer: one multi-segment launch per 16 layers
+        std::vector<const float*> src;
+        std::vector<void*> dst;
+        std::vector<int64_t> cnt;
         for (int l = 0; l < c.L; ++l) {
             bf16_t* wl = (bf16_t*)(w + L.wbf) + (size_t)l * L.per_w;
             const float* const* p = lp + (size_t)l * P_COUNT;
-            RC(hs_cast_bf16(p[P_WQKV], wl, (int64_t)3 * d * d, stream));
-            RC(hs_cast_bf16(p[P_WO], wl + 3 * d * d, (int64_t)d * d, stream));
-            RC(hs_cast_bf16(p[P_W1], wl + 4 * d * d, (int64_t)mlp * d, stream));
-            RC(hs_cast_bf16(p[P_W2], wl + 4 * d * d + (size_t)mlp * d, (int64_t)d * mlp, stream));
+            src.push_back(p[P_WQKV]); dst.push_back(wl); cnt.push_back((int64_t)3 * d * d);
+            src.push_back(p[P_WO]); dst.push_back(wl + 3 * d * d); cnt.push_back((int64_t)d * d);
+            src.push_back(p[P_W1]); dst.push_back(wl + 4 * d * d); cnt.push_back((int64_t)mlp * d);
+            src.push_back(p[P_W2]); dst.push_back(wl + 4 * d * d + (size_t)mlp * d); cnt.push_back((int64_t)d * mlp);
         }
+        RC(hs_cast_bf16_multi(src.data(), dst.data(), cnt.data(), (int)src.size(), stream));
     }
     for (int l = 0; l < c.L; ++l) {
         const size_t ls = c.save_for_bwd ? l : 0;
