@@ -1,24 +1,31 @@
 #!/usr/bin/env python3
-"""bench.py — CT-volumes/sec of the 3D-ViT encoder train step on MI355X (BASELINE.json metric).
+"""bench.py — CT-volumes/sec of the dual 3D vision-encoder train step on MI355X (BASELINE.json metric).
 
-Workload at N GPUs (weak scaling, one process per GPU): BASELINE configs[1] — 256^3 volume, 3D-ViT
-(patch 16^3, 12 layers, d=768, 12 heads, N=4097 tokens), fwd + bwd + DP gradient all-reduce (RCCL) + AdamW,
-bf16 MFMA inputs / fp32 accumulate / fp32 residual stream, `--batch` volumes per GPU, synthetic U[0,1) volumes
-already resident in HBM, random-init weights.  A "step" = one such train step over one batch.
+Default workload at N GPUs (weak scaling, one process per GPU) = BASELINE configs[2]: 256^3 volume -> 3D-ViT AND 2E3-ViT
+(patch 16^3, 12 layers, d=768, 12 heads, N=4097 tokens each; the 2E3 encoder with its slice-guided scorer over (32,768) slice
+features) -> two Spatial Packers (grid 16^3, kernel (2,4,4)) -> (B, 256, 3072); loss = mean-square of that output;
+fwd + bwd of all four modules + DP gradient all-reduce (RCCL) + clipped AdamW; bf16 MFMA inputs / fp32 accumulate / fp32
+residual stream; `--batch` volumes per GPU, synthetic U[0,1) volumes and N(0,1) slice features already resident in HBM,
+random-init weights.  A "step" = one such train step over one batch.
 
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line (rank 0).  Extra objects: `roofline` (dominant kernel class, measured with HIP events on
-the launch stream in a second, instrumented pass over the same steps) and `cpu_baseline` (the CPU oracle —
-a plain-PyTorch fp32 port of the reference — timed on this host, rank 0, N=1 only).
+Other workloads: --workload vit256 (configs[1]: the 3D-ViT alone), clip_c4a (configs[3]: the reference's stage-2 CLIP step),
+native_dual (configs[2] at the reference's own 32x256x256 / 4x16x16 geometry).
+
+Prints ONE JSON line (rank 0).  Extra objects: `roofline` (dominant kernel class, measured with HIP events on the launch
+stream in a second, instrumented pass over the same steps), `cpu_baseline` (the CPU oracle — a plain-PyTorch fp32 port of the
+reference — timed on this host for the SAME workload, rank 0, N=1 only) and `batch1` (the same step at 1 volume per GPU, the
+per-GPU load of configs[3]/[4]).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import platform
 import sys
 import time
 
@@ -30,49 +37,152 @@ sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA, MI355X (MI355X_MICROARCH.md "Chip-level parameters")
 PEAK_HBM_GBS = 8000.0
+METRIC = "CT-volumes/sec (256³) dual-encoder fwd+bwd @1/2/4/8 MI355X; % MFMA roofline"
 
 GEOM = {
-    "vit256": dict(img=(256, 256, 256), patch=(16, 16, 16)),    # BASELINE configs[1]
-    "native": dict(img=(32, 256, 256), patch=(4, 16, 16)),      # the reference's own geometry
+    "dual256": dict(img=(256, 256, 256), patch=(16, 16, 16), grid=(16, 16, 16), kernel=(2, 4, 4), cfg="configs[2]"),
+    "vit256": dict(img=(256, 256, 256), patch=(16, 16, 16), cfg="configs[1]"),
+    "clip_c4a": dict(img=(256, 256, 256), patch=(16, 16, 16), cfg="configs[3]"),
+    "native_dual": dict(img=(32, 256, 256), patch=(4, 16, 16), grid=(8, 16, 16), kernel=(1, 4, 4), cfg="configs[2] at the reference-native geometry"),
 }
+OUT_DIM = 3072    # Phi-4-mini hidden size: the projector's output width (multimodal_projector/builder.py:99)
 
 
-def flops_per_volume(Np, Pd, d, L):
-    """fwd = 2 Np Pd d + L (24 N d^2 + 4 N^2 d); fwd+bwd = 3x."""
+class TowerCfg:
+    vision_tower = "vit_stage2_dual_encoders"
+    vision_select_layer, vision_select_feature, image_channel = -1, "patch", 1
+    remain_2d3d_ViT_type = "dual_vits"
+
+    def __init__(self, img, patch):
+        self.image_size, self.patch_size = img, patch
+
+
+def flops_per_volume(workload, Np, Pd, d=768, L=12, ns=32, cells=128, out=OUT_DIM):
+    """SURVEY.md section 8(d): encoder fwd = 2 Np Pd d + L (24 N d^2 + 4 N^2 d); scorer (SGA) and packer terms as listed there;
+    fwd+bwd = 3 x fwd for everything that is differentiated."""
     N = Np + 1
-    fwd = 2.0 * Np * Pd * d + L * (24.0 * N * d * d + 4.0 * N * N * d)
-    return fwd, 3.0 * fwd
+    enc = 2.0 * Np * Pd * d + L * (24.0 * N * d * d + 4.0 * N * N * d)
+    sga = 2 * 2.0 * Np * d * d + 2 * 2.0 * ns * d * d + 4.0 * Np * ns * d
+    packer = 2 * 2.0 * Np * d * d + 2 * 2.0 * cells * d * d + 4.0 * Np * d + 2.0 * cells * d * out + 2.0 * cells * out * out
+    if workload in ("dual256", "native_dual"):
+        return 3.0 * (2 * enc + sga + 2 * packer)
+    if workload == "clip_c4a":      # frozen 3D-ViT forward + trainable 2E3 fwd+bwd (CLIP_stage2.py:119-151): 4 forward units
+        return enc + 3.0 * (enc + sga)
+    return 3.0 * enc
 
 
-def measured_traffic(kernel, batch):
-    """HBM bytes per launch of `kernel` from committed rocprofv3 --pmc passes (profiles/r01_traffic.json, produced by
+def measured_traffic(kernel, batch, workload):
+    """HBM bytes per launch of `kernel` from committed rocprofv3 --pmc passes (profiles/r02_traffic.json, produced by
     tools/collect_traffic.sh: FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled as the MI355X microarch
-    guide prescribes).  None when no measurement for this kernel / batch is committed."""
+    guide prescribes).  None when no measurement for this kernel / batch / workload is committed."""
     try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+        t = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
         e = t.get(kernel)
-        if e and int(e.get("batch", -1)) == int(batch):
+        if e and int(e.get("batch", -1)) == int(batch) and e.get("workload") == workload:
             return e["hbm_bytes_per_launch"]
     except Exception:
         pass
     return None
 
 
-def cpu_baseline(geom, threads, max_seconds=60.0):
-    """the oracle (port of the reference's CPU path) on the host cores: 1 volume fwd+bwd, fp32."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return platform.processor() or "unknown CPU"
+
+
+def cpu_baseline(workload, geom, cap_seconds=150.0):
+    """the oracle (port of the reference's CPU path) on ALL host cores for the SAME workload: one volume fwd+bwd in fp32,
+    1 warm-up + up to 3 timed iterations (fewer only if the warm-up shows they would exceed `cap_seconds`), median."""
     from oracle import ref_cpu as R
+    threads = os.cpu_count() or 1
     torch.set_num_threads(threads)
     img, patch = geom["img"], geom["patch"]
-    m = R.ViT_stage1(in_channels=1, img_size=img, patch_size=patch, pos_embed="perceptron", classification=True)
-    m.load_state_dict(R.seeded_state_dict(m, 41))
     x = R.synthetic_volume((1, 1) + img, 1234)
+    if workload in ("dual256", "native_dual"):
+        tower = R.ViT3DTower_dual_encoders(TowerCfg(img, patch))
+        pk = dict(grid=geom["grid"], kernel_size=geom["kernel"])
+        p1 = R.VisualPacker_3d_phi_v3(img, patch, 768, OUT_DIM, "mlp", 2, **pk)
+        p2 = R.VisualPacker_3d_phi_v3(img, patch, 768, OUT_DIM, "mlp", 2, **pk)
+        mods = [tower, p1, p2]
+        s = R.synthetic_slices(1, 1235)
+
+        def step():
+            out = R.encode_images(tower, p1, p2, x, s)
+            (out * out).mean().backward()
+        what = "dual encoders + 2 Spatial Packers"
+    elif workload == "clip_c4a":
+        from oracle import clip_cpu as RC
+        step, mods = RC.c4a_cpu_step(img, patch, x)
+        what = "stage-2 CLIP step (frozen 3D-ViT fwd + 2E3 fwd+bwd + InfoNCE + relation MSE)"
+    else:
+        m = R.ViT_stage1(in_channels=1, img_size=img, patch_size=patch, pos_embed="perceptron", classification=True)
+        mods = [m]
+
+        def step():
+            y, _ = m(x)
+            (y * y).mean().backward()
+        what = "3D-ViT"
+    for i, m in enumerate(mods):
+        m.load_state_dict(R.seeded_state_dict(m, 41 + i))
     t0 = time.perf_counter()
-    y, _ = m(x)
-    (y * y).mean().backward()
-    dt = time.perf_counter() - t0
-    return dict(value=1.0 / dt, unit="CT-volumes/sec", cores=threads, kind="port",
-                sample=f"1 volume {img} fwd+bwd, fp32, torch {torch.__version__} CPU oracle (oracle/ref_cpu.py), "
-                       f"{threads} threads, single un-warmed iteration = {dt:.1f} s")
+    step()                                           # warm-up (allocator, thread pool, first-touch)
+    warm = time.perf_counter() - t0
+    n = max(1, min(3, int((cap_seconds - warm) // max(warm, 1e-3))))
+    times = []
+    for _ in range(n):
+        for m in mods:
+            m.zero_grad(set_to_none=True)
+        t0 = time.perf_counter()
+        step()
+        times.append(time.perf_counter() - t0)
+    med = float(np.median(times))
+    return dict(value=1.0 / med, unit="CT-volumes/sec", cores=threads, kind="port",
+                sample=f"1 volume {img} fwd+bwd of {what}, fp32, torch {torch.__version__} CPU oracle (oracle/ref_cpu.py) on "
+                       f"{cpu_model()} with {threads} threads: 1 warm-up ({warm:.1f} s) + {n} timed, median {med:.1f} s")
+
+
+def build_engine(workload, geom, batch, dev, group=None):
+    import hsenet_amd as H
+    from hsenet_amd.engine import DualEngine, FlatEncoder
+    img, patch = geom["img"], geom["patch"]
+    torch.manual_seed(1234)
+    if workload in ("dual256", "native_dual"):
+        tower = H.build_vision_tower(TowerCfg(img, patch)).to(dev)
+        pk = dict(grid=geom["grid"], kernel_size=geom["kernel"])
+        p1 = H.VisualPacker_3d_phi_v3(img, patch, 768, OUT_DIM, "mlp", 2, **pk).to(dev)
+        p2 = H.VisualPacker_3d_phi_v3(img, patch, 768, OUT_DIM, "mlp", 2, **pk).to(dev)
+        eng = DualEngine(tower, p1, p2, batch, lr=1e-4, weight_decay=0.1, group=group)
+        pe = tower.vision_tower_stage1.patch_embedding
+        return eng, pe, True
+    if workload == "clip_c4a":
+        from hsenet_amd.clip_step import ClipStage2Engine, make_clip_stage2
+        model = make_clip_stage2(img, patch).to(dev)
+        eng = ClipStage2Engine(model, batch, lr=1e-4, weight_decay=0.1, group=group)
+        return eng, model.vision_encoder.patch_embedding, True
+    model = H.ViT_stage1(in_channels=1, img_size=img, patch_size=patch, pos_embed="perceptron", classification=True).to(dev)
+    eng = FlatEncoder(model, batch, lr=1e-4, weight_decay=0.1, group=group)
+    return eng, model.patch_embedding, False
+
+
+def timed_run(eng, needs_2d, vols, slices, steps, warmup, sync):
+    def step(i):
+        if needs_2d:
+            eng.train_step(vols[i % 2], slices[i % 2])
+        else:
+            eng.train_step(vols[i % 2])
+    for i in range(warmup):
+        step(i)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(i)
+    sync()
+    return time.perf_counter() - t0, step
 
 
 def main():
@@ -80,11 +190,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=20, help="volumes per GPU per step")
-    ap.add_argument("--workload", default="vit256", choices=list(GEOM))
+    ap.add_argument("--batch", type=int, default=None, help="volumes per GPU per step (default: 20; clip_c4a: 1 = global batch 8 on 8 GPUs)")
+    ap.add_argument("--workload", default="dual256", choices=list(GEOM))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-batch1", action="store_true")
     a = ap.parse_args()
+    if a.batch is None:
+        a.batch = 1 if a.workload == "clip_c4a" else 20
 
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -106,19 +219,13 @@ def main():
     if a.gpus != world and rank == 0:
         print(f"[bench] note: --gpus {a.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
 
-    import hsenet_amd as H
     from hsenet_amd import _lib as L
-    from hsenet_amd.engine import FlatEncoder, profile_classes
+    from hsenet_amd.engine import profile_classes
     L.load()
     L.call("hs_device_check", local)
 
     geom = GEOM[a.workload]
     img, patch = geom["img"], geom["patch"]
-    torch.manual_seed(1234)
-    model = H.ViT_stage1(in_channels=1, img_size=img, patch_size=patch, pos_embed="perceptron", classification=True).to(dev)
-    eng = FlatEncoder(model, a.batch, lr=1e-4, weight_decay=0.1)
-    rng = np.random.default_rng(1234 + rank)
-    vols = [torch.from_numpy(rng.random((a.batch, 1) + img, dtype=np.float32)).to(dev) for _ in range(2)]
 
     def sync():
         torch.cuda.synchronize()
@@ -126,19 +233,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(a.warmup):
-        eng.train_step(vols[i % 2])
-    sync()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        eng.train_step(vols[i % 2])
-    sync()
-    dt = time.perf_counter() - t0
+    def inputs(batch):
+        rng = np.random.default_rng(1234 + rank)
+        vols = [torch.from_numpy(rng.random((batch, 1) + img, dtype=np.float32)).to(dev) for _ in range(2)]
+        slices = [torch.from_numpy(rng.standard_normal((batch, 32, 768), dtype=np.float32)).to(dev) for _ in range(2)]
+        return vols, slices
+
+    eng, pe, needs_2d = build_engine(a.workload, geom, a.batch, dev)
+    vols, slices = inputs(a.batch)
+    dt, step = timed_run(eng, needs_2d, vols, slices, a.steps, a.warmup, sync)
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    finite = bool(torch.isfinite(eng.y).all().item())
+    finite = bool(torch.isfinite(eng.flat).all().item())
 
     # ---- instrumented pass: per-kernel-class HIP-event timing on the launch stream, same steps --------------
     # EVERY rank runs these steps (they contain the gradient all-reduces); only rank 0 records and reads the timers.
@@ -147,7 +255,7 @@ def main():
         if rank == 0:
             L.call("hs_prof_enable", 1)
         for i in range(max(1, min(a.steps, 3))):
-            eng.train_step(vols[i % 2])
+            step(i)
         torch.cuda.synchronize()
         if rank == 0:
             classes = profile_classes()
@@ -159,20 +267,28 @@ def main():
             mf = [c for c in classes if c["flops"]]
             dom = max(mf, key=lambda c: c["total_ms"])
             roof = dict(kernel=dom["name"], bound="mfma", achieved=round(dom["tflops"], 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
-                        frac=round(dom["tflops"] / PEAK_BF16_TFLOPS, 4), traffic=measured_traffic(dom["name"], a.batch),
+                        frac=round(dom["tflops"] / PEAK_BF16_TFLOPS, 4), traffic=measured_traffic(dom["name"], a.batch, a.workload),
                         avg_launch_us=round(dom["avg_us"], 2), flops_per_launch=dom["flops"] / dom["launches"])
     if world > 1:
         dist.barrier()
 
-    Np = model.patch_embedding.n_patches
-    fwd, fb = flops_per_volume(Np, model.patch_embedding.patch_dim, model.hidden_size, len(model.blocks))
+    Np, Pd = pe.n_patches, pe.patch_dim
+    fb = flops_per_volume(a.workload, Np, Pd)
     vols_per_s = world * a.batch * a.steps / dt
+    desc = {
+        "dual256": "dual 3D-ViT + 2E3-ViT encoders (patch {p}, 12 layers, d=768, N={N} tokens each) + two Spatial Packers -> (B,256,3072), "
+                   "loss mean-square, fwd+bwd+grad all-reduce+clipped AdamW",
+        "native_dual": "dual 3D-ViT + 2E3-ViT encoders (patch {p}, 12 layers, d=768, N={N} tokens each) + two Spatial Packers -> (B,256,3072), "
+                       "loss mean-square, fwd+bwd+grad all-reduce+clipped AdamW",
+        "vit256": "3D-ViT patch {p} 12 layers d=768 (N={N} tokens), fwd+bwd+grad all-reduce+clipped AdamW",
+        "clip_c4a": "stage-2 CLIP step (CLIP_stage2.py:119-151): frozen 3D-ViT forward + 2E3-ViT fwd+bwd (patch {p}, N={N}), cls -> "
+                    "mm_vision_proj -> normalize, all-gather, InfoNCE vs frozen text embeds + relation MSE, grad all-reduce+clipped AdamW",
+    }[a.workload].format(p=patch, N=Np + 1)
     out = {
-        "metric": "CT-volumes/sec (256\u00b3) dual-encoder fwd+bwd @1/2/4/8 MI355X; % MFMA roofline", "value": round(vols_per_s, 3), "unit": "CT-volumes/sec",
+        "metric": METRIC, "value": round(vols_per_s, 3), "unit": "CT-volumes/sec",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": f"BASELINE configs[1]: {img[0]}x{img[1]}x{img[2]} volume, 3D-ViT patch {patch} 12 layers d=768 "
-                               f"(N={Np + 1} tokens), fwd+bwd+grad all-reduce+AdamW, random-init weights",
+        "config": {"workload": f"BASELINE {geom['cfg']}: {img[0]}x{img[1]}x{img[2]} volume, {desc}, random-init weights",
                    "batch_per_gpu": a.batch, "global_batch": a.batch * world, "parallelism": f"dp{world}"},
         "model_tflops": round(vols_per_s * fb / 1e12, 2),
         "mfma_roofline_frac_end_to_end": round(vols_per_s * fb / 1e12 / (PEAK_BF16_TFLOPS * world), 4),
@@ -182,8 +298,20 @@ def main():
         out["roofline"] = roof
         out["kernels"] = [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in c.items() if k != "bytes" and k != "flops"}
                           for c in sorted(classes, key=lambda c: -c["total_ms"])]
+
+    # ---- the same step at ONE volume per GPU (the per-GPU load of configs[3]/[4]: batch 8 over 8 GPUs) ----------
+    if not a.no_batch1 and a.batch != 1 and world == 1:
+        del eng, vols, slices, step
+        torch.cuda.empty_cache()
+        eng1, _, _ = build_engine(a.workload, geom, 1, dev)
+        v1, s1 = inputs(1)
+        n1 = max(5, a.steps)
+        dt1, _ = timed_run(eng1, needs_2d, v1, s1, n1, max(2, a.warmup), sync)
+        out["batch1"] = {"value": round(n1 / dt1, 3), "unit": "CT-volumes/sec", "ms_per_step": round(1e3 * dt1 / n1, 3), "steps": n1,
+                         "mfma_roofline_frac_end_to_end": round(n1 / dt1 * fb / 1e12 / PEAK_BF16_TFLOPS, 4)}
+        del eng1
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(geom, threads=min(os.cpu_count() or 1, 16))
+        out["cpu_baseline"] = cpu_baseline(a.workload, geom)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

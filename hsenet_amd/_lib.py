@@ -42,6 +42,18 @@ class VitDesc(C.Structure):
                 ("prec", C.c_int), ("save_for_bwd", C.c_int), ("ln_eps", C.c_float), ("qkv_bias", C.c_void_p)]
 
 
+class EmbedDesc(C.Structure):
+    _fields_ = [("B", C.c_int), ("Np", C.c_int), ("Pd", C.c_int), ("d", C.c_int), ("has_cls", C.c_int), ("scorer", C.c_int),
+                ("ns", C.c_int), ("save_for_bwd", C.c_int), ("drop_p", C.c_float), ("seed", C.c_uint64 * 2), ("offset", C.c_uint64 * 2)]
+
+
+class PackerDesc(C.Structure):
+    _fields_ = [("B", C.c_int), ("gd", C.c_int), ("gh", C.c_int), ("gw", C.c_int), ("kd", C.c_int), ("kh", C.c_int), ("kw", C.c_int),
+                ("d", C.c_int), ("out_dim", C.c_int), ("in_row_offset", C.c_int), ("in_batch_stride", C.c_int64),
+                ("out_batch_stride", C.c_int64), ("save_for_bwd", C.c_int), ("drop_p", C.c_float), ("seed", C.c_uint64 * 2),
+                ("offset", C.c_uint64 * 2)]
+
+
 _vp, _i, _f, _i64, _sz, _u64 = C.c_void_p, C.c_int, C.c_float, C.c_int64, C.c_size_t, C.c_uint64
 
 # name -> argtypes (restype int unless listed in _RESTYPE); mirrors include/hsenet_hip.h one to one
@@ -87,8 +99,25 @@ SIGNATURES = {
     "hs_vit_workspace_bytes": [C.POINTER(VitDesc)],
     "hs_vit_blocks_fwd": [C.POINTER(VitDesc), _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
     "hs_vit_blocks_bwd": [C.POINTER(VitDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _vp],
+    "hs_embed_workspace_bytes": [C.POINTER(EmbedDesc)],
+    "hs_embed_fwd": [C.POINTER(EmbedDesc), _vp, _vp, _vp, _vp, _vp, _sz, _vp],
+    "hs_embed_bwd": [C.POINTER(EmbedDesc), _vp, _vp, _vp, _vp, _vp, _sz, _vp],
+    "hs_packer_workspace_bytes": [C.POINTER(PackerDesc)],
+    "hs_packer_fwd": [C.POINTER(PackerDesc), _vp, _vp, _vp, _vp, _sz, _vp],
+    "hs_packer_bwd": [C.POINTER(PackerDesc), _vp, _vp, _vp, _vp, _vp, _sz, _vp],
+    "hs_mse_grad": [_vp, _vp, _vp, _i64, _vp],
+    "hs_sumsq": [_vp, _vp, _i64, _vp],
+    "hs_adamw_masked": [_vp, _vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _f, _vp, _f, _i, _vp],
+    "hs_rows_copy": [_vp, _i64, _vp, _vp, _i64, _i, _i, _i, _vp],
+    "hs_rows_scatter": [_vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "hs_scale_dev": [_vp, _vp, _vp, _f, _i64, _vp],
+    "hs_dot": [_vp, _vp, _vp, _f, _i64, _vp],
+    "hs_relation_mse": [_vp, _vp, _vp, _vp, _i64, _f, _i, _vp],
+    "hs_ce_rows": [_vp, _vp, _vp, _i, _i, _i, _f, _i, _vp],
+    "hs_debug_set": [_i, _i],
 }
-_RESTYPE = {"hs_vit_workspace_bytes": _sz, "hs_prof_name": C.c_char_p}
+_RESTYPE = {"hs_vit_workspace_bytes": _sz, "hs_embed_workspace_bytes": _sz, "hs_packer_workspace_bytes": _sz,
+            "hs_prof_name": C.c_char_p, "hs_debug_set": None}
 
 _lib = None
 _lock = threading.Lock()

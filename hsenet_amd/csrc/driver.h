@@ -1,0 +1,54 @@
+// Host-side helpers shared by the fused drivers (vit.hip: block stack; path.hip: embedding / scorer / packer).
+#pragma once
+#include "common.h"
+
+int hs_cast_bf16_multi(const float* const* src, void* const* dst, const int64_t* n, int count, void* stream);   // small.hip
+
+namespace hsdrv {
+
+inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// bump allocator over a caller-provided workspace: offsets only (the same walk sizes and lays out the workspace)
+struct Bump {
+    size_t off = 0;
+    size_t take(size_t bytes) { size_t o = off; off += al256(bytes); return o; }
+};
+
+inline int gemm(int prec, int layout, const void* A, const void* Bm, int M, int N, int K, long lda, long ldb, float* of32, void* obf,
+                long ldc, const float* bias, const float* resid, const void* aux, void* aux_out, int flags, int split_k, void* s,
+                float* colsum = nullptr, int scale_cols = 0, float scale_cols_alpha = 1.0f, int batch = 1, long sA = 0, long sB = 0,
+                long sC = 0) {
+    hs_gemm_args g = {};
+    g.colsum_out = colsum;
+    g.scale_cols = scale_cols; g.scale_cols_alpha = scale_cols_alpha;
+    g.A = A; g.B = Bm; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.batch = batch;
+    g.strideA = sA; g.strideB = sB; g.strideC = sC;
+    g.out_f32 = of32; g.out_bf16 = obf; g.ldc = ldc; g.bias = bias; g.resid = resid; g.aux = aux; g.aux_out = aux_out;
+    g.alpha = 1.0f; g.flags = flags; g.layout = layout; g.split_k = split_k;
+    return hs_gemm(&g, prec, s);
+}
+
+// split-K factor for a wgrad whose output has ceil(Mo/256)*ceil(No/128) tiles and K reduction rows: pick the split
+// that minimises (rounds over 256 CUs) x (K-tiles per block + a fixed per-block cost ~ the atomic epilogue).
+inline int wgrad_split(int Mo, int No, int K) {
+    const int tiles = ((Mo + 255) / 256) * ((No + 127) / 128);
+    const int kt = (K + 63) / 64;
+    int best = 1;
+    long best_cost = -1;
+    for (int s = 1; s <= 32 && s <= kt; ++s) {
+        const long rounds = ((long)tiles * s + 255) / 256;
+        const long cost = rounds * ((kt + s - 1) / s + 16);
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = s; }
+    }
+    return best;
+}
+
+// dW[No_rows = n_out][n_in] += dY^T X   (dY bf16 [rows][ldy] columns [0, n_out), X bf16 [rows][ldx]); dW zeroed by the caller
+inline int wgrad(const void* dy, long ldy, const void* x, long ldx, float* dw, int n_out, int n_in, int rows, void* s) {
+    return gemm(HS_PREC_BF16, HS_GEMM_TN, dy, x, n_out, n_in, rows, ldy, ldx, dw, nullptr, n_in, nullptr, nullptr, nullptr, nullptr,
+                HS_EPI_ATOMIC, wgrad_split(n_out, n_in, rows), s);
+}
+
+}  // namespace hsdrv
+
+#define RC(x) do { int rc__ = (x); if (rc__ != HS_OK) return rc__; } while (0)

@@ -11,10 +11,10 @@
 //   a = gelu(h2 W1^T + b1)                               gemm NT, epilogue bias+GELU -> bf16 (gelu'(z) saved)
 //   x' = xm + a W2^T + b2                                gemm NT, epilogue bias+residual -> fp32 (= hidden[l])
 // The residual stream (x, xm) is fp32 throughout, as under the reference's autocast policy.
-#include "common.h"
+#include "driver.h"
 #include <vector>
 
-int hs_cast_bf16_multi(const float* const* src, void* const* dst, const int64_t* n, int count, void* stream);   // small.hip
+using namespace hsdrv;
 
 namespace {
 
@@ -23,15 +23,13 @@ struct Layout {
     size_t per_w;  // bf16 weight elements per layer
 };
 
-inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
-
 Layout make_layout(const hs_vit_desc& c) {
     Layout L;
     const size_t M = (size_t)c.B * c.N, d = c.d, mlp = c.mlp;
     const size_t Ls = c.save_for_bwd ? c.L : 1;
     const size_t es = c.prec == HS_PREC_BF16 ? 2 : 4;
     size_t off = 0;
-    auto take = [&](size_t bytes) { size_t o = off; off += al(bytes); return o; };
+    auto take = [&](size_t bytes) { size_t o = off; off += al256(bytes); return o; };
     L.per_w = 3 * d * d + d * d + mlp * d + d * mlp;
     L.wbf = take(c.prec == HS_PREC_BF16 ? (size_t)c.L * L.per_w * 2 : 0);
     L.xmid = take(Ls * M * d * 4);
@@ -71,36 +69,7 @@ int check_desc(const hs_vit_desc* c) {
 // indices into the per-layer parameter list (MONAI state-dict order)
 enum { P_W1 = 0, P_B1, P_W2, P_B2, P_N1W, P_N1B, P_WO, P_BO, P_WQKV, P_N2W, P_N2B, P_COUNT };
 
-int gemm(int prec, int layout, const void* A, const void* Bm, int M, int N, int K, long lda, long ldb, float* of32, void* obf,
-         long ldc, const float* bias, const float* resid, const void* aux, void* aux_out, int flags, int split_k, void* s,
-         float* colsum = nullptr, int scale_cols = 0, float scale_cols_alpha = 1.0f) {
-    hs_gemm_args g = {};
-    g.colsum_out = colsum;
-    g.scale_cols = scale_cols; g.scale_cols_alpha = scale_cols_alpha;
-    g.A = A; g.B = Bm; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.batch = 1;
-    g.out_f32 = of32; g.out_bf16 = obf; g.ldc = ldc; g.bias = bias; g.resid = resid; g.aux = aux; g.aux_out = aux_out;
-    g.alpha = 1.0f; g.flags = flags; g.layout = layout; g.split_k = split_k;
-    return hs_gemm(&g, prec, s);
-}
-
-// split-K factor for a wgrad whose output has ceil(Mo/256)*ceil(No/128) tiles and K reduction rows: pick the split
-// that minimises (rounds over 256 CUs) x (K-tiles per block + a fixed per-block cost ~ the atomic epilogue).
-int wgrad_split(int Mo, int No, int K) {
-    const int tiles = ((Mo + 255) / 256) * ((No + 127) / 128);
-    const int kt = (K + 63) / 64;
-    int best = 1;
-    long best_cost = -1;
-    for (int s = 1; s <= 32 && s <= kt; ++s) {
-        const long rounds = ((long)tiles * s + 255) / 256;
-        const long cost = rounds * ((kt + s - 1) / s + 16);
-        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = s; }
-    }
-    return best;
-}
-
 const float kQScale = 0.125f * 1.44269504088896341f;   // dh^-0.5 * log2(e), dh = 64
-
-#define RC(x) do { int rc__ = (x); if (rc__ != HS_OK) return rc__; } while (0)
 
 }  // namespace
 

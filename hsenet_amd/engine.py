@@ -1,21 +1,33 @@
-"""Training-step engine for the 3D-ViT encoder (BASELINE configs[1]): forward + backward + DP gradient
-all-reduce + AdamW, every kernel from libhsenet_hip.so, parameters / gradients / Adam moments in flat fp32
-buffers.  This is the measurement harness' stand-in for the reference's HF Trainer step
-(train/train_CLIP_stage1.py:231-244 -> DDP -> optim "adamw_torch" :85); the module API in encoder.py stays the
-drop-in surface, and ``FlatEncoder`` adopts such a module's parameters in place (they become views of the flat
-buffer, so ``state_dict()`` / ``load_state_dict()`` keep working).
+"""Train-step engines for the dual 3D vision-encoder path: forward + backward + DP gradient all-reduce + AdamW with every
+kernel from libhsenet_hip.so and parameters / gradients / Adam moments in flat fp32 buffers.
+
+* ``DualEngine``  — BASELINE configs[2]: ``ViT3DTower_dual_encoders`` (3D-ViT + 2E3-ViT on the same volume, vit.py:926-948)
+  feeding two ``VisualPacker_3d_phi_v3`` whose outputs are concatenated to (B, 256, hidden) (lamed_arch.py:122-141).
+* ``FlatEncoder`` — BASELINE configs[1]: one encoder (``ViT_stage1`` or ``ViT_stage2``).
+
+These are the measurement harness' stand-in for the reference's HF Trainer step (train/train_CLIP_stage1.py:231-244 -> DDP ->
+optim "adamw_torch" :85, weight_decay 0.1, default max_grad_norm 1.0): like the Trainer they exclude biases and LayerNorm
+weights from weight decay and clip the global gradient norm.  The module API in encoder.py / projector.py stays the drop-in
+surface; an engine ADOPTS such modules' parameters in place (they become views of the flat buffer, so ``state_dict()`` /
+``load_state_dict()`` keep working and ``p.grad`` is a view of the flat gradient).
+
+Flat-buffer order is chosen so that the backward pass completes it from the top down in contiguous ranges (packers, then per
+encoder: final norm, blocks L-1..0, patch-embed/cls/pos/scorer): each finished range is all-reduced (RCCL over xGMI) while the
+remaining backward kernels run.
 """
 from __future__ import annotations
 
 import ctypes as C
-from typing import List, Optional
+from typing import Callable, List, Optional, Sequence, Tuple
 
 import torch
+import torch.nn as nn
 
 from . import _lib as L
 from . import functional as Fn
 from .dp import GradBuckets
-from .encoder import ViT_stage1
+from .encoder import ViT_stage1, ViT_stage2, ViT3DTower_dual_encoders
+from .projector import VisualPacker_3d_phi_v3
 
 
 def _al(n: int, a: int = 64) -> int:
@@ -23,10 +35,9 @@ def _al(n: int, a: int = 64) -> int:
 
 
 def bucket_plan(names, offsets, total: int, n_layers: int, n_buckets: int):
-    """Backward-completion-ordered layer chunks [(l_hi, l_lo)] and the flat-gradient element range each one
-    finishes.  Parameters sit in state-dict order (cls, pos, patch-embed, blocks.0 .. blocks.L-1, norm), backward
-    completes blocks from L-1 down, so chunk i covers [offset(blocks.l_lo), previous start); the first chunk also
-    carries the final norm (it sits behind blocks.L-1), the last one cls/pos/patch-embed (in front of blocks.0)."""
+    """Backward-completion-ordered layer chunks [(l_hi, l_lo)] of ONE encoder laid out as [head.., blocks.0 .. blocks.L-1, norm]
+    and the flat element range each one finishes: chunk i covers [offset(blocks.l_lo), previous start); the first chunk also
+    carries the final norm (behind blocks.L-1), the last one everything in front of blocks.0 (cls / pos / patch-embed / scorer)."""
     per = max(1, (n_layers + n_buckets - 1) // n_buckets)
     chunks, hi = [], n_layers
     while hi > 0:
@@ -42,112 +53,411 @@ def bucket_plan(names, offsets, total: int, n_layers: int, n_buckets: int):
     return chunks, bounds
 
 
-class FlatEncoder:
-    """ViT_stage1 with flat parameter / gradient / moment buffers and an explicit fused train step."""
+def decays(module: nn.Module) -> dict:
+    """{parameter name: bool} — HF Trainer's get_decay_parameter_names: everything except LayerNorm parameters and biases."""
+    no = set()
+    for mn, m in module.named_modules():
+        if isinstance(m, nn.LayerNorm):
+            for pn, _ in m.named_parameters(recurse=False):
+                no.add(f"{mn}.{pn}" if mn else pn)
+    return {n: (n not in no and "bias" not in n) for n, _ in module.named_parameters()}
 
-    def __init__(self, model: ViT_stage1, batch: int, *, lr=1e-4, weight_decay=0.1, n_buckets=4, group=None):
-        if not isinstance(model, ViT_stage1):
-            raise TypeError("FlatEncoder drives ViT_stage1 (BASELINE configs[1])")
-        p0 = next(model.parameters())
-        if not p0.is_cuda:
-            raise L.HsError("FlatEncoder needs the module on an MI355X ('cuda') device")
-        self.model, self.dev, self.B = model, p0.device, batch
-        named = list(model.named_parameters())
-        self.names = [n for n, _ in named]
+
+class FlatParams:
+    """Flat fp32 parameter / gradient / Adam-moment buffers over an ordered list of (name, parameter, decays) entries; each
+    parameter starts on a 64-element boundary and becomes a view of ``flat`` (its ``.grad`` a view of ``grad``)."""
+
+    def __init__(self, entries: Sequence[Tuple[str, nn.Parameter, bool]], device: torch.device):
+        self.names = [n for n, _, _ in entries]
         offs, off = [], 0
-        for _, p in named:
+        for _, p, _ in entries:
             offs.append(off)
             off += _al(p.numel())
         self.offsets, self.total = offs, off
-        self.flat = torch.zeros(off, dtype=torch.float32, device=self.dev)
+        self.flat = torch.zeros(off, dtype=torch.float32, device=device)
         self.grad = torch.zeros_like(self.flat)
         self.m = torch.zeros_like(self.flat)
         self.v = torch.zeros_like(self.flat)
-        for (n, p), o in zip(named, offs):
+        mask = torch.zeros(off // 64, dtype=torch.uint8)
+        for (n, p, dec), o in zip(entries, offs):
+            if p.dtype != torch.float32:
+                raise L.HsError(f"parameter {n} must be fp32")
             view = self.flat[o:o + p.numel()].view(p.shape)
             view.copy_(p.data)
             p.data = view
             p.grad = self.grad[o:o + p.numel()].view(p.shape)
-        self.lr, self.wd, self.step_no = lr, weight_decay, 0
+            if dec:
+                mask[o // 64:(o + _al(p.numel())) // 64] = 1
+        self.decay_mask = mask.to(device)
+        self.gsq = torch.zeros(1, dtype=torch.float32, device=device)
+        self.step_no = 0
+
+    def offset(self, name: str) -> int:
+        return self.offsets[self.names.index(name)]
+
+    def step(self, *, lr: float, weight_decay: float, grad_scale: float, max_grad_norm: Optional[float], betas=(0.9, 0.999),
+             eps: float = 1e-8) -> None:
+        """one fused AdamW pass (decay mask, global-norm clip on the device)."""
+        self.step_no += 1
+        s = Fn._s()
+        gsq = None
+        if max_grad_norm is not None and max_grad_norm > 0:
+            self.gsq.zero_()
+            L.call("hs_sumsq", self.grad.data_ptr(), self.gsq.data_ptr(), self.total, s)
+            gsq = self.gsq.data_ptr()
+        L.call("hs_adamw_masked", self.flat.data_ptr(), self.grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
+               self.decay_mask.data_ptr(), self.total, lr, betas[0], betas[1], eps, weight_decay, grad_scale, gsq,
+               float(max_grad_norm or 0.0), self.step_no, s)
+
+
+def _seeds(desc, train: bool) -> None:
+    """fresh Philox (seed, offset) pairs for the two dropout sites of a scorer / packer when its module is in train()."""
+    if train:
+        desc.drop_p = 0.1
+        for i in range(2):
+            sd, of = Fn.draw_dropout_seed()
+            desc.seed[i], desc.offset[i] = sd, of
+    else:
+        desc.drop_p = 0.0
+
+
+class EncoderUnit:
+    """One encoder (P4 ViT_stage1 / P6 ViT_stage2) on the fused drivers: hs_embed_* + hs_vit_blocks_*, own workspaces."""
+
+    def __init__(self, model, batch: int, trainable: bool = True):
+        if not isinstance(model, (ViT_stage1, ViT_stage2)):
+            raise TypeError("EncoderUnit drives ViT_stage1 / ViT_stage2")
+        p0 = next(model.parameters())
+        if not p0.is_cuda:
+            raise L.HsError("the engine needs the module on an MI355X ('cuda') device")
+        self.model, self.dev, self.B, self.trainable = model, p0.device, batch, trainable
+        self.scorer = isinstance(model, ViT_stage2)
         pe = model.patch_embedding
         self.Np, self.Pd, self.d = pe.n_patches, pe.patch_dim, model.hidden_size
-        self.N = self.Np + 1
+        self.has_cls = hasattr(model, "cls_token")
+        self.N = self.Np + (1 if self.has_cls else 0)
         self.Ln = len(model.blocks)
-        self.desc = L.VitDesc(batch, self.N, self.d, model.num_heads, model.mlp_dim, self.Ln, L.PREC_BF16, 1, 0.0, None)
-        nbytes = L.load().hs_vit_workspace_bytes(C.byref(self.desc))
-        if nbytes == 0:
+        sv = 1 if trainable else 0
+        self.desc = L.VitDesc(batch, self.N, self.d, model.num_heads, model.mlp_dim, self.Ln, L.PREC_BF16, sv, 0.0, None)
+        self.edesc = L.EmbedDesc(batch, self.Np, self.Pd, self.d, int(self.has_cls), int(self.scorer), 32, sv, 0.0)
+        lib = L.load()
+        self.ws_bytes = lib.hs_vit_workspace_bytes(C.byref(self.desc))
+        if self.ws_bytes == 0:
             raise L.HsError("unsupported encoder geometry")
-        self.ws_bytes = nbytes
-        self.ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.dev)
-        self.ws_ptr = self.ws.data_ptr() + (-self.ws.data_ptr()) % 256
+        self.ws, self.ws_ptr = self._alloc(self.ws_bytes)
         f32 = dict(dtype=torch.float32, device=self.dev)
-        B, Np, N, d = batch, self.Np, self.N, self.d
-        self.patches = torch.empty(B * Np, self.Pd, dtype=torch.bfloat16, device=self.dev)
-        self.w_pe = torch.empty(d, self.Pd, dtype=torch.bfloat16, device=self.dev)
-        self.pe = torch.empty(B * Np, d, **f32)
+        B, N, d = batch, self.N, self.d
         self.x0 = torch.empty(B, N, d, **f32)
         self.y = torch.empty(B, N, d, **f32)
-        self.hidden = torch.empty(self.Ln, B, N, d, **f32)
-        self.dy = torch.empty(B, N, d, **f32)
-        self.dx0 = torch.empty(B, N, d, **f32)
-        self.dpe = torch.empty(B * Np, d, **f32)
-        self.dpe_b = torch.empty(B * Np, d, dtype=torch.bfloat16, device=self.dev)
-        blocks = [p for blk in model.blocks for p in blk.ordered_params()]
-        self._lp = Fn._ptr_array(blocks)
-        self._np = Fn._ptr_array([model.norm.weight, model.norm.bias])
-        self._lg = Fn._ptr_array([p.grad for p in blocks])
-        self._ng = Fn._ptr_array([model.norm.weight.grad, model.norm.bias.grad])
-        self.layer_chunks, bounds = bucket_plan(self.names, offs, self.total, self.Ln, n_buckets)
-        self.buckets = GradBuckets(self.grad, bounds, group)
+        self.hidden = torch.empty(self.Ln, B, N, d, **f32)      # the hidden-state list the reference returns (= saved layer inputs)
+        if trainable:
+            self.dy = torch.empty(B, N, d, **f32)
+            self.dx0 = torch.empty(B, N, d, **f32)
+        self._ews = None                     # sized per call: depends on drop_p (train / eval)
+        self._ews_key = None
 
-    # -- pieces --------------------------------------------------------------------------------------------
-    def forward(self, vol: torch.Tensor) -> torch.Tensor:
-        m, s = self.model, Fn._s()
-        pe = m.patch_embedding
-        lin = pe.patch_embeddings[1]
-        B, Cc, D, H, W = vol.shape
-        if B != self.B or tuple(vol.shape[2:]) != pe.img_size or not vol.is_cuda or vol.dtype != torch.float32:
-            raise L.HsError("FlatEncoder.forward: volume must be fp32 on the GPU with the configured batch/geometry")
-        L.call("hs_patchify", vol.data_ptr(), self.patches.data_ptr(), B, Cc, D, H, W, *pe.patch_size, L.PREC_BF16, s)
-        L.call("hs_cast_bf16", lin.weight.data_ptr(), self.w_pe.data_ptr(), lin.weight.numel(), s)
-        Fn.gemm(self.patches, self.w_pe, L.GEMM_NT, prec=L.PREC_BF16, out_f32=self.pe, bias=lin.bias, flags=L.EPI_BIAS)
-        cls = m.cls_token.data_ptr() if hasattr(m, "cls_token") else None
-        L.call("hs_assemble_tokens", self.pe.data_ptr(), pe.position_embeddings.data_ptr(), cls, None, self.x0.data_ptr(), None,
-               B, self.Np, self.d, s)
+    def _alloc(self, nbytes: int):
+        t = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.dev)
+        return t, t.data_ptr() + (-t.data_ptr()) % 256
+
+    # ---- parameter lists (the fused drivers' orders) ------------------------------------------------------------------
+    def head_params(self) -> List[Tuple[str, nn.Parameter]]:
+        """embedding-driver parameters in ITS order (hs_embed_*: cls, pos, pe.w, pe.b [, scorer x12]) with state-dict names."""
+        m = self.model
+        out = []
+        if self.has_cls:
+            out.append(("cls_token", m.cls_token))
+        out += [("patch_embedding.position_embeddings", m.patch_embedding.position_embeddings),
+                ("patch_embedding.patch_embeddings.1.weight", m.patch_embedding.patch_embeddings[1].weight),
+                ("patch_embedding.patch_embeddings.1.bias", m.patch_embedding.patch_embeddings[1].bias)]
+        if self.scorer:
+            out += [("patch_score_proj.weight", m.patch_score_proj.weight), ("patch_score_proj.bias", m.patch_score_proj.bias)]
+            sga = m.slice_guided_attention
+            for nm in ("Wq", "Wk", "Wv", "output_linear"):
+                lin = getattr(sga, nm)
+                out += [(f"slice_guided_attention.{nm}.weight", lin.weight), (f"slice_guided_attention.{nm}.bias", lin.bias)]
+            out += [("slice_guided_attention.norm.weight", sga.norm.weight), ("slice_guided_attention.norm.bias", sga.norm.bias)]
+        return out
+
+    def flat_order(self) -> List[Tuple[str, nn.Parameter]]:
+        """[head.., blocks.0 .. blocks.L-1, norm]: the order the backward pass completes from the END."""
+        named = dict(self.model.named_parameters())
+        out = self.head_params()
+        for l in range(self.Ln):
+            pre = f"blocks.{l}."
+            out += [(n, p) for n, p in named.items() if n.startswith(pre)]
+        out += [("norm.weight", self.model.norm.weight), ("norm.bias", self.model.norm.bias)]
+        assert len(out) == len(named), "every encoder parameter must be in the flat order exactly once"
+        return out
+
+    def bind(self) -> None:
+        """(re)build the device-pointer tables after the parameters were adopted into flat buffers."""
+        m = self.model
+        blocks = [p for blk in m.blocks for p in blk.ordered_params()]
+        self._lp = Fn._ptr_array(blocks)
+        self._np = Fn._ptr_array([m.norm.weight, m.norm.bias])
+        head = [p for _, p in self.head_params()]
+        if not self.has_cls:
+            head = [None] + head
+        head += [None] * (16 - len(head))
+        self._ep = (C.c_void_p * 16)(*[None if p is None else p.data_ptr() for p in head])
+        if self.trainable:
+            self._lg = Fn._ptr_array([p.grad for p in blocks])
+            self._ng = Fn._ptr_array([m.norm.weight.grad, m.norm.bias.grad])
+            self._eg = (C.c_void_p * 16)(*[None if p is None else p.grad.data_ptr() for p in head])
+
+    # ---- passes -----------------------------------------------------------------------------------------------------------
+    def _embed_ws(self):
+        key = float(self.edesc.drop_p)
+        if self._ews_key != key:
+            nb = L.load().hs_embed_workspace_bytes(C.byref(self.edesc))
+            if nb == 0:
+                raise L.HsError("unsupported embedding geometry")
+            self._ews, self._ews_ptr = self._alloc(nb)
+            self._ews_bytes, self._ews_key = nb, key
+        return self._ews_ptr, self._ews_bytes
+
+    def forward(self, patches: torch.Tensor, image_2d: Optional[torch.Tensor] = None) -> torch.Tensor:
+        s = Fn._s()
+        if self.scorer:
+            if image_2d is None:
+                raise L.HsError("ViT_stage2 needs image_2d (the 2D slice features)")
+            image_2d = image_2d.view(self.B, 32, -1)
+            Fn._need(image_2d)
+            if image_2d.dtype != torch.float32 or image_2d.shape[2] != self.d:
+                raise L.HsError("image_2d must be fp32 [B, 32, hidden]")
+            _seeds(self.edesc, self.model.training)
+        ews, ewb = self._embed_ws()
+        L.call("hs_embed_fwd", C.byref(self.edesc), patches.data_ptr(), Fn._p(image_2d) if self.scorer else None, self._ep,
+               self.x0.data_ptr(), ews, ewb, s)
         L.call("hs_vit_blocks_fwd", C.byref(self.desc), self.x0.data_ptr(), self._lp, self._np, self.y.data_ptr(),
                self.hidden.data_ptr(), self.ws_ptr, self.ws_bytes, s)
         return self.y
 
-    def backward(self, dy: torch.Tensor) -> None:
-        m, s = self.model, Fn._s()
-        pe = m.patch_embedding
-        lin = pe.patch_embeddings[1]
-        self.grad.zero_()
-        for i, (hi, lo) in enumerate(self.layer_chunks):
+    def backward(self, patches: torch.Tensor, dy: torch.Tensor, chunks: Sequence[Tuple[int, int]],
+                 on_chunk: Callable[[int], None]) -> None:
+        """dy [B,N,d] -> parameter gradients (accumulated into the zeroed flat gradient); ``on_chunk(i)`` after layer chunk i
+        (and, for the last chunk, after the embedding backward) so the caller can launch that range's all-reduce."""
+        if not self.trainable:
+            raise L.HsError("this encoder unit was built frozen (forward-only)")
+        s = Fn._s()
+        for i, (hi, lo) in enumerate(chunks):
             L.call("hs_vit_blocks_bwd", C.byref(self.desc), self.x0.data_ptr(), self._lp, self._np, dy.data_ptr(), self.dx0.data_ptr(),
                    self._lg, self._ng, self.hidden.data_ptr(), self.ws_ptr, self.ws_bytes, hi, lo, s)
             if lo > 0:
-                self.buckets.reduce(i)
-        has_cls = hasattr(m, "cls_token")
-        L.call("hs_assemble_tokens_bwd", self.dx0.data_ptr(), None, None, self.dpe.data_ptr(), pe.position_embeddings.grad.data_ptr(),
-               m.cls_token.grad.data_ptr() if has_cls else None, None, self.B, self.Np, self.d, s)
-        L.call("hs_cast_bf16", self.dpe.data_ptr(), self.dpe_b.data_ptr(), self.dpe.numel(), s)
-        Fn.gemm(self.dpe_b, self.patches, L.GEMM_TN, prec=L.PREC_BF16, out_f32=lin.weight.grad, flags=L.EPI_ATOMIC,
-                split_k=Fn._wgrad_split(self.d, self.Pd, self.B * self.Np))
-        Fn.colsum(self.dpe_b, lin.bias.grad)
-        self.buckets.reduce(len(self.layer_chunks) - 1)
-        self.buckets.wait()
+                on_chunk(i)
+        ews, ewb = self._embed_ws()
+        L.call("hs_embed_bwd", C.byref(self.edesc), patches.data_ptr(), self.dx0.data_ptr(), self._ep, self._eg, ews, ewb, s)
+        on_chunk(len(chunks) - 1)
+
+
+class PackerUnit:
+    """One Spatial Packer (P2) on hs_packer_*: reads an encoder's output in place (cls row skipped), writes its half of the
+    concatenated (B, slots*cells, out_dim) tensor."""
+
+    def __init__(self, packer: VisualPacker_3d_phi_v3, batch: int, in_tokens: int, in_row_offset: int, out_slots: int, slot: int,
+                 trainable: bool = True):
+        p0 = next(packer.parameters())
+        if not p0.is_cuda:
+            raise L.HsError("the engine needs the module on an MI355X ('cuda') device")
+        self.packer, self.dev, self.B, self.trainable = packer, p0.device, batch, trainable
+        gd, gh, gw = packer.grid
+        kd, kh, kw = packer.kernel_size
+        self.cells = (gd // kd) * (gh // kh) * (gw // kw)
+        self.out_dim, self.slot, self.out_slots = packer.out_dim, slot, out_slots
+        d = packer.in_dim
+        if in_tokens != in_row_offset + gd * gh * gw:
+            raise L.HsError(f"packer grid {packer.grid} does not match {in_tokens - in_row_offset} patch tokens")
+        self.desc = L.PackerDesc(batch, gd, gh, gw, kd, kh, kw, d, self.out_dim, in_row_offset, in_tokens * d,
+                                 out_slots * self.cells * self.out_dim, 1 if trainable else 0, 0.0)
+        self._ws_key = None
+
+    def flat_order(self) -> List[Tuple[str, nn.Parameter]]:
+        return list(self.packer.named_parameters())
+
+    def bind(self) -> None:
+        pk, ra = self.packer, self.packer.resolution_attention
+        ps = [pk.proj_mpls[0].weight, pk.proj_mpls[0].bias, pk.proj_mpls[2].weight, pk.proj_mpls[2].bias,
+              ra.Wq.weight, ra.Wq.bias, ra.Wk.weight, ra.Wk.bias, ra.Wv.weight, ra.Wv.bias, ra.output_linear.weight,
+              ra.output_linear.bias, ra.norm.weight, ra.norm.bias]
+        self._pp = Fn._ptr_array(ps)
+        if self.trainable:
+            self._pg = Fn._ptr_array([p.grad for p in ps])
+
+    def _ws(self):
+        key = float(self.desc.drop_p)
+        if self._ws_key != key:
+            nb = L.load().hs_packer_workspace_bytes(C.byref(self.desc))
+            if nb == 0:
+                raise L.HsError("unsupported packer geometry")
+            t = torch.empty(nb + 256, dtype=torch.uint8, device=self.dev)
+            self._wst, self._ws_ptr, self._ws_bytes, self._ws_key = t, t.data_ptr() + (-t.data_ptr()) % 256, nb, key
+        return self._ws_ptr, self._ws_bytes
+
+    def _slot_ptr(self, t: torch.Tensor) -> int:
+        return t.data_ptr() + 4 * self.slot * self.cells * self.out_dim
+
+    def forward(self, feat: torch.Tensor, out: torch.Tensor) -> None:
+        _seeds(self.desc, self.packer.training)
+        ws, wb = self._ws()
+        L.call("hs_packer_fwd", C.byref(self.desc), feat.data_ptr(), self._pp, self._slot_ptr(out), ws, wb, Fn._s())
+
+    def backward(self, dout: torch.Tensor, dfeat: Optional[torch.Tensor]) -> None:
+        ws, wb = self._ws()
+        L.call("hs_packer_bwd", C.byref(self.desc), self._slot_ptr(dout), self._pp, self._pg, Fn._p(dfeat), ws, wb, Fn._s())
+
+
+class _Engine:
+    """shared: flat buffers, gradient buckets, optimizer."""
+
+    def _finish(self, entries, bounds, *, lr, weight_decay, max_grad_norm, group):
+        self.params = FlatParams(entries, self.dev)
+        self.flat, self.grad = self.params.flat, self.params.grad
+        self.buckets = GradBuckets(self.grad, bounds, group)
+        self.lr, self.wd, self.max_grad_norm = lr, weight_decay, max_grad_norm
+        self.loss = torch.zeros(1, dtype=torch.float32, device=self.dev)
+
+    @property
+    def step_no(self) -> int:
+        return self.params.step_no
 
     def optimizer_step(self) -> None:
-        self.step_no += 1
-        Fn.adamw_step(self.flat, self.grad, self.m, self.v, lr=self.lr, weight_decay=self.wd, grad_scale=self.buckets.grad_scale,
-                      step=self.step_no)
+        self.params.step(lr=self.lr, weight_decay=self.wd, grad_scale=self.buckets.grad_scale, max_grad_norm=self.max_grad_norm)
 
-    def train_step(self, vol: torch.Tensor) -> None:
-        """one step of L = mean(y^2): fwd, dL/dy = 2 y / numel, bwd (+ bucketed all-reduce), AdamW."""
-        y = self.forward(vol)
-        L.call("hs_scale", y.data_ptr(), self.dy.data_ptr(), 2.0 / y.numel(), y.numel(), Fn._s())
+    def _patchify(self, vol: torch.Tensor, pe, patches: torch.Tensor) -> None:
+        Fn._need(vol)
+        B, Cc, D, H, W = vol.shape
+        if B != self.B or tuple(vol.shape[2:]) != pe.img_size or vol.dtype != torch.float32:
+            raise L.HsError("volume must be contiguous fp32 on the GPU with the configured batch/geometry")
+        L.call("hs_patchify", vol.data_ptr(), patches.data_ptr(), B, Cc, D, H, W, *pe.patch_size, L.PREC_BF16, Fn._s())
+
+
+def _encoder_entries(unit: EncoderUnit, prefix: str):
+    dec = decays(unit.model)
+    return [(prefix + n, p, dec[n]) for n, p in unit.flat_order()]
+
+
+def _encoder_bounds(unit: EncoderUnit, params_names, params_offsets, prefix: str, seg_start: int, seg_end: int, n_buckets: int):
+    per = max(1, (unit.Ln + n_buckets - 1) // n_buckets)
+    chunks, hi = [], unit.Ln
+    while hi > 0:
+        lo = max(0, hi - per)
+        chunks.append((hi, lo))
+        hi = lo
+    off = dict(zip(params_names, params_offsets))
+    bounds, end = [], seg_end
+    for (hi, lo) in chunks:
+        start = off[f"{prefix}blocks.{lo}.mlp.linear1.weight"] if lo > 0 else seg_start
+        bounds.append((start, end))
+        end = start
+    return chunks, bounds
+
+
+class FlatEncoder(_Engine):
+    """One encoder with flat parameter / gradient / moment buffers and an explicit fused train step (BASELINE configs[1])."""
+
+    def __init__(self, model, batch: int, *, lr=1e-4, weight_decay=0.1, max_grad_norm: Optional[float] = 1.0, n_buckets=4, group=None):
+        self.unit = EncoderUnit(model, batch, trainable=True)
+        self.model, self.dev, self.B = model, self.unit.dev, batch
+        entries = _encoder_entries(self.unit, "")
+        probe_names = [n for n, _, _ in entries]
+        offs, off = [], 0
+        for _, p, _ in entries:
+            offs.append(off)
+            off += _al(p.numel())
+        self.layer_chunks, bounds = _encoder_bounds(self.unit, probe_names, offs, "", 0, off, n_buckets)
+        self._finish(entries, bounds, lr=lr, weight_decay=weight_decay, max_grad_norm=max_grad_norm, group=group)
+        self.unit.bind()
+        u = self.unit
+        self.patches = torch.empty(batch * u.Np, u.Pd, dtype=torch.bfloat16, device=self.dev)
+        self.y, self.dy, self.hidden = u.y, u.dy, u.hidden
+
+    def forward(self, vol: torch.Tensor, image_2d: Optional[torch.Tensor] = None) -> torch.Tensor:
+        self._patchify(vol, self.model.patch_embedding, self.patches)
+        return self.unit.forward(self.patches, image_2d)
+
+    def backward(self, dy: torch.Tensor) -> None:
+        Fn._need(dy)
+        self.grad.zero_()
+        self.unit.backward(self.patches, dy, self.layer_chunks, self.buckets.reduce)
+        self.buckets.wait()
+
+    def train_step(self, vol: torch.Tensor, image_2d: Optional[torch.Tensor] = None) -> None:
+        """one step of L = mean(y^2): fwd, dL/dy = 2 y / numel, bwd (+ bucketed all-reduce), clipped AdamW."""
+        y = self.forward(vol, image_2d)
+        L.call("hs_mse_grad", y.data_ptr(), self.dy.data_ptr(), None, y.numel(), Fn._s())
         self.backward(self.dy)
+        self.optimizer_step()
+
+
+class DualEngine(_Engine):
+    """BASELINE configs[2]: dual encoders + two Spatial Packers -> (B, 2*cells, hidden), all four modules trainable.
+
+    forward  = encode_images (lamed_arch.py:122-141) over ViT3DTower_dual_encoders.forward (vit.py:926-948): the volume is
+               patchified ONCE, both encoders read the same bf16 patch matrix; each packer reads its encoder's output in place
+               (cls row skipped = select_feature 'patch') and writes its half of the concatenated output.
+    backward = packers -> 2E3 encoder -> 3D-ViT encoder, gradient ranges all-reduced as they complete."""
+
+    def __init__(self, tower: ViT3DTower_dual_encoders, packer1: VisualPacker_3d_phi_v3, packer2: VisualPacker_3d_phi_v3, batch: int, *,
+                 lr=1e-4, weight_decay=0.1, max_grad_norm: Optional[float] = 1.0, n_buckets=4, group=None):
+        if tower.select_feature != "patch" or tower.remain_2d3d_ViT_type != "dual_vits":
+            raise L.HsError("DualEngine drives the shipped configuration: select_feature='patch', remain_2d3d_ViT_type='dual_vits'")
+        self.tower, self.B = tower, batch
+        self.u1 = EncoderUnit(tower.vision_tower_stage1, batch, True)
+        self.u2 = EncoderUnit(tower.vision_tower_stage2, batch, True)
+        self.dev = self.u1.dev
+        off1 = 1 if self.u1.has_cls else 0
+        self.p1 = PackerUnit(packer1, batch, self.u1.N, off1, 2, 0, True)
+        self.p2 = PackerUnit(packer2, batch, self.u2.N, off1, 2, 1, True)
+        if packer1.out_dim != packer2.out_dim or self.p1.cells != self.p2.cells:
+            raise L.HsError("the two packers must agree on out_dim and token count")
+        e1 = _encoder_entries(self.u1, "vision_tower_stage1.")
+        e2 = _encoder_entries(self.u2, "vision_tower_stage2.")
+        d1, d2 = decays(packer1), decays(packer2)
+        ep1 = [("mm_projector." + n, p, d1[n]) for n, p in self.p1.flat_order()]
+        ep2 = [("mm_projector2." + n, p, d2[n]) for n, p in self.p2.flat_order()]
+        entries = e1 + e2 + ep1 + ep2
+        names = [n for n, _, _ in entries]
+        offs, off = [], 0
+        for _, p, _ in entries:
+            offs.append(off)
+            off += _al(p.numel())
+        s2, sp = offs[len(e1)], offs[len(e1) + len(e2)]
+        self.chunks1, b1 = _encoder_bounds(self.u1, names, offs, "vision_tower_stage1.", 0, s2, n_buckets)
+        self.chunks2, b2 = _encoder_bounds(self.u2, names, offs, "vision_tower_stage2.", s2, sp, n_buckets)
+        bounds = [(sp, off)] + b2 + b1                   # backward-completion order: packers, 2E3 chunks, 3D-ViT chunks
+        self._finish(entries, bounds, lr=lr, weight_decay=weight_decay, max_grad_norm=max_grad_norm, group=group)
+        for u in (self.u1, self.u2, self.p1, self.p2):
+            u.bind()
+        self.patches = torch.empty(batch * self.u1.Np, self.u1.Pd, dtype=torch.bfloat16, device=self.dev)
+        self.out = torch.empty(batch, 2 * self.p1.cells, packer1.out_dim, dtype=torch.float32, device=self.dev)
+        self.dout = torch.empty_like(self.out)
+
+    def forward(self, vol: torch.Tensor, image_2d: torch.Tensor) -> torch.Tensor:
+        self._patchify(vol, self.tower.vision_tower_stage1.patch_embedding, self.patches)
+        y1 = self.u1.forward(self.patches)
+        y2 = self.u2.forward(self.patches, image_2d)
+        self.p1.forward(y1, self.out)
+        self.p2.forward(y2, self.out)
+        return self.out
+
+    def backward(self, dout: torch.Tensor) -> None:
+        Fn._need(dout)
+        self.grad.zero_()
+        self.p2.backward(dout, self.u2.dy)
+        self.p1.backward(dout, self.u1.dy)
+        self.buckets.reduce(0)
+        n2 = len(self.chunks2)
+        self.u2.backward(self.patches, self.u2.dy, self.chunks2, lambda i: self.buckets.reduce(1 + i))
+        self.u1.backward(self.patches, self.u1.dy, self.chunks1, lambda i: self.buckets.reduce(1 + n2 + i))
+        self.buckets.wait()
+
+    def train_step(self, vol: torch.Tensor, image_2d: torch.Tensor) -> None:
+        """one step of L = mean(out^2) over the (B, 256, hidden) projector output."""
+        out = self.forward(vol, image_2d)
+        self.loss.zero_()
+        L.call("hs_mse_grad", out.data_ptr(), self.dout.data_ptr(), self.loss.data_ptr(), out.numel(), Fn._s())
+        self.backward(self.dout)
         self.optimizer_step()
 
 

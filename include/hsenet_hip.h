@@ -235,6 +235,98 @@ int hs_vit_blocks_bwd(const hs_vit_desc* desc, const float* x0, const float* con
                       float* const* norm_grads, const float* hidden, void* ws, size_t ws_bytes, int l_hi, int l_lo,
                       void* stream);
 
+/* ---- fused embedding driver: P1 (MONAI PatchEmbeddingBlock: Linear over the patchified volume + bias + learned positions,
+ * vit.py:428-437,455) and the token assembly of ViT_stage1 (cls concat, vit.py:459-461); with scorer = 1 also P5/P6 of
+ * ViT_stage2 (vit.py:325-349): x = embedding + pos; regular_attention(x, sem, sem) (single head, d_k = d, softmax over the ns
+ * slice features, Dropout(0.1) on the probabilities and on the pre-residual output in train mode, LN(q + out), vit.py:36-64);
+ * score = sigmoid(patch_score_proj(.)); tokens = cat(cls, x * score).
+ * patches: [B*Np][Pd] bf16 from hs_patchify (shared by both encoders of the dual tower: the volume is read once).
+ * image_2d: [B][ns][d] fp32 (the pre-computed BiomedCLIP slice features; scorer only).  tokens: [B][Np + has_cls][d] fp32.
+ * params / grads: 16 device pointers in the reference's state-dict order of these tensors:
+ *   [cls_token, patch_embedding.position_embeddings, patch_embedding.patch_embeddings.1.weight, ...1.bias,
+ *    patch_score_proj.weight, .bias, slice_guided_attention.Wq.weight, .bias, Wk.weight, .bias, Wv.weight, .bias,
+ *    output_linear.weight, .bias, slice_guided_attention.norm.weight, .bias]     (entries 4.. ignored when scorer = 0;
+ *    entry 0 ignored when has_cls = 0).  Gradients ACCUMULATE (split-K atomics): the caller zeroes them.
+ * seed/offset: Philox streams of the two dropout sites [probabilities, pre-residual output]; the backward call must get the
+ * same descriptor as the forward call it differentiates. */
+typedef struct hs_embed_desc {
+    int B, Np, Pd, d;
+    int has_cls;          /* classification=True: row 0 of every volume's tokens is cls_token */
+    int scorer;           /* 0 = ViT_stage1, 1 = ViT_stage2 (slice-guided scorer) */
+    int ns;               /* slices per volume (32, vit.py:332) */
+    int save_for_bwd;
+    float drop_p;         /* 0 = eval(); 0.1 = train() (vit.py:46-47) */
+    uint64_t seed[2], offset[2];
+} hs_embed_desc;
+size_t hs_embed_workspace_bytes(const hs_embed_desc* desc);
+int hs_embed_fwd(const hs_embed_desc* desc, const void* patches, const float* image_2d, const float* const* params,
+                 float* tokens, void* ws, size_t ws_bytes, void* stream);
+int hs_embed_bwd(const hs_embed_desc* desc, const void* patches, const float* dtokens, const float* const* params,
+                 float* const* grads, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- fused Spatial Packer driver: P2 VisualPacker_3d_phi_v3.forward (multimodal_projector/spatial_pooling_projector.py:138-146)
+ * = view as token grid (:140) -> avg_pool3d (:141) -> resolution_attention_v3 (:62-83: Wq on the pooled cells, ONE [Wk;Wv] GEMM
+ * over every HR token, 1 query x kd*kh*kw children softmax, Dropout(0.1) x2 in train mode, output_linear, LN(q + .)) ->
+ * proj_mpls Linear-GELU-Linear (:127-131,144).
+ * feat: fp32 token tensor; volume b's HR tokens are rows [in_row_offset, in_row_offset + gd*gh*gw) of the block starting at
+ *   feat + b*in_batch_stride (elements): in_row_offset = 1, in_batch_stride = (T+1)*d reads an encoder output [B][T+1][d] in place,
+ *   skipping the cls row (select_feature == 'patch', vit.py:934-936).
+ * out: fp32 [B][cells][out_dim] with batch stride out_batch_stride (elements): 2*cells*out_dim lets the two packers of the dual
+ *   tower fill the two halves of one [B][2*cells][out_dim] tensor (lamed_arch.py:127-132's cat) without a copy.
+ * params / grads: 14 pointers in state-dict order [proj_mpls.0.weight, .0.bias, proj_mpls.2.weight, .2.bias,
+ *   resolution_attention.Wq.weight, .bias, Wk.weight, .bias, Wv.weight, .bias, output_linear.weight, .bias, norm.weight, .bias];
+ *   gradients accumulate (caller zeroes).  dfeat (optional): gradient w.r.t. feat, same layout as feat, rows below
+ *   in_row_offset zeroed (dense [B][in_row_offset + T][d]: requires in_batch_stride == (in_row_offset + T)*d). */
+typedef struct hs_packer_desc {
+    int B, gd, gh, gw, kd, kh, kw, d, out_dim;
+    int in_row_offset;
+    int64_t in_batch_stride, out_batch_stride;
+    int save_for_bwd;
+    float drop_p;
+    uint64_t seed[2], offset[2];
+} hs_packer_desc;
+size_t hs_packer_workspace_bytes(const hs_packer_desc* desc);
+int hs_packer_fwd(const hs_packer_desc* desc, const float* feat, const float* const* params, float* out, void* ws, size_t ws_bytes,
+                  void* stream);
+int hs_packer_bwd(const hs_packer_desc* desc, const float* dout, const float* const* params, float* const* grads, float* dfeat,
+                  void* ws, size_t ws_bytes, void* stream);
+
+/* ---- train-step glue (the measurement harness' stand-in for HF Trainer: optim adamw_torch, weight_decay 0.1, max_grad_norm 1.0)
+ * hs_mse_grad: L = mean(y^2): dy = 2 y / n, loss[0] += L (loss optional, caller zeroes).
+ * hs_sumsq: out[0] += sum(x^2) (caller zeroes) -- the squared global gradient norm, kept on the device.
+ * hs_adamw_masked: hs_adamw with (a) decay_mask: one byte per 64-element chunk of the flat buffer, 0 = no weight decay (biases and
+ *   LayerNorm weights, as HF Trainer's get_decay_parameter_names), NULL = decay everything; (b) grad_sumsq (device, optional):
+ *   squared norm of the SUMMED gradient; the update uses g * grad_scale * min(1, max_grad_norm / (sqrt(sumsq)*grad_scale + 1e-6))
+ *   = torch.nn.utils.clip_grad_norm_ on the DP-mean gradient, without a host round trip. */
+int hs_mse_grad(const float* y, float* dy, float* loss, int64_t n, void* stream);
+int hs_sumsq(const float* x, float* out, int64_t n, void* stream);
+int hs_adamw_masked(float* p, const float* g, float* m, float* v, const unsigned char* decay_mask, int64_t n, float lr, float beta1,
+                    float beta2, float eps, float weight_decay, float grad_scale, const float* grad_sumsq, float max_grad_norm,
+                    int step, void* stream);
+
+/* dst[b*dst_batch_stride + r*d + :] = src[b*src_batch_stride + r*d + :] for r < R, as fp32 and/or bf16: a block of R rows per batch
+ * entry between two strided [B][.][d] tensors (the cls row of every volume: R = 1, src stride N*d = `[:, 0]`, CLIP_stage1.py:117;
+ * the patch rows: src + d, R = N-1 = `[:, 1:]`, vit.py:934-936).  hs_rows_scatter: dst [B][Rt][d] gets the dense src rows at
+ * [r0, r0+R) and zeros elsewhere (the adjoint of such a row selection). */
+int hs_rows_copy(const float* src, int64_t src_batch_stride, float* dst_f32, void* dst_bf16, int64_t dst_batch_stride, int B, int R, int d,
+                 void* stream);
+int hs_rows_scatter(const float* src, float* dst, int B, int r0, int R, int Rt, int d, void* stream);
+
+/* ---- N1 glue with the logit scale ON THE DEVICE (it is a trained nn.Parameter, CLIP_stage2.py:99; no host read per step)
+ * hs_scale_dev: y = x * alpha_dev[0] * alpha (alpha_dev NULL: y = x * alpha).  hs_dot: out[0] += alpha * sum(a*b).
+ * hs_relation_mse: image_text_relation_regulation on ONE pair of logit matrices (CLIP_stage2.py:187-190): loss[0] += mean((l-l_ref)^2);
+ *   dl = (accumulate ? dl : 0) + weight * 2/n * (l - l_ref)   (weight = the relation_loss_weight schedule, :141-149).
+ * hs_ce_rows: F.cross_entropy(logits [rows][cols], labels = label0 + row), the local_loss branch (:173-177):
+ *   loss[0] += weight * mean CE;  dlogits = (accumulate ? dlogits : 0) + weight * (softmax - onehot) / rows. */
+int hs_scale_dev(const float* x, float* y, const float* alpha_dev, float alpha, int64_t n, void* stream);
+int hs_dot(const float* a, const float* b, float* out, float alpha, int64_t n, void* stream);
+int hs_relation_mse(const float* l_ref, const float* l, float* dl, float* loss, int64_t n, float weight, int accumulate, void* stream);
+int hs_ce_rows(const float* logits, float* dlogits, float* loss, int rows, int cols, int label0, float weight, int accumulate,
+               void* stream);
+
+/* diagnostic: selects a kernel variant per class for tools/kbench A/B runs (every key defaults to 0 = the shipped kernel) */
+void hs_debug_set(int key, int value);
+
 #ifdef __cplusplus
 }
 #endif

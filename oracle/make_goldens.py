@@ -10,7 +10,7 @@ For each case the oracle restatement and the reference get the same seeded weigh
 (or a row subset + per-token norms for the big geometries) are written as fixtures.  Weights and
 inputs are NOT stored: tests regenerate them from the seeds recorded in each file.
 
-Usage:  python oracle/make_goldens.py [--skip-big]
+Usage:  python oracle/make_goldens.py [--skip-big] [--only grads]
 """
 from __future__ import annotations
 
@@ -199,6 +199,129 @@ def big(vit, spp):
     print("vit256_stage1 ok")
 
 
+# --------------------------------------------------------------------------------------
+# gradient fixtures (round 2): autograd of sum(out * w) through the REFERENCE modules
+# --------------------------------------------------------------------------------------
+FULL_BLOCKS = (0, 5, 11)      # blocks whose gradients are stored as row subsets; every tensor gets its norm
+
+
+def _grad_fixture(named, tag):
+    """{tag}_names, {tag}_norms for every tensor; for small tensors and the tensors of blocks 0/5/11, the embeddings, the scorer
+    and the packers also values: full when numel <= 4096, else rows [0, mid, last] of the 2-D view (last dim kept)."""
+    names, norms, vals = [], [], {}
+    for n, p in named:
+        g = p.grad
+        assert g is not None, n
+        names.append(n)
+        norms.append(float(g.double().norm()))
+        blk = None
+        parts = n.split(".")
+        if "blocks" in parts:
+            blk = int(parts[parts.index("blocks") + 1])
+        if blk is not None and blk not in FULL_BLOCKS:
+            continue
+        g2 = g.reshape(-1, g.shape[-1]) if g.dim() >= 2 else g.reshape(1, -1)
+        if g.numel() <= 4096:
+            vals[f"{tag}_g/{n}"] = g.numpy().copy()
+        else:
+            rows = sorted({0, g2.shape[0] // 2, g2.shape[0] - 1})
+            vals[f"{tag}_g/{n}"] = g2[rows].numpy().copy()
+            vals[f"{tag}_r/{n}"] = np.array(rows)
+    vals[f"{tag}_names"] = np.array(names)
+    vals[f"{tag}_norms"] = np.array(norms)
+    return vals
+
+
+def _grads_equal(named_a, named_b, what, tol=2e-5):
+    worst = 0.0
+    for (na, pa), (nb, pb) in zip(named_a, named_b):
+        assert na == nb
+        den = float(pb.grad.double().norm())
+        err = float((pa.grad.double() - pb.grad.double()).norm()) / max(den, 1e-30)
+        if den > 1e-9:
+            worst = max(worst, err)
+            assert err <= tol, f"restatement gradient != reference gradient for {what}: {na} {err}"
+    return worst
+
+
+def _packer_apply(pk, feats, grid, kernel):
+    """VisualPacker_3d_phi_v3.forward (spatial_pooling_projector.py:138-146) with the token grid / pooling kernel as arguments
+    (the reference hard-codes (8,16,16) / (1,4,4)); the arithmetic is the reference module's own resolution_attention + proj_mpls."""
+    b = feats.size(0)
+    hr = feats.view(b, *grid, 768)
+    lr = torch.nn.functional.avg_pool3d(hr.clone().permute(0, 4, 1, 2, 3), kernel_size=kernel).permute(0, 2, 3, 4, 1)
+    return pk.proj_mpls(pk.resolution_attention(lr, hr, kernel)).view(b, -1, pk.out_dim)
+
+
+def _dual_case(vit, spp, img, patch, grid, kernel, seeds, use_wrapper):
+    """fwd + bwd of encode_images through the reference tower and two reference packers; returns (fixture dict, out)."""
+    s_t, s_p1, s_p2, s_x, s_s, s_w = seeds
+    pk_args = (img, patch, 768, 3072, "mlp", 2)
+    x, s = R.synthetic_volume((1, 1) + img, s_x), R.synthetic_slices(1, s_s)
+    w = torch.from_numpy(np.random.default_rng(s_w).standard_normal((1, 256, 3072), dtype=np.float32))
+
+    def run(tower_cls, packer_cls, reference):
+        tower = tower_cls(Cfg(img, patch)).eval()
+        p1, p2 = packer_cls(*pk_args).eval(), packer_cls(*pk_args).eval()
+        for m, sd_seed in ((tower, s_t), (p1, s_p1), (p2, s_p2)):
+            m.load_state_dict(R.seeded_state_dict(m, sd_seed))
+        f1, f2 = tower(x, s)                                                           # vit.py:926-948
+        if reference and use_wrapper:
+            out = torch.cat([p1(f1), p2(f2)], dim=1)                                    # lamed_arch.py:127-132
+        else:
+            out = torch.cat([_packer_apply(p1, f1, grid, kernel), _packer_apply(p2, f2, grid, kernel)], dim=1)
+        (out * w).sum().backward()
+        named = ([("vision_tower." + n, p) for n, p in tower.named_parameters()] + [("mm_projector." + n, p) for n, p in p1.named_parameters()]
+                 + [("mm_projector2." + n, p) for n, p in p2.named_parameters()])
+        return out.detach(), named
+
+    out_r, named_r = run(vit.ViT3DTower_dual_encoders, spp.VisualPacker_3d_phi_v3, True)
+    fx = _grad_fixture(named_r, "grad")
+    out_o, named_o = run(R.ViT3DTower_dual_encoders, R.VisualPacker_3d_phi_v3, False)
+    _eq(out_o, out_r, f"encode_images {img}")
+    worst = _grads_equal(named_o, named_r, f"dual {img}")
+    prow = [0, 1, 127, 128, 255]
+    fx.update(img=np.array(img), patch=np.array(patch), grid=np.array(grid), kernel=np.array(kernel), seed_tower=s_t, seed_p1=s_p1, seed_p2=s_p2,
+              seed_x=s_x, seed_s=s_s, seed_w=s_w, out_rows_idx=np.array(prow), out_rows=_sel(out_r, prow),
+              out_row_norms=out_r.norm(dim=-1).numpy())
+    return fx, worst
+
+
+def grads(vit, spp):
+    """Gradient fixtures from the imported reference: loss = sum(out * w), w ~ N(0,1) seeded.
+      grad_native_dual.npz : reference-native 32x256x256 dual tower + the reference packer WRAPPER -> (1,256,3072)   (configs[2] at
+                             the geometry the reference hard-codes)
+      grad_dual256.npz     : BASELINE configs[2], 256^3 / 16^3: reference tower + the reference packers' own resolution_attention /
+                             proj_mpls on the (16,16,16) grid with kernel (2,4,4) (the wrapper's .view is the only line bypassed)
+      grad_vit256_stage1.npz: BASELINE configs[1], 256^3 ViT_stage1 alone, loss on the (1,4097,768) output
+    Each holds per-tensor gradient norms for EVERY parameter tensor and values (full or rows [0, mid, last]) for the embeddings,
+    scorer, final norm, packers and blocks 0 / 5 / 11.  The restatement's gradients are asserted equal to the reference's."""
+    fx, worst = _dual_case(vit, spp, (32, 256, 256), (4, 16, 16), (8, 16, 16), (1, 4, 4), (61, 62, 63, 64, 65, 66), True)
+    np.savez_compressed(os.path.join(OUT, "grad_native_dual.npz"), **fx)
+    print(f"grad_native_dual ok (restatement vs reference gradients: worst {worst:.1e})")
+    fx, worst = _dual_case(vit, spp, (256, 256, 256), (16, 16, 16), (16, 16, 16), (2, 4, 4), (71, 72, 73, 74, 75, 76), False)
+    np.savez_compressed(os.path.join(OUT, "grad_dual256.npz"), **fx)
+    print(f"grad_dual256 ok (restatement vs reference gradients: worst {worst:.1e})")
+
+    img, patch = (256, 256, 256), (16, 16, 16)
+    kw = dict(in_channels=1, img_size=img, patch_size=patch, pos_embed="perceptron", classification=True)
+    x = R.synthetic_volume((1, 1) + img, 82)
+    w = torch.from_numpy(np.random.default_rng(83).standard_normal((1, 4097, 768), dtype=np.float32))
+    res = []
+    for cls in (vit.ViT_stage1, R.ViT_stage1):
+        m = cls(**kw).eval()
+        m.load_state_dict(R.seeded_state_dict(m, 81))
+        y, _ = m(x)
+        (y * w).sum().backward()
+        res.append((y.detach(), list(m.named_parameters())))
+    _eq(res[1][0], res[0][0], "256^3 stage1 (grad case)")
+    worst = _grads_equal(res[1][1], res[0][1], "256^3 stage1")
+    fx = _grad_fixture(res[0][1], "grad")
+    fx.update(seed_w=81, seed_x=82, seed_dy=83)
+    np.savez_compressed(os.path.join(OUT, "grad_vit256_stage1.npz"), **fx)
+    print(f"grad_vit256_stage1 ok (restatement vs reference gradients: worst {worst:.1e})")
+
+
 @torch.no_grad()
 def plumbing(vit):
     """BASELINE configs[0]: one 128^3 volume, ViT-small (6 layers, d=384, 6 heads, mlp 1536), fwd only."""
@@ -218,17 +341,22 @@ def plumbing(vit):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-big", action="store_true")
+    ap.add_argument("--only", default=None, choices=["grads"], help="regenerate only this group of fixtures")
     a = ap.parse_args()
     if not os.path.isdir(REF):
         sys.exit("reference not present (this script only runs in the build container)")
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(os.cpu_count())
     vit, spp = load_reference()
+    if a.only == "grads":
+        grads(vit, spp)
+        return
     tiny_encoders(vit)
     packer(spp)
     plumbing(vit)
     if not a.skip_big:
         big(vit, spp)
+        grads(vit, spp)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,211 @@
+"""The train-step engines (hsenet_amd/engine.py — the path bench.py times) against the CPU oracle: DualEngine =
+BASELINE configs[2] (dual encoders + two Spatial Packers), FlatEncoder = configs[1]; forward output, every parameter
+gradient, and the optimizer step (HF-Trainer semantics: no decay on biases / LayerNorm, global-norm clip) vs torch.optim.AdamW."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TOL_BF16 = 2e-2
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+class Cfg:
+    vision_tower = "vit_stage2_dual_encoders"
+    vision_select_layer, vision_select_feature, image_channel = -1, "patch", 1
+    remain_2d3d_ViT_type = "dual_vits"
+
+    def __init__(self, img, patch):
+        self.image_size, self.patch_size = img, patch
+
+
+IMG, PATCH, GRID, KERN, OUT = (8, 64, 64), (4, 16, 16), (2, 4, 4), (1, 2, 2), 256
+PARGS = (IMG, PATCH, 768, OUT, "mlp", 2)
+
+
+def _shrink(tower, layers):
+    for t in (tower.vision_tower_stage1, tower.vision_tower_stage2):
+        del t.blocks[layers:]
+    return tower
+
+
+def _oracle(B, seed, layers=2):
+    from oracle import ref_cpu as R
+    tower = _shrink(R.ViT3DTower_dual_encoders(Cfg(IMG, PATCH)), layers).eval()
+    p1 = R.VisualPacker_3d_phi_v3(*PARGS, grid=GRID, kernel_size=KERN).eval()
+    p2 = R.VisualPacker_3d_phi_v3(*PARGS, grid=GRID, kernel_size=KERN).eval()
+    sds = [R.seeded_state_dict(m, seed + i) for i, m in enumerate((tower, p1, p2))]
+    for m, sd in zip((tower, p1, p2), sds):
+        m.load_state_dict(sd)
+    x, s = R.synthetic_volume((B, 1) + IMG, seed + 10), R.synthetic_slices(B, seed + 11)
+    return tower, p1, p2, sds, x, s
+
+
+def _mine(sds, dev, layers=2, train=False):
+    import hsenet_amd as H
+    tower = _shrink(H.build_vision_tower(Cfg(IMG, PATCH)), layers)
+    p1 = H.VisualPacker_3d_phi_v3(*PARGS, grid=GRID, kernel_size=KERN)
+    p2 = H.VisualPacker_3d_phi_v3(*PARGS, grid=GRID, kernel_size=KERN)
+    for m, sd in zip((tower, p1, p2), sds):
+        m.load_state_dict(sd)
+        m.to(dev)
+        m.train(train)
+    return tower, p1, p2
+
+
+def _named(tower, p1, p2):
+    return ([("vision_tower." + n, p) for n, p in tower.named_parameters()] + [("mm_projector." + n, p) for n, p in p1.named_parameters()]
+            + [("mm_projector2." + n, p) for n, p in p2.named_parameters()])
+
+
+def test_dual_engine_vs_oracle(dev):
+    """configs[2] in miniature (grid (2,4,4), kernel (1,2,2), L=2, batch 3): engine output and ALL parameter gradients of
+    L = mean(out^2) vs the oracle's autograd; then one optimizer step vs torch.optim.AdamW with HF Trainer's grouping + clip."""
+    from hsenet_amd.engine import DualEngine, decays
+    from oracle import ref_cpu as R
+    from test_gpu_parity import grad_errs
+    B = 3
+    tr, p1r, p2r, sds, x, s = _oracle(B, 900)
+    out_r = R.encode_images(tr, p1r, p2r, x, s)
+    (out_r * out_r).mean().backward()
+    tower, p1, p2 = _mine(sds, dev)
+    eng = DualEngine(tower, p1, p2, B, lr=1e-3, weight_decay=0.1, max_grad_norm=1.0)
+    assert eng.params.total >= sum(p.numel() for _, p in _named(tower, p1, p2))
+    out = eng.forward(x.to(dev), s.to(dev))
+    assert tuple(out.shape) == (B, 2 * p1.proj_out_num, OUT) == tuple(out_r.shape)
+    e = rel(out, out_r.detach())
+    print(f"DualEngine fwd: {e:.2e}")
+    assert e < TOL_BF16
+    from hsenet_amd import _lib as L, functional as Fn
+    eng.loss.zero_()
+    L.call("hs_mse_grad", out.data_ptr(), eng.dout.data_ptr(), eng.loss.data_ptr(), out.numel(), Fn._s())
+    eng.backward(eng.dout)
+    torch.cuda.synchronize()
+    lr_ = float((out_r * out_r).mean().detach())
+    assert abs(float(eng.loss) - lr_) < 3e-2 * lr_
+    errs = grad_errs(_named(tower, p1, p2), _named(tr, p1r, p2r))
+    worst = max(errs, key=errs.get)
+    print(f"DualEngine backward worst grad err: {worst} {errs[worst]:.2e} over {len(errs)} tensors")
+    assert errs[worst] < 5e-2, (worst, errs[worst])
+
+    # ---- optimizer: same gradients into torch.optim.AdamW the way HF Trainer builds it
+    ref_named = _named(tr, p1r, p2r)
+    mine_named = dict(_named(tower, p1, p2))
+    dec = {}
+    for pre, mod in (("vision_tower.", tr), ("mm_projector.", p1r), ("mm_projector2.", p2r)):
+        dec.update({pre + n: v for n, v in decays(mod).items()})
+    assert not dec["vision_tower.vision_tower_stage1.norm.weight"] and not dec["mm_projector.proj_mpls.0.bias"]
+    assert dec["vision_tower.vision_tower_stage1.cls_token"] and dec["vision_tower.vision_tower_stage2.blocks.0.attn.qkv.weight"]
+    for n, p in ref_named:
+        p.grad = mine_named[n].grad.detach().cpu().clone()
+    opt = torch.optim.AdamW([{"params": [p for n, p in ref_named if dec[n]], "weight_decay": 0.1},
+                             {"params": [p for n, p in ref_named if not dec[n]], "weight_decay": 0.0}], lr=1e-3)
+    before = {n: p.detach().clone() for n, p in ref_named}
+    gn = torch.nn.utils.clip_grad_norm_([p for _, p in ref_named], 1.0)
+    opt.step()
+    eng.optimizer_step()
+    torch.cuda.synchronize()
+    gn_mine = float(eng.params.gsq.sqrt())
+    assert abs(gn_mine - float(gn)) < 1e-3 * float(gn), (gn_mine, float(gn))
+    for n, p in ref_named:
+        moved = float((p.detach() - before[n]).norm())
+        diff = float((mine_named[n].detach().cpu() - p.detach()).norm())
+        assert diff <= 1e-3 * moved + 1e-7, (n, diff, moved)
+    print(f"optimizer step matches torch AdamW (+clip at |g| = {float(gn):.3f}) on {len(ref_named)} tensors")
+
+
+def test_dual_engine_matches_module_path(dev):
+    """engine (fused drivers, flat buffers) == module API (per-op autograd Functions) on the same weights: same kernels
+    underneath, so only summation order / epilogue fusion differ."""
+    import hsenet_amd as H
+    from hsenet_amd.engine import DualEngine
+    from hsenet_amd import _lib as L, functional as Fn
+    B = 2
+    _, _, _, sds, x, s = _oracle(B, 920)
+    tower_m, p1m, p2m = _mine(sds, dev)
+    out_m = H.encode_images(tower_m, p1m, p2m, x.to(dev), s.to(dev))
+    (out_m * out_m).mean().backward()
+    tower, p1, p2 = _mine(sds, dev)
+    eng = DualEngine(tower, p1, p2, B)
+    out = eng.forward(x.to(dev), s.to(dev))
+    L.call("hs_mse_grad", out.data_ptr(), eng.dout.data_ptr(), None, out.numel(), Fn._s())
+    eng.backward(eng.dout)
+    torch.cuda.synchronize()
+    assert rel(out, out_m.detach()) < 8e-3      # the engine's packer fuses GELU into the GEMM epilogue (bf16-rounded pre-activation)
+    ref = dict(_named(tower_m, p1m, p2m))
+    worst = 0.0
+    for n, p in _named(tower, p1, p2):
+        g = ref[n].grad
+        e = float((p.grad - g).norm() / g.norm().clamp_min(1e-12))
+        worst = max(worst, e)
+        assert e < 2e-2 or float(g.norm()) < 1e-6, (n, e)
+    print(f"engine vs module path: worst grad diff {worst:.2e}")
+
+
+def test_dual_engine_train_mode_and_state_dict(dev):
+    """train(): the hard-coded Dropout(0.1) sites fire (vit.py:46-47, spatial_pooling_projector.py:58-59) and replay under
+    torch.manual_seed; adopting the parameters keeps state_dict()/load_state_dict() working; steps reduce the loss."""
+    from hsenet_amd.engine import DualEngine
+    B = 2
+    _, _, _, sds, x, s = _oracle(B, 940)
+    tower, p1, p2 = _mine(sds, dev, train=True)
+    keys = list(tower.state_dict().keys())
+    eng = DualEngine(tower, p1, p2, B, lr=1e-3)
+    assert list(tower.state_dict().keys()) == keys
+    xd, sd_ = x.to(dev), s.to(dev)
+    torch.manual_seed(5)
+    a = eng.forward(xd, sd_).clone()
+    torch.manual_seed(5)
+    b = eng.forward(xd, sd_).clone()
+    torch.manual_seed(6)
+    c = eng.forward(xd, sd_).clone()
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    for m in (tower, p1, p2):
+        m.eval()
+    d = eng.forward(xd, sd_).clone()
+    assert rel(a, d) > 1e-3                      # dropout really changed the function
+    losses = []
+    for _ in range(4):
+        eng.train_step(xd, sd_)
+        losses.append(float(eng.loss))
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+    # load_state_dict writes through to the flat buffer
+    tower.load_state_dict(sds[0])
+    off = eng.params.offset("vision_tower_stage1.norm.weight")
+    assert torch.equal(eng.flat[off:off + 768].cpu(), sds[0]["vision_tower_stage1.norm.weight"])
+
+
+def test_flat_encoder_stage2_vs_oracle(dev):
+    """FlatEncoder also drives the 2E3 encoder alone (the trainable half of the stage-2 CLIP step)."""
+    import hsenet_amd as H
+    from hsenet_amd.engine import FlatEncoder
+    from hsenet_amd import _lib as L, functional as Fn
+    from oracle import ref_cpu as R
+    from test_gpu_parity import grad_errs
+    kw = dict(in_channels=1, img_size=IMG, patch_size=PATCH, num_layers=2, pos_embed="perceptron", classification=True)
+    B = 2
+    ref = R.ViT_stage2(**kw).eval()
+    sd = R.seeded_state_dict(ref, 960)
+    ref.load_state_dict(sd)
+    x, s = R.synthetic_volume((B, 1) + IMG, 961), R.synthetic_slices(B, 962)
+    yr, _ = ref(x, s)
+    (yr * yr).mean().backward()
+    m = H.ViT_stage2(**kw).eval()
+    m.load_state_dict(sd)
+    eng = FlatEncoder(m.to(dev), B)
+    y = eng.forward(x.to(dev), s.to(dev))
+    assert rel(y, yr.detach()) < TOL_BF16
+    L.call("hs_mse_grad", y.data_ptr(), eng.dy.data_ptr(), None, y.numel(), Fn._s())
+    eng.backward(eng.dy)
+    torch.cuda.synchronize()
+    errs = grad_errs(m.named_parameters(), ref.named_parameters())
+    worst = max(errs, key=errs.get)
+    print(f"FlatEncoder(ViT_stage2) worst grad err: {worst} {errs[worst]:.2e}")
+    assert errs[worst] < 5e-2, (worst, errs[worst])
+    with pytest.raises(L.HsError):
+        eng.forward(x.to(dev).transpose(3, 4), s.to(dev))          # non-contiguous volume: refused, not silently mis-read

@@ -1,0 +1,142 @@
+"""Full-size backward parity against gradient fixtures produced by the REFERENCE modules' autograd
+(oracle/make_goldens.py::grads — loss = sum(out * w), fp32 CPU): the path bench.py times (engine.DualEngine / FlatEncoder:
+fused drivers, flat buffers, chunked (l_hi, l_lo) block backward, split-K atomics) and the module/autograd path, at the
+reference-native 32x256x256 geometry and at BASELINE's 256^3 (N = 4097 tokens, L = 12).
+
+Checked per parameter tensor: (1) the gradient norm of EVERY tensor, (2) the values of the stored tensors (full, or rows
+[0, mid, last]) — embeddings, cls, scorer, final norm, packers, blocks 0 / 5 / 11.  Tolerance 2e-2 per tensor (bf16 MFMA inputs in
+every forward/dgrad/wgrad GEMM against an fp32 reference; measured values are printed)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-2
+
+
+class Cfg:
+    vision_tower = "vit_stage2_dual_encoders"
+    vision_select_layer, vision_select_feature, image_channel = -1, "patch", 1
+    remain_2d3d_ViT_type = "dual_vits"
+
+    def __init__(self, img, patch):
+        self.image_size, self.patch_size = img, patch
+
+
+def check_grads(named_mine, g, what, tol=TOL):
+    names, norms = [str(n) for n in g["grad_names"]], g["grad_norms"]
+    mine = {n: p.grad.detach().double().cpu() for n, p in named_mine}
+    assert sorted(mine) == sorted(names), "parameter sets differ"
+    big = float(norms.max())
+    worst_norm, worst_val = ("", 0.0), ("", 0.0)
+    n_vals = 0
+    for n, rn in zip(names, norms):
+        gm = mine[n]
+        # (1) norms.  A tensor whose reference gradient is ~0 (e.g. Wk.bias of a softmax attention: the output is invariant to
+        # it) only has to stay small.
+        if rn < 1e-4 * big:
+            assert float(gm.norm()) < 1e-3 * big, (what, n, float(gm.norm()), rn)
+        else:
+            e = abs(float(gm.norm()) - rn) / rn
+            if e > worst_norm[1]:
+                worst_norm = (n, e)
+        key = f"grad_g/{n}"
+        if key not in g.files:
+            continue
+        ref = torch.from_numpy(g[key]).double()
+        rk = f"grad_r/{n}"
+        got = gm.reshape(-1, gm.shape[-1])[torch.from_numpy(g[rk])] if rk in g.files else gm.reshape(ref.shape)
+        # (2) values: error of the stored part relative to its own norm, floored by its share of the whole tensor's norm
+        floor = rn * (ref.numel() / gm.numel()) ** 0.5
+        den = max(float(ref.norm()), floor, 1e-4 * big * (ref.numel() / gm.numel()) ** 0.5)
+        e = float((got - ref).norm()) / den
+        n_vals += 1
+        if e > worst_val[1]:
+            worst_val = (n, e)
+    print(f"{what}: {len(names)} tensor norms, worst {worst_norm[0]} {worst_norm[1]:.2e}; {n_vals} tensors by value, worst "
+          f"{worst_val[0]} {worst_val[1]:.2e}")
+    assert worst_norm[1] < tol, (what, worst_norm)
+    assert worst_val[1] < tol, (what, worst_val)
+
+
+def _dual_modules(g, dev):
+    import hsenet_amd as H
+    from oracle import ref_cpu as R
+    img, patch = tuple(int(v) for v in g["img"]), tuple(int(v) for v in g["patch"])
+    grid, kernel = tuple(int(v) for v in g["grid"]), tuple(int(v) for v in g["kernel"])
+    tower = H.build_vision_tower(Cfg(img, patch)).eval()
+    args = (img, patch, 768, 3072, "mlp", 2)
+    p1 = H.VisualPacker_3d_phi_v3(*args, grid=grid, kernel_size=kernel).eval()
+    p2 = H.VisualPacker_3d_phi_v3(*args, grid=grid, kernel_size=kernel).eval()
+    for m, seed in ((tower, g["seed_tower"]), (p1, g["seed_p1"]), (p2, g["seed_p2"])):
+        m.load_state_dict(R.seeded_state_dict(m, int(seed)))
+        m.to(dev)
+    x = R.synthetic_volume((1, 1) + img, int(g["seed_x"])).to(dev)
+    s = R.synthetic_slices(1, int(g["seed_s"])).to(dev)
+    w = torch.from_numpy(np.random.default_rng(int(g["seed_w"])).standard_normal((1, 256, 3072), dtype=np.float32)).to(dev)
+    return tower, p1, p2, x, s, w
+
+
+def _named(tower, p1, p2):
+    return ([("vision_tower." + n, p) for n, p in tower.named_parameters()] + [("mm_projector." + n, p) for n, p in p1.named_parameters()]
+            + [("mm_projector2." + n, p) for n, p in p2.named_parameters()])
+
+
+def _rel(a, b):
+    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    return float((a - b).norm() / b.norm())
+
+
+@pytest.mark.parametrize("name", ["grad_native_dual.npz", "grad_dual256.npz"])
+def test_dual_engine_vs_reference_gradients(dev, golden, name):
+    """BASELINE configs[2] (and its reference-native twin) through DualEngine — the bench path."""
+    from hsenet_amd.engine import DualEngine
+    g = golden(name)
+    tower, p1, p2, x, s, w = _dual_modules(g, dev)
+    eng = DualEngine(tower, p1, p2, 1)
+    out = eng.forward(x, s)
+    rows = [int(r) for r in g["out_rows_idx"]]
+    e_rows, e_norm = _rel(out[:, rows], g["out_rows"]), _rel(out.norm(dim=-1), g["out_row_norms"])
+    print(f"{name} forward: rows {e_rows:.2e} row norms {e_norm:.2e}")
+    assert e_rows < TOL and e_norm < TOL
+    eng.dout.copy_(w)
+    eng.backward(eng.dout)
+    torch.cuda.synchronize()
+    check_grads(_named(tower, p1, p2), g, f"DualEngine {name}")
+
+
+def test_dual_module_path_vs_reference_gradients(dev, golden):
+    """the drop-in module API (autograd Functions) at the reference-native geometry."""
+    import hsenet_amd as H
+    g = golden("grad_native_dual.npz")
+    tower, p1, p2, x, s, w = _dual_modules(g, dev)
+    out = H.encode_images(tower, p1, p2, x, s)
+    (out * w).sum().backward()
+    torch.cuda.synchronize()
+    check_grads(_named(tower, p1, p2), g, "module path native dual")
+
+
+@pytest.mark.parametrize("path", ["engine", "module"])
+def test_vit256_stage1_vs_reference_gradients(dev, golden, path):
+    """BASELINE configs[1]: 256^3 ViT_stage1, N = 4097, L = 12 — FlatEncoder (4 layer chunks) and the autograd path."""
+    import hsenet_amd as H
+    from hsenet_amd.engine import FlatEncoder
+    from oracle import ref_cpu as R
+    g = golden("grad_vit256_stage1.npz")
+    img, patch = (256,) * 3, (16,) * 3
+    m = H.ViT_stage1(in_channels=1, img_size=img, patch_size=patch, pos_embed="perceptron", classification=True).eval()
+    m.load_state_dict(R.seeded_state_dict(m, int(g["seed_w"])))
+    m.to(dev)
+    x = R.synthetic_volume((1, 1) + img, int(g["seed_x"])).to(dev)
+    w = torch.from_numpy(np.random.default_rng(int(g["seed_dy"])).standard_normal((1, 4097, 768), dtype=np.float32)).to(dev)
+    if path == "engine":
+        eng = FlatEncoder(m, 1, n_buckets=4)
+        assert len(eng.layer_chunks) == 4
+        eng.forward(x)
+        eng.backward(w)
+    else:
+        y, _ = m(x)
+        (y * w).sum().backward()
+    torch.cuda.synchronize()
+    check_grads(list(m.named_parameters()), g, f"ViT_stage1 256^3 ({path})")

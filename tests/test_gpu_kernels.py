@@ -201,6 +201,38 @@ def test_attn_bwd(dev, N):
         assert e < 1.5e-2, (name, e)
 
 
+@pytest.mark.parametrize("N", [2049, 4097])
+def test_attn_bwd_full_length_vs_fp64(dev, N):
+    """the sequence lengths the encoders actually run (native 2049, 256^3 4097) against an fp64 statement of SABlock's core:
+    B=2 x H=12 like a real layer; the fp64 reference is evaluated head by head on the GPU (N x N fp64 = 134 MB per head)."""
+    from hsenet_amd import functional as Fn, _lib as L
+    B, H = 2, 12
+    D = H * 64
+    qkv = rnd((B, N, 3 * D), 640 + N, dev, 1.1).bfloat16()
+    d_o = rnd((B, N, D), 641 + N, dev).bfloat16()
+    o, lse = Fn.attn_fwd(qkv, H, L.PREC_BF16)
+    dqkv = Fn.attn_bwd(qkv, o, d_o, lse, H).float()
+    num, den = torch.zeros(3, dtype=torch.float64, device=dev), torch.zeros(3, dtype=torch.float64, device=dev)
+    worst_head = 0.0
+    for b in range(B):
+        for h in range(H):
+            sl = [slice(i * D + h * 64, i * D + (h + 1) * 64) for i in range(3)]
+            q, k, v = (qkv[b, :, s].double().requires_grad_() for s in sl)
+            p = (q @ k.t() * 0.125).softmax(-1)
+            ro = p @ v
+            assert rel(o[b, :, h * 64:(h + 1) * 64].float(), ro.detach()) < 6e-3
+            gq, gk, gv = torch.autograd.grad((ro * d_o[b, :, h * 64:(h + 1) * 64].double()).sum(), (q, k, v))
+            for i, g in enumerate((gq, gk, gv)):
+                diff = (dqkv[b, :, sl[i]].double() - g).pow(2).sum()
+                num[i] += diff
+                den[i] += g.pow(2).sum()
+                worst_head = max(worst_head, float((diff / g.pow(2).sum()).sqrt()))
+            del q, k, v, p, ro, gq, gk, gv
+    errs = (num / den).sqrt().tolist()
+    print(f"attn bwd N={N}: dq {errs[0]:.2e} dk {errs[1]:.2e} dv {errs[2]:.2e}; worst single head/tensor {worst_head:.2e}")
+    assert max(errs) < 1.5e-2 and worst_head < 2e-2
+
+
 @pytest.mark.parametrize("rows,d", [(5, 768), (1030, 768), (64, 384), (7, 1024)])
 def test_layernorm(dev, rows, d):
     from hsenet_amd import functional as Fn, _lib as L
