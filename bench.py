@@ -95,12 +95,33 @@ def cpu_model():
     return platform.processor() or "unknown CPU"
 
 
+def host_cores():
+    """cores this process may actually use: the affinity mask, capped by the cgroup CPU quota (a GPU box hands each lease a share
+    of a much larger host; oversubscribing torch's thread pool beyond that share makes the CPU leg many times slower)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except Exception:
+            pass
+    return max(1, n)
+
+
 def cpu_baseline(workload, geom, cap_seconds=150.0):
     """the oracle (port of the reference's CPU path) on ALL host cores for the SAME workload: one volume fwd+bwd in fp32,
-    1 warm-up + up to 3 timed iterations (fewer only if the warm-up shows they would exceed `cap_seconds`), median."""
+    1 warm-up + up to 3 timed iterations (fewer only if the warm-up shows they would exceed `cap_seconds`), median.  "All cores" =
+    host_cores(): the cores the lease may use, stated in the result."""
     from oracle import ref_cpu as R
-    threads = os.cpu_count() or 1
+    threads = host_cores()
     torch.set_num_threads(threads)
+    print(f"[bench] cpu_baseline: {threads} usable cores of {os.cpu_count()} visible", file=sys.stderr, flush=True)
     img, patch = geom["img"], geom["patch"]
     x = R.synthetic_volume((1, 1) + img, 1234)
     if workload in ("dual256", "native_dual"):
@@ -132,6 +153,7 @@ def cpu_baseline(workload, geom, cap_seconds=150.0):
     t0 = time.perf_counter()
     step()                                           # warm-up (allocator, thread pool, first-touch)
     warm = time.perf_counter() - t0
+    print(f"[bench] cpu_baseline: warm-up iteration {warm:.1f} s", file=sys.stderr, flush=True)
     n = max(1, min(3, int((cap_seconds - warm) // max(warm, 1e-3))))
     times = []
     for _ in range(n):
@@ -140,6 +162,7 @@ def cpu_baseline(workload, geom, cap_seconds=150.0):
         t0 = time.perf_counter()
         step()
         times.append(time.perf_counter() - t0)
+        print(f"[bench] cpu_baseline: timed iteration {times[-1]:.1f} s", file=sys.stderr, flush=True)
     med = float(np.median(times))
     return dict(value=1.0 / med, unit="CT-volumes/sec", cores=threads, kind="port",
                 sample=f"1 volume {img} fwd+bwd of {what}, fp32, torch {torch.__version__} CPU oracle (oracle/ref_cpu.py) on "
@@ -163,6 +186,10 @@ def build_engine(workload, geom, batch, dev, group=None):
         from hsenet_amd.clip_step import ClipStage2Engine, make_clip_stage2
         model = make_clip_stage2(img, patch).to(dev)
         eng = ClipStage2Engine(model, batch, lr=1e-4, weight_decay=0.1, group=group)
+        rng = np.random.default_rng(4321 + int(os.environ.get("RANK", "0")))
+        txt = [torch.nn.functional.normalize(torch.from_numpy(rng.standard_normal((batch, 768), dtype=np.float32)), dim=-1).to(dev)
+               for _ in range(2)]                                   # frozen text embeddings: normalize(N(0,1))
+        eng.set_text_features(*txt)
         return eng, model.vision_encoder.patch_embedding, True
     model = H.ViT_stage1(in_channels=1, img_size=img, patch_size=patch, pos_embed="perceptron", classification=True).to(dev)
     eng = FlatEncoder(model, batch, lr=1e-4, weight_decay=0.1, group=group)

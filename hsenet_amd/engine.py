@@ -121,6 +121,37 @@ def _seeds(desc, train: bool) -> None:
         desc.drop_p = 0.0
 
 
+def encoder_head_params(m) -> List[Tuple[str, nn.Parameter]]:
+    """embedding-driver parameters in ITS order (hs_embed_*: cls, pos, pe.w, pe.b [, scorer x12]) with their state-dict names."""
+    out = []
+    if hasattr(m, "cls_token"):
+        out.append(("cls_token", m.cls_token))
+    out += [("patch_embedding.position_embeddings", m.patch_embedding.position_embeddings),
+            ("patch_embedding.patch_embeddings.1.weight", m.patch_embedding.patch_embeddings[1].weight),
+            ("patch_embedding.patch_embeddings.1.bias", m.patch_embedding.patch_embeddings[1].bias)]
+    if isinstance(m, ViT_stage2):
+        out += [("patch_score_proj.weight", m.patch_score_proj.weight), ("patch_score_proj.bias", m.patch_score_proj.bias)]
+        sga = m.slice_guided_attention
+        for nm in ("Wq", "Wk", "Wv", "output_linear"):
+            lin = getattr(sga, nm)
+            out += [(f"slice_guided_attention.{nm}.weight", lin.weight), (f"slice_guided_attention.{nm}.bias", lin.bias)]
+        out += [("slice_guided_attention.norm.weight", sga.norm.weight), ("slice_guided_attention.norm.bias", sga.norm.bias)]
+    return out
+
+
+def encoder_flat_order(m) -> List[Tuple[str, nn.Parameter]]:
+    """[head.., blocks.0 .. blocks.L-1, norm]: the order the backward pass completes from the END."""
+    named = dict(m.named_parameters())
+    out = encoder_head_params(m)
+    for l in range(len(m.blocks)):
+        pre = f"blocks.{l}."
+        out += [(n, p) for n, p in named.items() if n.startswith(pre)]
+    out += [("norm.weight", m.norm.weight), ("norm.bias", m.norm.bias)]
+    if len(out) != len(named) or {n for n, _ in out} != set(named):
+        raise L.HsError("every encoder parameter must be in the flat order exactly once")
+    return out
+
+
 class EncoderUnit:
     """One encoder (P4 ViT_stage1 / P6 ViT_stage2) on the fused drivers: hs_embed_* + hs_vit_blocks_*, own workspaces."""
 
@@ -162,33 +193,10 @@ class EncoderUnit:
 
     # ---- parameter lists (the fused drivers' orders) ------------------------------------------------------------------
     def head_params(self) -> List[Tuple[str, nn.Parameter]]:
-        """embedding-driver parameters in ITS order (hs_embed_*: cls, pos, pe.w, pe.b [, scorer x12]) with state-dict names."""
-        m = self.model
-        out = []
-        if self.has_cls:
-            out.append(("cls_token", m.cls_token))
-        out += [("patch_embedding.position_embeddings", m.patch_embedding.position_embeddings),
-                ("patch_embedding.patch_embeddings.1.weight", m.patch_embedding.patch_embeddings[1].weight),
-                ("patch_embedding.patch_embeddings.1.bias", m.patch_embedding.patch_embeddings[1].bias)]
-        if self.scorer:
-            out += [("patch_score_proj.weight", m.patch_score_proj.weight), ("patch_score_proj.bias", m.patch_score_proj.bias)]
-            sga = m.slice_guided_attention
-            for nm in ("Wq", "Wk", "Wv", "output_linear"):
-                lin = getattr(sga, nm)
-                out += [(f"slice_guided_attention.{nm}.weight", lin.weight), (f"slice_guided_attention.{nm}.bias", lin.bias)]
-            out += [("slice_guided_attention.norm.weight", sga.norm.weight), ("slice_guided_attention.norm.bias", sga.norm.bias)]
-        return out
+        return encoder_head_params(self.model)
 
     def flat_order(self) -> List[Tuple[str, nn.Parameter]]:
-        """[head.., blocks.0 .. blocks.L-1, norm]: the order the backward pass completes from the END."""
-        named = dict(self.model.named_parameters())
-        out = self.head_params()
-        for l in range(self.Ln):
-            pre = f"blocks.{l}."
-            out += [(n, p) for n, p in named.items() if n.startswith(pre)]
-        out += [("norm.weight", self.model.norm.weight), ("norm.bias", self.model.norm.bias)]
-        assert len(out) == len(named), "every encoder parameter must be in the flat order exactly once"
-        return out
+        return encoder_flat_order(self.model)
 
     def bind(self) -> None:
         """(re)build the device-pointer tables after the parameters were adopted into flat buffers."""

@@ -418,7 +418,7 @@ def seeded_state_dict(module: nn.Module, seed: int) -> dict:
         a = rng.standard_normal(tuple(t.shape), dtype=np.float32) * 0.02
         if name.endswith("weight") and t.dim() == 1:       # LayerNorm gamma
             a = 1.0 + 2.5 * a
-        out[name] = torch.from_numpy(a)
+        out[name] = torch.from_numpy(np.asarray(a, dtype=np.float32))     # (asarray: a 0-d parameter such as logit_scale draws a scalar)
     return out
 
 

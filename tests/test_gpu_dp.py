@@ -86,3 +86,87 @@ def test_flat_encoder_matches_autograd_path(dev):
     for (n, p), (_, q) in zip(m_eng.named_parameters(), m_ref.named_parameters()):
         e = float((p.grad - q.grad).norm() / q.grad.norm().clamp_min(1e-20))
         assert e < 2e-3, (n, e)       # atomics order / bucket chunking only
+
+
+# ---- the stage-2 CLIP step (configs[3]) across ranks: all-gather of the cls features inside the step + bucketed all-reduce ----
+CLIP_GEOM = dict(img_size=(8, 64, 64), patch_size=(4, 16, 16), num_layers=2)
+
+
+def _clip_model(dev):
+    from hsenet_amd.clip import M3DCLIPVision_stage2
+    from oracle import clip_cpu as RC, ref_cpu as R
+    ref = RC.M3DCLIPVision_stage2(CLIP_GEOM["img_size"], CLIP_GEOM["patch_size"], CLIP_GEOM["num_layers"])
+    sd = R.seeded_state_dict(ref, 87)
+    sd["logit_scale"] = torch.tensor(float(np.log(1 / 0.07)))
+    sd["stage1_pretrained_CLIP.logit_scale"] = sd["logit_scale"].clone()
+    m = M3DCLIPVision_stage2(**CLIP_GEOM)
+    m.load_state_dict(sd)
+    return m.to(dev).eval()
+
+
+def _clip_inputs(n):
+    from oracle import clip_cpu as RC, ref_cpu as R
+    return (R.synthetic_volume((n, 1, 8, 64, 64), 88), R.synthetic_slices(n, 89), RC.synthetic_text_features(n, 90),
+            RC.synthetic_text_features(n, 91))
+
+
+def _clip_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from hsenet_amd.clip_step import ClipStage2Engine
+        from hsenet_amd import clip
+        dev = torch.device("cuda:0")
+        eng = ClipStage2Engine(_clip_model(dev), 4, lr=1e-3)
+        assert eng.world == 2 and eng.all.shape[0] == 8
+        x, s, t1, t2 = (t[rank * 4:(rank + 1) * 4].to(dev) for t in _clip_inputs(8))
+        for _ in range(2):
+            eng.train_step(x, s, t1, t2)
+        torch.cuda.synchronize()
+        # local_loss branch across ranks: sum over ranks of the per-rank losses, gradient w.r.t. this rank's features
+        im, tm = t1.clone().requires_grad_(), t2.clone().requires_grad_()
+        sc = torch.tensor(2.0, device=dev)
+        loss, lpi, lpt = clip.image_text_contrastive_learning(im, tm, sc, local_loss=True)
+        loss.backward()
+        torch.cuda.synchronize()
+        torch.save(dict(flat=eng.flat.cpu(), loss=float(loss), gi=im.grad.cpu(), gt=tm.grad.cpu(), lpi=lpi.detach().cpu()), f"{out}.{rank}")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_clip_step_two_ranks_match_single_rank(dev, tmp_path):
+    """2 ranks x 4 volumes == 1 rank x 8 volumes for the stage-2 CLIP step (the cls features are all-gathered inside the step, the
+    logits are 8x8 on both ranks); and the local_loss=True branch across 2 ranks vs the oracle's restatement of each rank's loss."""
+    from hsenet_amd.clip_step import ClipStage2Engine
+    from oracle import clip_cpu as RC
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "clip2")
+    mp.spawn(_clip_worker, args=(2, port, out), nprocs=2, join=True)
+    r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
+    assert torch.equal(r0["flat"], r1["flat"])                      # replicas stay identical
+    eng = ClipStage2Engine(_clip_model(dev), 8, lr=1e-3)
+    x, sl, t1, t2 = (t.to(dev) for t in _clip_inputs(8))
+    p0 = eng.flat.clone()
+    for _ in range(2):
+        eng.train_step(x, sl, t1, t2)
+    torch.cuda.synchronize()
+    single = eng.flat.cpu()
+    moved, diff = float((single - p0.cpu()).norm()), float((single - r0["flat"]).norm())
+    print(f"clip step: param movement {moved:.3e}, |dp2 - single| {diff:.3e}")
+    assert moved > 0 and diff < 3e-2 * moved
+    # local_loss: rank r's loss uses its 4 rows against all 8; gather_with_grad sums every rank's gradient into the local rows
+    _, _, t1c, t2c = _clip_inputs(8)
+    ir, tr = t1c.clone().requires_grad_(), t2c.clone().requires_grad_()
+    total = 0
+    for r, got in enumerate((r0, r1)):
+        lo, lpi, _ = RC.image_text_contrastive_learning(ir[r * 4:(r + 1) * 4], tr[r * 4:(r + 1) * 4], torch.tensor(2.0), local_loss=True,
+                                                        world=2, rank=r, all_image_features=ir, all_text_features=tr)
+        assert abs(float(lo) - got["loss"]) < 1e-5 and float((lpi.detach() - got["lpi"]).abs().max()) < 1e-5
+        total = total + lo
+    total.backward()
+    for r, got in enumerate((r0, r1)):
+        assert float((got["gi"] - ir.grad[r * 4:(r + 1) * 4]).abs().max()) < 1e-5
+        assert float((got["gt"] - tr.grad[r * 4:(r + 1) * 4]).abs().max()) < 1e-5

@@ -227,3 +227,72 @@ def test_trunk2d_state_dict_is_timm_ordered():
                     "blocks.0.mlp.fc1.bias", "blocks.0.mlp.fc2.weight", "blocks.0.mlp.fc2.bias", "norm.weight", "norm.bias"]
     from oracle import trunk2d_cpu as T
     assert list(T.Trunk(depth=1).state_dict()) == keys
+
+
+# ---- round 2: CLIP stage-2 pieces of the oracle (oracle/clip_cpu.py) against torch.nn.functional identities ----
+def test_clip_cpu_pieces():
+    import torch.nn.functional as F
+    from oracle import clip_cpu as RC
+    assert RC.relation_loss_weight(0) == 0.1 and abs(RC.relation_loss_weight(2500) - 0.05) < 1e-15
+    assert RC.relation_loss_weight(5000) == 0.0 and RC.relation_loss_weight(10 ** 6) == 0.0 and RC.relation_loss_weight(None) == 0.0
+    i, t = RC.synthetic_text_features(6, 1), RC.synthetic_text_features(6, 2)
+    assert torch.allclose(i.norm(dim=-1), torch.ones(6), atol=1e-6)
+    s = torch.tensor(2.659)
+    l0, a0, b0 = RC.image_text_contrastive_learning(i, t, s)
+    l1, a1, b1 = RC.image_text_contrastive_learning(i, t, s, local_loss=True)
+    assert torch.allclose(l0, l1, atol=1e-6) and torch.allclose(a0, a1, atol=1e-6) and torch.allclose(b0, b1, atol=1e-5)   # world 1
+    assert torch.allclose(b0, a0.T) and torch.allclose(l0, R.clip_contrastive_loss(i, t, s), atol=1e-6)
+    # rank-local loss over two "ranks": the mean of the per-rank losses is the global loss
+    per = [RC.image_text_contrastive_learning(i[r * 3:(r + 1) * 3], t[r * 3:(r + 1) * 3], s, True, 2, r, i, t)[0] for r in range(2)]
+    assert torch.allclose((per[0] + per[1]) / 2, l0, atol=1e-6)
+    i2, t2 = RC.synthetic_text_features(6, 3), RC.synthetic_text_features(6, 4)
+    _, a2, b2 = RC.image_text_contrastive_learning(i2, t2, s)
+    rr = RC.image_text_relation_regulation(a0, b0, a2, b2)
+    assert torch.allclose(rr, F.mse_loss(a0, a2), atol=1e-7)               # logits_per_text is the transpose: the two terms are equal
+    e, f = torch.randn(2, 300, 16), torch.randn(2, 256, 16)
+    o = RC.splice_image_features(e, f)
+    assert o.shape == (2, 300, 16) and torch.equal(o[:, 0], e[:, 0]) and torch.equal(o[:, 1:257], f) and torch.equal(o[:, 257:], e[:, 257:])
+    assert RC.splice_image_features(e[:, :100], f).shape == (2, 257, 16)    # a short prompt is simply overrun (lamed_arch.py:153)
+
+
+def test_clip_cpu_stage2_step_small():
+    """the restated stage-2 forward: frozen tower gets no gradient, the relation term switches off after 5000 steps."""
+    from oracle import clip_cpu as RC
+    m = RC.M3DCLIPVision_stage2((8, 32, 32), (4, 16, 16), 1)
+    x, s = R.synthetic_volume((3, 1, 8, 32, 32), 5), R.synthetic_slices(3, 6)
+    t1, t2 = RC.synthetic_text_features(3, 7), RC.synthetic_text_features(3, 8)
+    a = m(x, t1, t2, s, global_step=0)
+    b = m(x, t1, t2, s, global_step=5000)
+    assert float(a["loss"]) > float(b["loss"]) and torch.allclose(b["loss"], b["loss_CL_stage2"])
+    assert torch.allclose(a["loss"], a["loss_CL_stage2"] + 0.1 * a["loss_relation"])
+    a["loss"].backward()
+    assert all(p.grad is None for p in m.stage1_pretrained_CLIP.parameters())
+    assert m.logit_scale.grad is not None and m.vision_encoder.cls_token.grad is not None
+
+
+def test_engine_flat_layout_and_decay_rules():
+    """host logic of hsenet_amd/engine.py on the CPU: flat order covers every parameter once, head first / final norm last (so the
+    backward pass completes contiguous ranges from the end), bucket bounds tile the buffer, the decay mask follows HF Trainer."""
+    import hsenet_amd as H
+    from hsenet_amd import engine as E
+    kw = dict(in_channels=1, img_size=(8, 64, 64), patch_size=(4, 16, 16), num_layers=4, pos_embed="perceptron", classification=True)
+    for cls, n_head in ((H.ViT_stage1, 4), (H.ViT_stage2, 16)):
+        m = cls(**kw)
+        order = E.encoder_flat_order(m)
+        names = [n for n, _ in order]
+        assert sorted(names) == sorted(n for n, _ in m.named_parameters()) and len(set(names)) == len(names)
+        assert names[0] == "cls_token" and names[n_head] == "blocks.0.mlp.linear1.weight" and names[-2:] == ["norm.weight", "norm.bias"]
+        assert [n for n, _ in E.encoder_head_params(m)] == names[:n_head]
+        dec = E.decays(m)
+        entries = [(n, p, dec[n]) for n, p in order]
+        fp = E.FlatParams(entries, torch.device("cpu"))
+        assert fp.total % 64 == 0 and all(o % 64 == 0 for o in fp.offsets)
+        sd_keys = list(m.state_dict().keys())
+        assert sd_keys == list(cls(**kw).state_dict().keys())                  # adoption leaves the state-dict contract alone
+        for (n, p, d_), o in zip(entries, fp.offsets):
+            assert p.data_ptr() == fp.flat.data_ptr() + 4 * o and p.grad.data_ptr() == fp.grad.data_ptr() + 4 * o
+            parent = n.split(".")[-2] if "." in n else ""
+            assert bool(fp.decay_mask[o // 64]) == d_ == (("bias" not in n) and not parent.startswith("norm"))
+        chunks, bounds = E.bucket_plan(names, fp.offsets, fp.total, 4, 3)
+        assert chunks == [(4, 2), (2, 0)] and bounds[0][1] == fp.total and bounds[-1][0] == 0
+        assert all(a[0] == b[1] for a, b in zip(bounds, bounds[1:]))
