@@ -106,7 +106,7 @@ SIGNATURES = {
     "hs_packer_fwd": [C.POINTER(PackerDesc), _vp, _vp, _vp, _vp, _sz, _vp],
     "hs_packer_bwd": [C.POINTER(PackerDesc), _vp, _vp, _vp, _vp, _vp, _sz, _vp],
     "hs_mse_grad": [_vp, _vp, _vp, _i64, _vp],
-    "hs_sumsq": [_vp, _vp, _i64, _vp],
+    "hs_sumsq": [_vp, _vp, _vp, _i64, _vp],
     "hs_adamw_masked": [_vp, _vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _f, _vp, _f, _i, _vp],
     "hs_rows_copy": [_vp, _i64, _vp, _vp, _i64, _i, _i, _i, _vp],
     "hs_rows_scatter": [_vp, _vp, _i, _i, _i, _i, _i, _vp],

@@ -474,30 +474,43 @@ extern "C" int hs_mse_grad(const float* y, float* dy, float* loss, int64_t n, vo
     return HS_OK;
 }
 
-// out[0] += sum(x^2)   (global gradient norm for clipping; caller zeroes out)
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, float* __restrict__ out, long n) {
+// out[0] = sum(x^2), DETERMINISTIC (fixed grid, fixed reduction order, no atomics): the clip coefficient derived from it must be
+// bit-identical on every data-parallel rank, or the replicas drift apart by an ulp per step.  scratch: SUMSQ_BLOCKS floats.
+#define SUMSQ_BLOCKS 1024
+__device__ __forceinline__ float block_sum_256(float acc, float* red) {
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ x, float* __restrict__ part, long n) {
+    __shared__ float red[4];
     float acc = 0.f;
-    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long)gridDim.x * 1024) {
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long)SUMSQ_BLOCKS * 1024) {
         if (i + 4 <= n) {
             const f32x4 v = *(const f32x4*)(x + i);
-            acc += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+            acc += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
         } else {
             for (long j = i; j < n; ++j) acc += x[j] * x[j];
         }
     }
-    __shared__ float red[4];
-    acc = wave_sum(acc);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+    acc = block_sum_256(acc, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = acc;
 }
-extern "C" int hs_sumsq(const float* x, float* out, int64_t n, void* stream) {
-    if (!x || !out) return HS_ERR_ARG;
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const float* __restrict__ part, float* __restrict__ out) {
+    __shared__ float red[4];
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < SUMSQ_BLOCKS / 256; ++k) acc += part[threadIdx.x + 256 * k];
+    acc = block_sum_256(acc, red);
+    if (threadIdx.x == 0) out[0] = acc;
+}
+extern "C" int hs_sumsq(const float* x, float* out, float* scratch, int64_t n, void* stream) {
+    if (!x || !out || !scratch) return HS_ERR_ARG;
     if (n < 1 || ((uintptr_t)x & 15)) return HS_ERR_SHAPE;
-    long blocks = (n + 1023) / 1024;
-    if (blocks > 2048) blocks = 2048;
     ProfScope prof(HS_PROF_OTHER, stream, 0, (double)n * 4);
-    hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, out, (long)n);
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(SUMSQ_BLOCKS), dim3(256), 0, (hipStream_t)stream, x, scratch, (long)n);
+    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)scratch, out);
     HS_CHECK_LAUNCH();
     return HS_OK;
 }

@@ -17,6 +17,7 @@ remaining backward kernels run.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 from typing import Callable, List, Optional, Sequence, Tuple
 
@@ -90,6 +91,7 @@ class FlatParams:
                 mask[o // 64:(o + _al(p.numel())) // 64] = 1
         self.decay_mask = mask.to(device)
         self.gsq = torch.zeros(1, dtype=torch.float32, device=device)
+        self._gsq_scratch = torch.zeros(1024, dtype=torch.float32, device=device)
         self.step_no = 0
 
     def offset(self, name: str) -> int:
@@ -102,8 +104,7 @@ class FlatParams:
         s = Fn._s()
         gsq = None
         if max_grad_norm is not None and max_grad_norm > 0:
-            self.gsq.zero_()
-            L.call("hs_sumsq", self.grad.data_ptr(), self.gsq.data_ptr(), self.total, s)
+            L.call("hs_sumsq", self.grad.data_ptr(), self.gsq.data_ptr(), self._gsq_scratch.data_ptr(), self.total, s)
             gsq = self.gsq.data_ptr()
         L.call("hs_adamw_masked", self.flat.data_ptr(), self.grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
                self.decay_mask.data_ptr(), self.total, lr, betas[0], betas[1], eps, weight_decay, grad_scale, gsq,
@@ -407,7 +408,7 @@ class DualEngine(_Engine):
     backward = packers -> 2E3 encoder -> 3D-ViT encoder, gradient ranges all-reduced as they complete."""
 
     def __init__(self, tower: ViT3DTower_dual_encoders, packer1: VisualPacker_3d_phi_v3, packer2: VisualPacker_3d_phi_v3, batch: int, *,
-                 lr=1e-4, weight_decay=0.1, max_grad_norm: Optional[float] = 1.0, n_buckets=4, group=None):
+                 lr=1e-4, weight_decay=0.1, max_grad_norm: Optional[float] = 1.0, n_buckets=4, group=None, two_streams: bool = True):
         if tower.select_feature != "patch" or tower.remain_2d3d_ViT_type != "dual_vits":
             raise L.HsError("DualEngine drives the shipped configuration: select_feature='patch', remain_2d3d_ViT_type='dual_vits'")
         self.tower, self.B = tower, batch
@@ -430,34 +431,53 @@ class DualEngine(_Engine):
         for _, p, _ in entries:
             offs.append(off)
             off += _al(p.numel())
-        s2, sp = offs[len(e1)], offs[len(e1) + len(e2)]
+        s2, sp, sp2 = offs[len(e1)], offs[len(e1) + len(e2)], offs[len(e1) + len(e2) + len(ep1)]
         self.chunks1, b1 = _encoder_bounds(self.u1, names, offs, "vision_tower_stage1.", 0, s2, n_buckets)
         self.chunks2, b2 = _encoder_bounds(self.u2, names, offs, "vision_tower_stage2.", s2, sp, n_buckets)
-        bounds = [(sp, off)] + b2 + b1                   # backward-completion order: packers, 2E3 chunks, 3D-ViT chunks
+        # bucket ids: 0 = packer 2, 1 = packer 1, then the 2E3 chunks, then the 3D-ViT chunks (each in backward-completion order)
+        bounds = [(sp2, off), (sp, sp2)] + b2 + b1
         self._finish(entries, bounds, lr=lr, weight_decay=weight_decay, max_grad_norm=max_grad_norm, group=group)
         for u in (self.u1, self.u2, self.p1, self.p2):
             u.bind()
         self.patches = torch.empty(batch * self.u1.Np, self.u1.Pd, dtype=torch.bfloat16, device=self.dev)
         self.out = torch.empty(batch, 2 * self.p1.cells, packer1.out_dim, dtype=torch.float32, device=self.dev)
         self.dout = torch.empty_like(self.out)
+        # The two encoder/packer chains are independent between the shared patchify and the loss: run the 2E3 chain on a side HIP
+        # stream so the dispatcher can fill CUs one chain's launch leaves idle (small batches: a 4097-row GEMM has 153-204 tiles
+        # for 256 CUs, an attention launch 396 blocks for 512 slots).
+        self.two_streams = two_streams
+        self.side = torch.cuda.Stream(device=self.dev) if two_streams else None
+
+    def _fork(self):
+        if self.side is not None:
+            self.side.wait_stream(torch.cuda.current_stream())
+            return torch.cuda.stream(self.side)
+        return contextlib.nullcontext()
+
+    def _join(self):
+        if self.side is not None:
+            torch.cuda.current_stream().wait_stream(self.side)
 
     def forward(self, vol: torch.Tensor, image_2d: torch.Tensor) -> torch.Tensor:
         self._patchify(vol, self.tower.vision_tower_stage1.patch_embedding, self.patches)
-        y1 = self.u1.forward(self.patches)
-        y2 = self.u2.forward(self.patches, image_2d)
-        self.p1.forward(y1, self.out)
-        self.p2.forward(y2, self.out)
+        with self._fork():
+            self.p2.forward(self.u2.forward(self.patches, image_2d), self.out)
+        self.p1.forward(self.u1.forward(self.patches), self.out)
+        self._join()
         return self.out
 
     def backward(self, dout: torch.Tensor) -> None:
         Fn._need(dout)
         self.grad.zero_()
-        self.p2.backward(dout, self.u2.dy)
-        self.p1.backward(dout, self.u1.dy)
-        self.buckets.reduce(0)
         n2 = len(self.chunks2)
-        self.u2.backward(self.patches, self.u2.dy, self.chunks2, lambda i: self.buckets.reduce(1 + i))
-        self.u1.backward(self.patches, self.u1.dy, self.chunks1, lambda i: self.buckets.reduce(1 + n2 + i))
+        with self._fork():
+            self.p2.backward(dout, self.u2.dy)
+            self.buckets.reduce(0)
+            self.u2.backward(self.patches, self.u2.dy, self.chunks2, lambda i: self.buckets.reduce(2 + i))
+        self.p1.backward(dout, self.u1.dy)
+        self.buckets.reduce(1)
+        self.u1.backward(self.patches, self.u1.dy, self.chunks1, lambda i: self.buckets.reduce(2 + n2 + i))
+        self._join()
         self.buckets.wait()
 
     def train_step(self, vol: torch.Tensor, image_2d: torch.Tensor) -> None:

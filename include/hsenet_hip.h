@@ -293,13 +293,14 @@ int hs_packer_bwd(const hs_packer_desc* desc, const float* dout, const float* co
 
 /* ---- train-step glue (the measurement harness' stand-in for HF Trainer: optim adamw_torch, weight_decay 0.1, max_grad_norm 1.0)
  * hs_mse_grad: L = mean(y^2): dy = 2 y / n, loss[0] += L (loss optional, caller zeroes).
- * hs_sumsq: out[0] += sum(x^2) (caller zeroes) -- the squared global gradient norm, kept on the device.
+ * hs_sumsq: out[0] = sum(x^2) -- the squared global gradient norm, kept on the device.  Deterministic (fixed reduction order, no
+ *   atomics; scratch: 1024 floats): every data-parallel rank must derive the SAME clip coefficient or the replicas drift.
  * hs_adamw_masked: hs_adamw with (a) decay_mask: one byte per 64-element chunk of the flat buffer, 0 = no weight decay (biases and
  *   LayerNorm weights, as HF Trainer's get_decay_parameter_names), NULL = decay everything; (b) grad_sumsq (device, optional):
  *   squared norm of the SUMMED gradient; the update uses g * grad_scale * min(1, max_grad_norm / (sqrt(sumsq)*grad_scale + 1e-6))
  *   = torch.nn.utils.clip_grad_norm_ on the DP-mean gradient, without a host round trip. */
 int hs_mse_grad(const float* y, float* dy, float* loss, int64_t n, void* stream);
-int hs_sumsq(const float* x, float* out, int64_t n, void* stream);
+int hs_sumsq(const float* x, float* out, float* scratch, int64_t n, void* stream);
 int hs_adamw_masked(float* p, const float* g, float* m, float* v, const unsigned char* decay_mask, int64_t n, float lr, float beta1,
                     float beta2, float eps, float weight_decay, float grad_scale, const float* grad_sumsq, float max_grad_norm,
                     int step, void* stream);
