@@ -99,6 +99,7 @@ class ClipStage2Engine(_Engine):
         self.dall = torch.empty(n, d, **f32)
         self.acc = torch.zeros(4, **f32)                           # [CE loss, sum(dlogits*logits), relation MSE, -]
         self.global_step = 0
+        self.side = torch.cuda.Stream(device=self.dev)
 
     # ------------------------------------------------------------------------------------------------------------------------
     def _logits(self, col_img: int, col_txt: int, raw: torch.Tensor, logits: torch.Tensor) -> None:
@@ -116,9 +117,14 @@ class ClipStage2Engine(_Engine):
         Fn._need(text_features_stage1, text_features)
         s, d, B = Fn._s(), self.u2.d, self.B
         self._patchify(images, self.model.vision_encoder.patch_embedding, self.patches)
-        self.u1.forward(self.patches)                                   # frozen stage-1 CLIP image tower (:124-127)
+        # the frozen tower on a side stream: independent of the 2E3 forward until the logits
+        self.side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.side):
+            self.u1.forward(self.patches)                               # frozen stage-1 CLIP image tower (:124-127)
+            f1 = self.h1.forward()
         self.u2.forward(self.patches, images_2d)                        # trainable 2E3 encoder (:131)
-        f1, f2 = self.h1.forward(), self.h2.forward()
+        f2 = self.h2.forward()
+        torch.cuda.current_stream().wait_stream(self.side)
         for i, t in enumerate((f1, text_features_stage1, f2, text_features)):
             L.call("hs_rows_copy", t.data_ptr(), d, self.local.data_ptr() + 4 * i * d, None, 4 * d, B, 1, d, s)
         if self.world > 1:

@@ -15,6 +15,11 @@
 #include <type_traits>
 
 #define NEG_INF (-__builtin_inff())
+#if HS_ABL & 1
+#define HS_BWD_EXP2(x) (x)
+#else
+#define HS_BWD_EXP2(x) __builtin_amdgcn_exp2f(x)
+#endif
 
 // XCD-aware block order for the attention kernels (1-D grid of nblk * H * B blocks).  Blocks are dealt round-robin
 // over the 8 XCDs; with the natural order the ~33 blocks of one (batch, head) — which all stream the same K/V (or
@@ -236,8 +241,12 @@ __device__ __forceinline__ unsigned lds_addr(const char* p) { return (unsigned)(
 template <int IMM>
 __device__ __forceinline__ void trR_issue(u32x4& f, unsigned b0, unsigned b1) {
     u32x2 lo, hi;
+#if HS_ABL & 2
+    asm volatile("" : "=&v"(lo), "=&v"(hi) : "v"(b0), "v"(b1));
+#else
     asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%4\n\tds_read_b64_tr_b16 %1, %3 offset:%4"
                  : "=&v"(lo), "=&v"(hi) : "v"(b0), "v"(b1), "i"(IMM) : "memory");
+#endif
     f[0] = lo[0]; f[1] = lo[1]; f[2] = hi[0]; f[3] = hi[1];
 }
 __device__ __forceinline__ void lds_settle2(u32x4& a, u32x4& b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b)::"memory"); }
@@ -565,251 +574,6 @@ __global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const float* __restri
 // ------------------------------------------------------------------------------------------------------
 // backward, bf16
 // ------------------------------------------------------------------------------------------------------
-// delta[b,h,n] = sum_d dO * O   (8 lanes per (n, head) row of 64)
-__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ d_o,
-                                                         float* __restrict__ delta, int B, int N, int H) {
-    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
-    const long total = (long)B * N * H * 8;
-    float acc = 0.f;
-    const bool ok = gid < total;
-    if (ok) {
-        const u32x4 a = *(const u32x4*)(o + gid * 8);
-        const u32x4 g = *(const u32x4*)(d_o + gid * 8);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            acc += __uint_as_float(a[i] << 16) * __uint_as_float(g[i] << 16);
-            acc += __uint_as_float(a[i] & 0xffff0000u) * __uint_as_float(g[i] & 0xffff0000u);
-        }
-    }
-    acc += __shfl_xor(acc, 1, 64);
-    acc += __shfl_xor(acc, 2, 64);
-    acc += __shfl_xor(acc, 4, 64);
-    if (ok && (threadIdx.x & 7) == 0) {
-        const long row = gid >> 3;  // (b*N + n)*H + head
-        const int head = (int)(row % H);
-        const long bn = row / H;
-        const int n = (int)(bn % N), b = (int)(bn / N);
-        delta[((long)b * H + head) * N + n] = acc;
-    }
-}
-
-// dK, dV: grid (ceil(N/128), H, B); each wave owns 32 keys, sweeps all queries in 64-row tiles.
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
-                                                            const float* __restrict__ lse, const float* __restrict__ delta,
-                                                            bf16_t* __restrict__ dqkv, int N, int H, float c2, float dk_mul) {
-    // c2 as in the forward kernels; dk_mul = dh^-0.5 / (factor q already carries)
-    // stage: Q image 8 KiB | dO image 8 KiB | -lse*log2(e)/c2 [64] f32 | -delta [64] f32
-    __shared__ __attribute__((aligned(16))) char smem[2 * 16896];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, c = lane & 31;
-    int blk, head, b;
-    attn_block_coords((N + 127) >> 7, H, blk, head, b);
-    const int k0 = blk * 128 + wave * 32;
-    const int Dm = H * 64, D3 = 3 * Dm;
-    const __amdgpu_buffer_rsrc_t rs = make_rsrc(qkv + (long)b * N * D3, (size_t)N * D3 * 2);
-    const __amdgpu_buffer_rsrc_t rsd = make_rsrc(d_o + (long)b * N * Dm, (size_t)N * Dm * 2);
-    const float* lse_b = lse + ((long)b * H + head) * N;
-    const float* del_b = delta + ((long)b * H + head) * N;
-    const float inv_scale = 1.44269504088896341f / c2;
-
-    const int key = k0 + c;
-    bf16x8 kf[4], vf[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        const unsigned off = key < N ? (unsigned)(((long)key * D3 + Dm + head * 64 + ks * 16 + 8 * h) * 2) : HS_OOB_OFF;
-        kf[ks] = __builtin_bit_cast(bf16x8, buf_load16(rs, off));
-        vf[ks] = __builtin_bit_cast(bf16x8, buf_load16(rs, key < N ? off + Dm * 2 : HS_OOB_OFF));
-    }
-    u32x4 rq[2], rd[2];
-    unsigned rstat = 0;
-    // waves 0/1 also fetch the tile's 64 lse / delta values.  Raw range-checked loads only: any arithmetic on a freshly
-    // loaded value here would force s_waitcnt vmcnt(0) and drain the whole next-tile prefetch before the MFMAs start.
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    const __amdgpu_buffer_rsrc_t rsl = make_rsrc(wave_u == 0 ? lse_b : del_b, (size_t)N * 4);
-    auto gload = [&](int t) {
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int idx = it * 256 + tid, q = t * 64 + (idx >> 3);
-            const bool ok = q < N;
-            const unsigned oq = (unsigned)(((long)q * D3 + head * 64 + (idx & 7) * 8) * 2);
-            const unsigned od = (unsigned)(((long)q * Dm + head * 64 + (idx & 7) * 8) * 2);
-            rq[it] = buf_load16(rs, ok ? oq : HS_OOB_OFF);
-            rd[it] = buf_load16(rsd, ok ? od : HS_OOB_OFF);
-        }
-        if (wave_u < 2) rstat = __builtin_amdgcn_raw_buffer_load_b32(rsl, (unsigned)(t * 64 + lane) * 4u, 0, 0);   // OOB -> 0
-    };
-    auto swrite = [&](int st, int t) {
-        char* sb = smem + st * 16896;
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int idx = it * 256 + tid, o_ = offR(idx >> 3, idx & 7);
-            *(u32x4*)(sb + o_) = rq[it];
-            *(u32x4*)(sb + 8192 + o_) = rd[it];
-        }
-        if (wave_u < 2) {
-            const float v = __uint_as_float(rstat);
-            const bool ok = t * 64 + lane < N;
-            // wave 0: -lse/scale (queries past N: -inf, so that P = exp2(-inf) = 0); wave 1: -delta
-            const float w = wave_u == 0 ? (ok ? -v * inv_scale : NEG_INF) : -v;
-            *(float*)(sb + 16384 + tid * 4) = w;
-        }
-    };
-    f32x16 dk[2] = {zero16(), zero16()}, dv[2] = {zero16(), zero16()};
-    const int nt = (N + 63) >> 6;
-    gload(0);
-    swrite(0, 0);
-    __syncthreads();
-    int cur = 0;
-    for (int t = 0; t < nt; ++t) {
-        const bool more = t + 1 < nt;
-        if (more) gload(t + 1);
-        const char* Ql = smem + cur * 16896;
-        const char* Dl = Ql + 8192;
-        const float* Ls = (const float*)(Ql + 16384);
-        const float* Ds = Ls + 64;
-#pragma unroll
-        for (int qb = 0; qb < 2; ++qb) {
-            f32x16 s, dp;
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const f32x4 lv = *(const f32x4*)(Ls + qb * 32 + 8 * g4 + 4 * h);
-                const f32x4 dl = *(const f32x4*)(Ds + qb * 32 + 8 * g4 + 4 * h);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    s[4 * g4 + e] = lv[e];
-                    dp[4 * g4 + e] = dl[e];
-                }
-            }
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Ql, qb * 32 + c, ks, h), kf[ks], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Dl, qb * 32 + c, ks, h), vf[ks], dp, 0, 0, 0);
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = __builtin_amdgcn_exp2f(s[r] * c2);
-                s[r] = p;
-                dp[r] = p * dp[r];
-            }
-#pragma unroll
-            for (int sp = 0; sp < 2; ++sp) {
-                const bf16x8 pf = pack8(s, sp), dsf = pack8(dp, sp);
-#pragma unroll
-                for (int db = 0; db < 2; ++db) {
-                    dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Dl, qb * 32 + 16 * sp, db, lane), pf, dv[db], 0, 0, 0);
-                    dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Ql, qb * 32 + 16 * sp, db, lane), dsf, dk[db], 0, 0, 0);
-                }
-            }
-        }
-        if (more) swrite(cur ^ 1, t + 1);
-        __syncthreads();
-        cur ^= 1;
-    }
-    if (key < N) {
-        bf16_t* row = dqkv + ((long)b * N + key) * D3 + head * 64;
-        store_dT(row + Dm, dk, dk_mul, h);
-        store_dT(row + 2 * Dm, dv, 1.0f, h);
-    }
-}
-
-// dQ: grid (ceil(N/128), H, B); each wave owns 32 queries, sweeps all keys in 64-row tiles.
-__global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
-                                                          const float* __restrict__ lse, const float* __restrict__ delta,
-                                                          bf16_t* __restrict__ dqkv, int N, int H, float c2, float scale) {
-    __shared__ __attribute__((aligned(16))) char smem[32768];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, c = lane & 31;
-    int blk, head, b;
-    attn_block_coords((N + 127) >> 7, H, blk, head, b);
-    const int q0 = blk * 128 + wave * 32;
-    const int Dm = H * 64, D3 = 3 * Dm;
-    const __amdgpu_buffer_rsrc_t rs = make_rsrc(qkv + (long)b * N * D3, (size_t)N * D3 * 2);
-    const __amdgpu_buffer_rsrc_t rsd = make_rsrc(d_o + (long)b * N * Dm, (size_t)N * Dm * 2);
-    const int qrow = min(q0 + c, N - 1);
-    bf16x8 qf[4], dof[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        qf[ks] = __builtin_bit_cast(bf16x8, buf_load16(rs, (unsigned)(((long)qrow * D3 + head * 64 + ks * 16 + 8 * h) * 2)));
-        dof[ks] = __builtin_bit_cast(bf16x8, buf_load16(rsd, (unsigned)(((long)qrow * Dm + head * 64 + ks * 16 + 8 * h) * 2)));
-    }
-    const float lq = lse[((long)b * H + head) * N + qrow] * 1.44269504088896341f;
-    const float dq_ = delta[((long)b * H + head) * N + qrow];
-    u32x4 rk[2], rv[2];
-    auto gload = [&](int t) {
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int idx = it * 256 + tid, key = t * 64 + (idx >> 3);
-            const unsigned off = key < N ? (unsigned)(((long)key * D3 + Dm + head * 64 + (idx & 7) * 8) * 2) : HS_OOB_OFF;
-            rk[it] = buf_load16(rs, off);
-            rv[it] = buf_load16(rs, key < N ? off + Dm * 2 : HS_OOB_OFF);
-        }
-    };
-    auto swrite = [&](int st) {
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int idx = it * 256 + tid, o_ = offR(idx >> 3, idx & 7);
-            *(u32x4*)(smem + st * 16384 + o_) = rk[it];
-            *(u32x4*)(smem + st * 16384 + 8192 + o_) = rv[it];
-        }
-    };
-    f32x16 dq[2] = {zero16(), zero16()};
-    const int nt = (N + 63) >> 6;
-    // one 64-key tile; LAST = the only tile that can hold keys >= N (separate instantiation: no masking in the loop)
-    auto tile = [&](int t, auto stage_tag, auto last_tag) {
-        constexpr bool LAST = decltype(last_tag)::value;
-        constexpr int ST = decltype(stage_tag)::value;
-        const char* Kl = smem + ST * 16384;
-        const char* Vl = Kl + 8192;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            f32x16 st = zero16(), dpt = zero16();
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Kl, kb * 32 + c, ks, h), qf[ks], st, 0, 0, 0);
-                dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Vl, kb * 32 + c, ks, h), dof[ks], dpt, 0, 0, 0);
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float p = __builtin_amdgcn_exp2f(st[r] * c2 - lq);
-                if (LAST && t * 64 + kb * 32 + acc_row(r, h) >= N) p = 0.f;
-                dpt[r] = p * (dpt[r] - dq_);
-            }
-#pragma unroll
-            for (int sp = 0; sp < 2; ++sp) {
-                const bf16x8 dsf = pack8(dpt, sp);
-#pragma unroll
-                for (int db = 0; db < 2; ++db)
-                    dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Kl, kb * 32 + 16 * sp, db, lane), dsf, dq[db], 0, 0, 0);
-            }
-        }
-    };
-    typedef std::integral_constant<int, 0> S0;
-    typedef std::integral_constant<int, 1> S1;
-    gload(0);
-    swrite(0);
-    __syncthreads();
-    int t = 0;
-    for (; t + 2 < nt; t += 2) {       // ring unrolled by two: even tiles live in stage 0, odd tiles in stage 1
-        gload(t + 1);
-        tile(t, S0{}, std::false_type{});
-        swrite(1);
-        __syncthreads();
-        gload(t + 2);
-        tile(t + 1, S1{}, std::false_type{});
-        swrite(0);
-        __syncthreads();
-    }
-    if (t + 1 < nt) {                   // two tiles left: t (stage 0), then the last one (stage 1)
-        gload(t + 1);
-        tile(t, S0{}, std::false_type{});
-        swrite(1);
-        __syncthreads();
-        tile(t + 1, S1{}, std::true_type{});
-    } else {
-        tile(t, S0{}, std::true_type{});
-    }
-    const int query = q0 + c;
-    if (query < N) store_dT(dqkv + ((long)b * N + query) * D3 + head * 64, dq, scale, h);
-}
-
 // ------------------------------------------------------------------------------------------------------
 // backward v2.  attn_stats_kernel leaves, per (b, head, query): ws[0] = -delta = -sum_d dO*O and ws[1] = -lse*log2(e), the
 // two row constants both sweeps preload into their MFMA accumulators (S' = q'.k - lse*log2e, dP' = dO.v - delta), so
@@ -955,7 +719,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void attn_bwd_dq2_kernel(
         auto valu = [&](int kb) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float ds = __builtin_amdgcn_exp2f(st[kb][r]) * dpt[kb][r];
+                float ds = HS_BWD_EXP2(st[kb][r]) * dpt[kb][r];
                 if (LAST && t * 64 + kb * 32 + acc_row(r, h) >= N) ds = 0.f;
                 dpt[kb][r] = ds;
             }
@@ -1029,7 +793,11 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void attn_bwd_dq2_kernel(
 
 template <int CNT>
 __device__ __forceinline__ void lds_wait8(u32x4& a, u32x4& b, u32x4& c, u32x4& d, u32x4& e, u32x4& f, u32x4& g, u32x4& i) {
+#if HS_ABL & 8
+    asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(i) : "i"(CNT) : "memory");
+#else
     asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(i) : "i"(CNT) : "memory");
+#endif
 }
 __device__ __forceinline__ f32x16 cat16(u32x4 a, u32x4 b, u32x4 c, u32x4 d) {
     f32x16 r;
@@ -1163,7 +931,7 @@ __device__ __forceinline__ void attn_bwd_dkdv2_body(const bf16_t* __restrict__ q
         auto valu = [&](int qb) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float p = __builtin_amdgcn_exp2f(s[qb][r]);
+                const float p = HS_BWD_EXP2(s[qb][r]);
                 s[qb][r] = p;
                 dp[qb][r] = p * dp[qb][r];
             }
@@ -1248,261 +1016,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv2_w4_kernel(const bf16_t*
                                                                   int N, int H, float kmul, float dk_mul) {
     attn_bwd_dkdv2_body<4>(qkv, d_o, ws, dqkv, B, N, H, kmul, dk_mul);
 }
-__global__ __launch_bounds__(512, 2) void attn_bwd_dkdv2_w8_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
-                                                                  const float* __restrict__ ws, bf16_t* __restrict__ dqkv, int B,
-                                                                  int N, int H, float kmul, float dk_mul) {
-    attn_bwd_dkdv2_body<8>(qkv, d_o, ws, dqkv, B, N, H, kmul, dk_mul);
-}
-
-// ------------------------------------------------------------------------------------------------------
-// dK, dV v3 (diagnostic variant, g_hs_dbg[2] == 3): 4 waves x 64 keys, ONE wave per SIMD with the whole register file.
-// Every Q / dO fragment (row reads for S, dP; transposed reads for dV, dK) feeds TWO MFMAs (key blocks 0 and 1), halving
-// the LDS traffic of the 32-keys-per-wave kernel; dK^T, dV^T (128 registers) live in AGPRs and are only touched by asm
-// MFMAs ("+a"); latency is hidden by a software pipeline instead of a second wave:
-//     per 32-query block j:   S/dP(j) MFMAs (16)  ||  exp2 / multiply / pack of block j-1 (VALU)
-//                             dV/dK(j-1) MFMAs (16, asm, accumulate in AGPRs)
-// LDS: 4-stage ring, prefetch distance 2; block j-1's transposed fragments are read from the previous tile's stage after
-// the tile barrier, hence 4 stages.  Stage 3 is zero-filled at start so that the pipeline's phantom block -1
-// (P = exp2(-inf) = 0, dS = 0) multiplies zeros, not LDS garbage.
-// ------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void mfma8_acc(f32x16& dv00, f32x16& dv01, f32x16& dk00, f32x16& dk01, f32x16& dv10, f32x16& dv11,
-                                          f32x16& dk10, f32x16& dk11, u32x4 fo0, u32x4 fo1, u32x4 fq0, u32x4 fq1, bf16x8 p0,
-                                          bf16x8 ds0, bf16x8 p1, bf16x8 ds1) {
-    // s_nop 1: the packed operands may have just been written by the VALU (hipcc pads no hazards inside asm)
-    asm volatile("s_nop 1\n\t"
-                 "v_mfma_f32_32x32x16_bf16 %0, %8, %12, %0\n\t"
-                 "v_mfma_f32_32x32x16_bf16 %1, %9, %12, %1\n\t"
-                 "v_mfma_f32_32x32x16_bf16 %2, %10, %13, %2\n\t"
-                 "v_mfma_f32_32x32x16_bf16 %3, %11, %13, %3\n\t"
-                 "v_mfma_f32_32x32x16_bf16 %4, %8, %14, %4\n\t"
-                 "v_mfma_f32_32x32x16_bf16 %5, %9, %14, %5\n\t"
-                 "v_mfma_f32_32x32x16_bf16 %6, %10, %15, %6\n\t"
-                 "v_mfma_f32_32x32x16_bf16 %7, %11, %15, %7"
-                 : "+a"(dv00), "+a"(dv01), "+a"(dk00), "+a"(dk01), "+a"(dv10), "+a"(dv11), "+a"(dk10), "+a"(dk11)
-                 : "v"(fo0), "v"(fo1), "v"(fq0), "v"(fq1), "v"(p0), "v"(ds0), "v"(p1), "v"(ds1));
-}
-__device__ __forceinline__ void acc_settle(f32x16& a, f32x16& b, f32x16& c, f32x16& d, f32x16& e, f32x16& f, f32x16& g, f32x16& i) {
-    // the last asm MFMAs' results must have left the matrix pipe before compiler code reads the accumulators
-    asm volatile("s_nop 15\n\ts_nop 15" : "+a"(a), "+a"(b), "+a"(c), "+a"(d), "+a"(e), "+a"(f), "+a"(g), "+a"(i));
-}
-
-// diagnostic cycle sums of dkdv3 (wave 0 of every block): 0 tail of previous block (last 8 MFMAs + seam bookkeeping) | 1 wait row constants |
-// 2 wait row fragments | 3 first 8 S/dP MFMAs + tr issue | 4 last 8 S/dP MFMAs + exp/mul | 5 wait transposed fragments | 6 first dV/dK
-// group | 7 seam (tile barrier + DMA + first reads)
-__device__ unsigned long long g_attn_stamps[8];
-extern "C" void hs_debug_attn_stamps(unsigned long long* out, int reset) {
-    if (out) (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_attn_stamps), sizeof(g_attn_stamps));
-    if (reset) { unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_attn_stamps), z, sizeof(z)); }
-}
-__global__ __launch_bounds__(256, 1) void attn_bwd_dkdv3_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
-                                                               const float* __restrict__ ws, bf16_t* __restrict__ dqkv, int B,
-                                                               int N, int H, float kmul, float dk_mul, int stamp) {
-    constexpr int STG = 16896, NST = 4;
-    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = stamp ? __builtin_amdgcn_s_memtime() : 0ull;
-#define TST(i) do { if (stamp) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tacc[i] += t_ - tprev; tprev = t_; } } while (0)
-    __shared__ __attribute__((aligned(16))) char smem[NST * STG];
-    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int blk, head, b;
-    attn_block_coords((N + 255) >> 8, H, blk, head, b);
-    const int k0 = blk * 256 + wave * 64;
-    const int Dm = H * 64, D3 = 3 * Dm;
-    const __amdgpu_buffer_rsrc_t rs = make_rsrc(qkv + (long)b * N * D3, (size_t)N * D3 * 2);
-    const __amdgpu_buffer_rsrc_t rsd = make_rsrc(d_o + (long)b * N * Dm, (size_t)N * Dm * 2);
-    const __amdgpu_buffer_rsrc_t rst_ = make_rsrc(ws + ((wave & 1) == 0 ? (long)B * H * N : 0) + ((long)b * H + head) * N, (size_t)N * 4);
-    const int nt = (N + 63) >> 6;
-    unsigned vq[2], vd[2], vql[2], vdl[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int row = (wave * 2 + j) * 8 + (lane >> 3);
-        const int ch = (lane & 7) ^ swzR(row);
-        vq[j] = (unsigned)(((long)row * D3 + head * 64 + ch * 8) * 2);
-        vd[j] = (unsigned)(((long)row * Dm + head * 64 + ch * 8) * 2);
-        const bool in = (nt - 1) * 64 + row < N;
-        vql[j] = in ? vq[j] : HS_OOB_OFF;
-        vdl[j] = in ? vd[j] : HS_OOB_OFF;
-    }
-    const unsigned vs = (unsigned)lane * 4u, vsl = (nt - 1) * 64 + lane < N ? vs : HS_OOB_OFF;
-    const unsigned qtile = (unsigned)(64 * D3 * 2), dtile = (unsigned)(64 * Dm * 2);
-    // branch-free: a tile past the end (t >= nt) is "loaded" with out-of-range offsets (zero fill into a dead stage), and
-    // every wave issues 5 pieces per tile (waves 2, 3 repeat the row-constant pieces of waves 0, 1: same bytes, same place),
-    // so that one vmcnt count serves every wave and the loop body has no control flow around its MFMAs
-    auto issue = [&](int t) {
-        const bool last = t == nt - 1, dead = t >= nt;
-        const unsigned so_q = dead ? 0u : (unsigned)t * qtile, so_d = dead ? 0u : (unsigned)t * dtile, so_s = dead ? 0u : (unsigned)t * 256u;
-        char* sb = smem + (t & 3) * STG;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            char* dst = sb + (wave * 2 + j) * 1024;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (LDS_PTR(void))dst, 16, dead ? HS_OOB_OFF : (last ? vql[j] : vq[j]), so_q, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsd, (LDS_PTR(void))(dst + 8192), 16, dead ? HS_OOB_OFF : (last ? vdl[j] : vd[j]), so_d, 0, 0);
-        }
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rst_, (LDS_PTR(void))(sb + 16384 + (wave & 1) * 256), 4, dead ? HS_OOB_OFF : (last ? vsl : vs), so_s, 0, 0);
-    };
-    {   // zero stage 3 (the phantom tile -1): 16 KiB of images by 256 threads
-        const u32x4 z = {0u, 0u, 0u, 0u};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) *(u32x4*)(smem + 3 * STG + (i * 256 + tid) * 16) = z;
-    }
-    issue(0);
-    issue(1);
-
-    bf16x8 kf[2][4], vf[2][4];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-        const int key = k0 + kb * 32 + c;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const unsigned off = key < N ? (unsigned)(((long)key * D3 + Dm + head * 64 + ks * 16 + 8 * h) * 2) : HS_OOB_OFF;
-            kf[kb][ks] = scale_frag(buf_load16(rs, off), kmul);
-            vf[kb][ks] = __builtin_bit_cast(bf16x8, buf_load16(rs, key < N ? off + Dm * 2 : HS_OOB_OFF));
-        }
-    }
-    unsigned rb0[4], tb0[2][2];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) rb0[ks] = lds_addr(smem) + offR(c, 2 * ks + h);
-    {
-        const int g = lane >> 4, p = lane & 3, q = (lane >> 2) & 3;
-#pragma unroll
-        for (int db = 0; db < 2; ++db) {
-            const int col = db * 32 + 16 * (g & 1) + 4 * p;
-            tb0[db][0] = lds_addr(smem) + offR(4 * h + q, col >> 3) + 8 * (p & 1);
-            tb0[db][1] = lds_addr(smem) + offR(4 * h + q + 8, col >> 3) + 8 * (p & 1);
-        }
-    }
-    const unsigned sb0 = lds_addr(smem) + 16384 + 16 * h;
-
-    f32x16 dv00 = zero16(), dv01 = zero16(), dk00 = zero16(), dk01 = zero16(), dv10 = zero16(), dv11 = zero16(), dk10 = zero16(), dk11 = zero16();
-    f32x16 sp[2] = {splat16(NEG_INF), splat16(NEG_INF)}, dpp[2] = {zero16(), zero16()};
-    typedef std::integral_constant<int, 0> I0;
-    typedef std::integral_constant<int, 1> I1;
-    u32x4 c1[8], ra[4];                     // the NEXT block's row constants and first row fragments, in flight across block seams
-    // first reads of 32-query block QB of the tile at stage offset so: row constants (8) + row fragments of k-steps 0, 1 (4)
-    auto first_reads = [&](auto qb_tag, unsigned so) {
-        constexpr int QB = decltype(qb_tag)::value;
-        const unsigned sbase = sb0 + so;
-        ldsr128<QB * 128>(c1[0], sbase); ldsr128<QB * 128 + 32>(c1[1], sbase); ldsr128<QB * 128 + 64>(c1[2], sbase); ldsr128<QB * 128 + 96>(c1[3], sbase);
-        ldsr128<QB * 128 + 256>(c1[4], sbase); ldsr128<QB * 128 + 288>(c1[5], sbase); ldsr128<QB * 128 + 320>(c1[6], sbase); ldsr128<QB * 128 + 352>(c1[7], sbase);
-        ldsr128<QB * 4096>(ra[0], rb0[0] + so); ldsr128<QB * 4096 + 8192>(ra[1], rb0[0] + so);
-        ldsr128<QB * 4096>(ra[2], rb0[1] + so); ldsr128<QB * 4096 + 8192>(ra[3], rb0[1] + so);
-    };
-    // one 32-query block (its first reads are already in flight); `seam` runs between the two dV/dK MFMA groups of the
-    // previous block and issues the next block's first reads (after the tile barrier when the next block opens a tile)
-    auto qblock = [&](auto qb_tag, unsigned so, auto pq_tag, unsigned po, auto&& seam) {
-        constexpr int QB = decltype(qb_tag)::value, PQ = decltype(pq_tag)::value;
-        u32x4 rb_[4], ta[4], tc[4];
-        f32x16 s[2], dp[2];
-        TST(0);
-        lds_wait8<4>(c1[0], c1[1], c1[2], c1[3], c1[4], c1[5], c1[6], c1[7]);
-        TST(1);
-        const f32x16 cl = cat16(c1[0], c1[1], c1[2], c1[3]), cd = cat16(c1[4], c1[5], c1[6], c1[7]);
-        ldsr128<QB * 4096>(rb_[0], rb0[2] + so); ldsr128<QB * 4096 + 8192>(rb_[1], rb0[2] + so);
-        ldsr128<QB * 4096>(rb_[2], rb0[3] + so); ldsr128<QB * 4096 + 8192>(rb_[3], rb0[3] + so);                       // [8]
-        lds_wait4<4>(ra[0], ra[1], ra[2], ra[3]);
-        TST(2);
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ra[0]), kf[kb][0], cl, 0, 0, 0);
-            dp[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ra[1]), vf[kb][0], cd, 0, 0, 0);
-        }
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ra[2]), kf[kb][1], s[kb], 0, 0, 0);
-            dp[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ra[3]), vf[kb][1], dp[kb], 0, 0, 0);
-        }
-        {
-            const unsigned t00 = tb0[0][0] + po, t01 = tb0[0][1] + po, t10 = tb0[1][0] + po, t11 = tb0[1][1] + po;
-            trR_issue<PQ * 4096 + 8192>(ta[0], t00, t01); trR_issue<PQ * 4096 + 8192>(ta[1], t10, t11);
-            trR_issue<PQ * 4096>(ta[2], t00, t01); trR_issue<PQ * 4096>(ta[3], t10, t11);                             // [12]
-        }
-        TST(3);
-        lds_wait4<8>(rb_[0], rb_[1], rb_[2], rb_[3]);
-        TST(2);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, rb_[2 * i]), kf[kb][2 + i], s[kb], 0, 0, 0);
-                dp[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, rb_[2 * i + 1]), vf[kb][2 + i], dp[kb], 0, 0, 0);
-            }
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = __builtin_amdgcn_exp2f(sp[kb][r]);
-                sp[kb][r] = p;
-                dpp[kb][r] = p * dpp[kb][r];
-            }
-        TST(4);
-        lds_wait4<0>(ta[0], ta[1], ta[2], ta[3]);
-        TST(5);
-        {
-            const unsigned t00 = tb0[0][0] + po, t01 = tb0[0][1] + po, t10 = tb0[1][0] + po, t11 = tb0[1][1] + po;
-            trR_issue<PQ * 4096 + 2048 + 8192>(tc[0], t00, t01); trR_issue<PQ * 4096 + 2048 + 8192>(tc[1], t10, t11);
-            trR_issue<PQ * 4096 + 2048>(tc[2], t00, t01); trR_issue<PQ * 4096 + 2048>(tc[3], t10, t11);               // [8]
-        }
-        mfma8_acc(dv00, dv01, dk00, dk01, dv10, dv11, dk10, dk11, ta[0], ta[1], ta[2], ta[3], pack8(sp[0], 0), pack8(dpp[0], 0),
-                  pack8(sp[1], 0), pack8(dpp[1], 0));
-        TST(6);
-        lds_wait4<0>(tc[0], tc[1], tc[2], tc[3]);
-        TST(5);
-        seam();
-        TST(7);                                                       // next block's first reads fly under the 8 MFMAs below
-        mfma8_acc(dv00, dv01, dk00, dk01, dv10, dv11, dk10, dk11, tc[0], tc[1], tc[2], tc[3], pack8(sp[0], 1), pack8(dpp[0], 1),
-                  pack8(sp[1], 1), pack8(dpp[1], 1));
-        sp[0] = s[0]; sp[1] = s[1]; dpp[0] = dp[0]; dpp[1] = dp[1];
-    };
-    auto tile_sync = [&](int t) {            // tile t has landed for every wave; then tile t+2's DMA goes into the stage tile t-2 left
-        asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        issue(t + 2);
-    };
-    tile_sync(0);
-    first_reads(I0{}, 0u);
-    for (int t = 0; t < nt; ++t) {
-        const unsigned so = (unsigned)(t & 3) * STG, po = (unsigned)((t + 3) & 3) * STG, no = (unsigned)((t + 1) & 3) * STG;
-        qblock(I0{}, so, I1{}, po, [&] { first_reads(I1{}, so); });          // queries 0..31   || finishes 32..63 of tile t-1
-        // (after the last tile the seam syncs on and reads a dead, zero-filled stage: harmless, and keeps the body branch-free)
-        qblock(I1{}, so, I0{}, so, [&] { tile_sync(t + 1); first_reads(I0{}, no); });   // queries 32..63 || finishes 0..31 of tile t
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    lds_wait8<0>(c1[0], c1[1], c1[2], c1[3], c1[4], c1[5], c1[6], c1[7]);
-    {   // drain: the last block's softmax-side math and its dV / dK products
-        u32x4 ta[4], tc[4];
-        const unsigned po = (unsigned)((nt - 1) & 3) * STG;
-        const unsigned t00 = tb0[0][0] + po, t01 = tb0[0][1] + po, t10 = tb0[1][0] + po, t11 = tb0[1][1] + po;
-        trR_issue<4096 + 8192>(ta[0], t00, t01); trR_issue<4096 + 8192>(ta[1], t10, t11);
-        trR_issue<4096>(ta[2], t00, t01); trR_issue<4096>(ta[3], t10, t11);
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = __builtin_amdgcn_exp2f(sp[kb][r]);
-                sp[kb][r] = p;
-                dpp[kb][r] = p * dpp[kb][r];
-            }
-        lds_wait4<0>(ta[0], ta[1], ta[2], ta[3]);
-        trR_issue<4096 + 2048 + 8192>(tc[0], t00, t01); trR_issue<4096 + 2048 + 8192>(tc[1], t10, t11);
-        trR_issue<4096 + 2048>(tc[2], t00, t01); trR_issue<4096 + 2048>(tc[3], t10, t11);
-        mfma8_acc(dv00, dv01, dk00, dk01, dv10, dv11, dk10, dk11, ta[0], ta[1], ta[2], ta[3], pack8(sp[0], 0), pack8(dpp[0], 0),
-                  pack8(sp[1], 0), pack8(dpp[1], 0));
-        lds_wait4<0>(tc[0], tc[1], tc[2], tc[3]);
-        mfma8_acc(dv00, dv01, dk00, dk01, dv10, dv11, dk10, dk11, tc[0], tc[1], tc[2], tc[3], pack8(sp[0], 1), pack8(dpp[0], 1),
-                  pack8(sp[1], 1), pack8(dpp[1], 1));
-    }
-    if (stamp && tid == 0) { for (int i = 0; i < 8; ++i) atomicAdd(&g_attn_stamps[i], tacc[i]); }
-    acc_settle(dv00, dv01, dk00, dk01, dv10, dv11, dk10, dk11);
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-        const int key = k0 + kb * 32 + c;
-        if (key < N) {
-            bf16_t* row = dqkv + ((long)b * N + key) * D3 + head * 64;
-            f32x16 dk_[2] = {kb ? dk10 : dk00, kb ? dk11 : dk01}, dv_[2] = {kb ? dv10 : dv00, kb ? dv11 : dv01};
-            store_dT(row + Dm, dk_, dk_mul, h);
-            store_dT(row + 2 * Dm, dv_, 1.0f, h);
-        }
-    }
-}
 
 extern "C" int hs_attn_fwd(const void* qkv, void* o, float* lse, int B, int N, int H, int dh, int prec, int flags, void* stream) {
     if (!qkv || !o) return HS_ERR_ARG;
@@ -1552,47 +1065,27 @@ extern "C" int hs_attn_bwd(const void* qkv, const void* o, const void* d_o, cons
     const float dk_mul = pre ? 1.0f / LOG2E : scale;        // dK = dh^-0.5 dS^T q = dS^T q' / log2(e)
     hipStream_t s = (hipStream_t)stream;
     const long total = (long)B * N * H * 8;
-    const double nn = (double)B * H * N * N * 64;   // algorithmic bwd = 5 products = 10*nn, split 6:4 over the two kernels
+    // FLOP credit follows SURVEY.md 8(d): the backward's ALGORITHMIC work is 2.0 x the forward's 4*nn (dV, dP, dQ, dK: four
+    // products); the recomputation of S (both kernels) and of dP (dQ kernel) is executed but NOT counted.  dK/dV kernel: dV, dP, dK
+    // = 6*nn (executes 8*nn); dQ kernel: dQ = 2*nn (executes 6*nn).
+    const double nn = (double)B * H * N * N * 64;
     const double io = (double)B * N * H * 64 * 2;
-    // g_hs_dbg[1] / [2] (diagnostic): 9 = the v1 dQ / dK,dV kernel; 1 = the 8-wave form of the v2 kernel
-    const int vq_ = g_hs_dbg[1], vk_ = g_hs_dbg[2];
     float* nstat = delta_ws;                                  // [0] = -delta, [1] = -lse*log2e   (2 x [B][H][N])
-    float* delta_v1 = delta_ws + 2 * (size_t)B * H * N;       // +delta for the v1 kernels (diagnostic runs only: 3 x [B][H][N])
     {
         ProfScope prof(HS_PROF_ATTN_DELTA, stream, 0, 2 * io);
         hipLaunchKernelGGL(attn_stats_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const bf16_t*)o,
                            (const bf16_t*)d_o, lse, nstat, B, N, H);
-        if (vq_ == 9 || vk_ == 9)
-            hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const bf16_t*)o,
-                               (const bf16_t*)d_o, delta_v1, B, N, H);
     }
-    dim3 grid((unsigned)(((N + 127) / 128) * H * B)), grid2((unsigned)(((N + 255) / 256) * H * B));
+    dim3 grid((unsigned)(((N + 127) / 128) * H * B));
     {
         ProfScope prof(HS_PROF_ATTN_DKDV, stream, 6.0 * nn, 6 * io);
-        if (vk_ == 9)
-            hipLaunchKernelGGL(attn_bwd_dkdv_kernel, grid, dim3(256), 0, s, (const bf16_t*)qkv, (const bf16_t*)d_o, lse, delta_v1,
-                               (bf16_t*)dqkv, N, H, c2, dk_mul);
-        else if (vk_ == 3)
-            hipLaunchKernelGGL(attn_bwd_dkdv3_kernel, grid2, dim3(256), 0, s, (const bf16_t*)qkv, (const bf16_t*)d_o, nstat,
-                               (bf16_t*)dqkv, B, N, H, c2, dk_mul, g_hs_dbg[4]);
-        else if (vk_ == 1)
-            hipLaunchKernelGGL(attn_bwd_dkdv2_w8_kernel, grid2, dim3(512), 0, s, (const bf16_t*)qkv, (const bf16_t*)d_o, nstat,
-                               (bf16_t*)dqkv, B, N, H, c2, dk_mul);
-        else
-            hipLaunchKernelGGL(attn_bwd_dkdv2_w4_kernel, grid, dim3(256), 0, s, (const bf16_t*)qkv, (const bf16_t*)d_o, nstat,
-                               (bf16_t*)dqkv, B, N, H, c2, dk_mul);
+        hipLaunchKernelGGL(attn_bwd_dkdv2_w4_kernel, grid, dim3(256), 0, s, (const bf16_t*)qkv, (const bf16_t*)d_o, nstat,
+                           (bf16_t*)dqkv, B, N, H, c2, dk_mul);
     }
     {
-        ProfScope prof(HS_PROF_ATTN_DQ, stream, 4.0 * nn, 5 * io);
-        if (vq_ == 9)
-            hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, s, (const bf16_t*)qkv, (const bf16_t*)d_o, lse, delta_v1,
-                               (bf16_t*)dqkv, N, H, c2, scale);
-        else if (vq_ == 1)
-            hipLaunchKernelGGL(attn_bwd_dq2_kernel<8>, grid2, dim3(512), 0, s, (const bf16_t*)qkv, (const bf16_t*)d_o, nstat,
-                               (bf16_t*)dqkv, B, N, H, c2, scale);
-        else
-            hipLaunchKernelGGL(attn_bwd_dq2_kernel<4>, grid, dim3(256), 0, s, (const bf16_t*)qkv, (const bf16_t*)d_o, nstat,
-                               (bf16_t*)dqkv, B, N, H, c2, scale);
+        ProfScope prof(HS_PROF_ATTN_DQ, stream, 2.0 * nn, 5 * io);
+        hipLaunchKernelGGL(attn_bwd_dq2_kernel<4>, grid, dim3(256), 0, s, (const bf16_t*)qkv, (const bf16_t*)d_o, nstat,
+                           (bf16_t*)dqkv, B, N, H, c2, scale);
     }
     HS_CHECK_LAUNCH();
     return HS_OK;

@@ -92,13 +92,26 @@ __device__ __forceinline__ bf16x8 cat4(bf16x4 a, bf16x4 b) {
 // Row-fragment reads issued from asm: left to hipcc, each pair of ds_read_b128 is issued just in time and
 // waited for with lgkmcnt(0) right in front of its MFMAs (one LDS round trip per two MFMAs).  Issued in groups ahead of
 // use and retired with COUNTED waits instead; the waits name the registers they release ("+v") so no consumer moves up.
+// HS_ABL (ablation builds of tools/build_variant.sh only, timing studies with WRONG results; never defined in the product):
+// bit 0 drops the exp2 of the attention backward kernels, bit 1 every asm-issued LDS read, bit 2 the dQ / dK,dV accumulation MFMAs
+#ifndef HS_ABL
+#define HS_ABL 0
+#endif
 template <int IMM>
 __device__ __forceinline__ void ldsr128(u32x4& f, unsigned base) {
+#if HS_ABL & 2
+    asm volatile("" : "=v"(f) : "v"(base));
+#else
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f) : "v"(base), "i"(IMM) : "memory");
+#endif
 }
 template <int CNT>
 __device__ __forceinline__ void lds_wait4(u32x4& a, u32x4& b, u32x4& c, u32x4& d) {
+#if HS_ABL & 8      // (timing study: reads issued but never waited for)
+    asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "i"(CNT) : "memory");
+#else
     asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "i"(CNT) : "memory");
+#endif
 }
 template <int CNT>
 __device__ __forceinline__ void lds_wait6(u32x4& a, u32x4& b, u32x4& c, u32x4& d, u32x4& e, u32x4& f) {

@@ -1432,6 +1432,20 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmP p) {
     for (int r = 0; r < 16; ++r) epilogue_store<true>(p, cz, m0 + wm * 32 + acc_row(r, h), n0 + wn * 32 + c, acc[r]);
 }
 
+// A/B switches of tools/kbench and tools/bench_gemm.py, read ONCE (none is set in production; hs_gemm runs ~900 times per step)
+namespace {
+struct GemmEnv {
+    bool no_nt, no_m16, persist, w4;
+    char tile;      // 0, 'b' (big) or 's' (small)
+    GemmEnv() : no_nt(getenv("HS_GEMM_NO_NT") != nullptr), no_m16(getenv("HS_GEMM_NO_M16") != nullptr),
+                persist(getenv("HS_GEMM_PERSIST") != nullptr), w4(getenv("HS_GEMM_W4") != nullptr), tile(0) {
+        const char* t = getenv("HS_GEMM_TILE");
+        if (t && (t[0] == 'b' || t[0] == 's')) tile = t[0];
+    }
+};
+const GemmEnv kEnv;
+}  // namespace
+
 extern "C" int hs_gemm(const hs_gemm_args* a, int prec, void* stream) {
     if (!a || !a->A || !a->B || (!a->out_f32 && !a->out_bf16)) return HS_ERR_ARG;
     if (a->M <= 0 || a->N <= 0 || a->K <= 0 || a->batch < 1 || a->split_k < 1) return HS_ERR_SHAPE;
@@ -1465,8 +1479,7 @@ extern "C" int hs_gemm(const hs_gemm_args* a, int prec, void* stream) {
     // wait 7.4k -> 3.8k cycles per tile, qkv/fc1 -6 % end to end; streaming LOADS of the A panel made them 3-8 % slower).
     {
         const double out_bytes = (double)a->M * a->N * a->batch * ((a->out_f32 ? 4 : 0) + (a->out_bf16 ? 2 : 0) + (a->aux_out ? 2 : 0));
-        static const bool no_nt = getenv("HS_GEMM_NO_NT") != nullptr;    // tools/kbench A/B runs
-        p.nt = out_bytes >= 64.0 * 1048576.0 && !(a->flags & HS_EPI_ATOMIC) && !no_nt;
+        p.nt = out_bytes >= 64.0 * 1048576.0 && !(a->flags & HS_EPI_ATOMIC) && !kEnv.no_nt;
     }
     hipStream_t s = (hipStream_t)stream;
     const int zdim = a->split_k > 1 ? a->split_k : a->batch;
@@ -1479,9 +1492,9 @@ extern "C" int hs_gemm(const hs_gemm_args* a, int prec, void* stream) {
         // (more than ncu/2 big tiles), and loses by 30-37 % below that (one round of half-size tiles)
         p.tiles_m = (a->M + 255) / 256;
         const long big_blocks = (long)p.tiles_m * ((a->N + 255) / 256) * zdim;
-        const char* force = getenv("HS_GEMM_TILE");   // "big" / "small": tools/bench_gemm.py A/B runs
         static const int ncu = [] { int dev = 0, n = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
-        const bool big = !(a->K & 63) && (force ? (force[0] == 'b') : (a->layout != HS_GEMM_TN && 2 * big_blocks > ncu));
+        // (kEnv.tile: 'b' / 's' force the NT / NN tile for A/B runs; the TN kernel only exists with the 256x128 tile)
+        const bool big = !(a->K & 63) && a->layout != HS_GEMM_TN && (kEnv.tile ? kEnv.tile == 'b' : 2 * big_blocks > ncu);
         p.tiles_n = (a->N + (big ? 255 : 127)) / (big ? 256 : 128);
         dim3 grid(p.tiles_m * p.tiles_n * zdim, 1, 1);
         // epilogue specialisations (compile-time flags); anything else runs the generic kernel (EF = -1)
@@ -1492,13 +1505,13 @@ extern "C" int hs_gemm(const hs_gemm_args* a, int prec, void* stream) {
         if (big) hipLaunchKernelGGL((gemm_bf16_kernel<ATR, BTR, true, EF>), grid, dim3(512), 0, s, p);                \
         else hipLaunchKernelGGL((gemm_bf16_kernel<ATR, BTR, false, EF>), grid, dim3(512), 0, s, p);                   \
     } while (0)
-        const bool m16 = big && a->layout == HS_GEMM_NT && !a->colsum_out && getenv("HS_GEMM_NO_M16") == nullptr;   // (env: kbench A/B)
+        const bool m16 = big && a->layout == HS_GEMM_NT && !a->colsum_out && !kEnv.no_m16;
 #define HS_LAUNCH_M16(EF) hipLaunchKernelGGL((gemm_bf16_kernel<false, false, true, EF, true>), grid, dim3(512), 0, s, p)
         p.nblocks = (int)grid.x;
         // the persistent variant is a measured dead end kept for A/B runs (tools/kbench, HS_GEMM_PERSIST=1): it hides the block
         // launch gap but the store issue of the epilogue stalls just as long
-        static const bool no_persist = getenv("HS_GEMM_PERSIST") == nullptr;
-        const bool w4 = getenv("HS_GEMM_W4") != nullptr && p.dbg != 4 && p.dbg != 7;
+        const bool no_persist = !kEnv.persist;
+        const bool w4 = kEnv.w4 && p.dbg != 4 && p.dbg != 7;
         const bool m16_ok = m16 && col8 && (f == 0 || f == (HS_EPI_BIAS | HS_EPI_RESID) || f == (HS_EPI_BIAS | HS_EPI_GELU | HS_EPI_SAVE_DGELU));
         if (m16_ok && zdim == 1 && a->K >= 192 && (int)grid.x > ncu && !no_persist && p.dbg != 1 && p.dbg != 2 && p.dbg != 4 && p.dbg != 7) {
             // persistent: one block per CU, a multiple of 8 so that block b stays on XCD b % 8

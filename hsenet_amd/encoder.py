@@ -8,9 +8,12 @@ SAME ORDER (138 tensors for ViT_stage1, 150 for ViT_stage2).  The modules only *
 arithmetic runs in libhsenet_hip.so through hsenet_amd.functional.  There is no CPU path: calling a module
 with CPU tensors raises.
 
-Dropout: MONAI blocks are built with dropout_rate=0.0 on this path (no-ops).  ``regular_attention`` hard-codes
-p=0.1 dropouts that fire in train() mode in the reference (vit.py:46-47); this implementation computes the
-eval-mode (deterministic) function in both modes — see DESIGN.md "Dropout".
+Dropout: MONAI blocks are built with dropout_rate=0.0 on this path (no-ops).  ``regular_attention`` hard-codes two
+p=0.1 dropouts (on the attention probabilities and on the pre-residual output, vit.py:46-47,58,62) that fire whenever the
+module is in train() — also for a "frozen" tower during MLLM finetuning (requires_grad_(False) does not call eval(),
+lamed_arch.py:66).  Same here: in train() both sites drop with a counter-based Philox mask seeded from torch's default CPU
+generator (``torch.manual_seed`` replays a step; the backward regenerates the mask); eval() is the deterministic function
+the parity fixtures pin.  A frozen tower that must be deterministic needs ``.eval()`` — see DESIGN.md "Dropout".
 """
 from __future__ import annotations
 

@@ -135,7 +135,7 @@ def attn_bwd(qkv, o, d_o, lse, H: int, q_prescaled: bool = False):
     _need(qkv, o, d_o, lse)
     B, N, _ = qkv.shape
     dqkv = torch.empty_like(qkv)
-    delta = torch.empty(3, B, H, N, dtype=torch.float32, device=qkv.device)   # 2 x [B,H,N] (+1 for the diagnostic v1 kernels)
+    delta = torch.empty(2, B, H, N, dtype=torch.float32, device=qkv.device)   # row constants -delta | -lse*log2e
     L.call("hs_attn_bwd", qkv.data_ptr(), o.data_ptr(), d_o.data_ptr(), lse.data_ptr(), dqkv.data_ptr(), delta.data_ptr(),
            B, N, H, 64, L.ATTN_Q_PRESCALED if q_prescaled else 0, _s())
     return dqkv

@@ -3,8 +3,9 @@
 
 Same class names / constructor and forward signatures / ``proj_out_num`` / state-dict keys
 (``proj_mpls.{0,2}.*``, ``resolution_attention.{Wq,Wk,Wv,output_linear,norm}.*``).  Arithmetic runs in
-libhsenet_hip.so; the modules only hold parameters.  Eval-mode function (the hard-coded p=0.1 dropouts of
-``resolution_attention_v3`` are not applied) — see DESIGN.md "Dropout".
+libhsenet_hip.so; the modules only hold parameters.  The two hard-coded p=0.1 dropouts of ``resolution_attention_v3``
+(spatial_pooling_projector.py:58-59: attention probabilities, pre-residual output) are active in train() — Philox masks
+seeded from torch's default CPU generator, regenerated in the backward — and off in eval(); see DESIGN.md "Dropout".
 """
 from __future__ import annotations
 

@@ -165,17 +165,6 @@ int main(int argc, char** argv) {
             CK(hipDeviceSynchronize());
             Cmp c = cmp_bf16(dqkv[0], dqkv[1], nq);
             printf("attn bwd B=%d N=%d: variant %d vs %d: dqkv rel %.3e maxabs %.3e\n", B, N, vA, vB, c.rel, c.maxabs);
-            if (getenv("HS_ATTN_STAMP")) {
-                typedef void (*st_t)(unsigned long long*, int);
-                auto st = sym<st_t>("hs_debug_attn_stamps");
-                unsigned long long v[8];
-                st(nullptr, 1); dbg(4, 1); dbg(1, var[1] % 10); dbg(2, var[1] / 10);
-                bwd(qkv, o[0], d_o, lse[0], dqkv[1], delta, B, N, H, 64, aflags, 0); CK(hipDeviceSynchronize());
-                dbg(4, 0); st(v, 0);
-                const double nsteps = (double)((N + 255) / 256) * H * B * ((N + 63) / 64) * 2;
-                printf("   dkdv3 cycles per 32-query step (wave 0): tail %.0f | wait consts %.0f | wait rows %.0f | S/dP a %.0f | S/dP b + VALU %.0f | wait tr %.0f | dV/dK a %.0f | seam %.0f\n",
-                       v[0] / nsteps, v[1] / nsteps, v[2] / nsteps, v[3] / nsteps, v[4] / nsteps, v[5] / nsteps, v[6] / nsteps, v[7] / nsteps);
-            }
             {   // per section (dq | dk | dv)
                 std::vector<uint16_t> ha(nq), hb(nq);
                 CK(hipMemcpy(ha.data(), dqkv[0], nq * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(hb.data(), dqkv[1], nq * 2, hipMemcpyDeviceToHost));
