@@ -112,6 +112,7 @@ SIGNATURES = {
     "hs_rows_scatter": [_vp, _vp, _i, _i, _i, _i, _i, _vp],
     "hs_scale_dev": [_vp, _vp, _vp, _f, _i64, _vp],
     "hs_dot": [_vp, _vp, _vp, _f, _i64, _vp],
+    "hs_rowmix": [_vp, _vp, _vp, _i, _i, _i, _i64, _i64, _i64, _i, _vp],
     "hs_relation_mse": [_vp, _vp, _vp, _vp, _i64, _f, _i, _vp],
     "hs_ce_rows": [_vp, _vp, _vp, _i, _i, _i, _f, _i, _vp],
     "hs_debug_set": [_i, _i],

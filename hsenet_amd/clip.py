@@ -58,12 +58,13 @@ class _LogitsFn(torch.autograd.Function):
         draw = torch.empty_like(dlog)
         L.call("hs_scale_dev", dlog.data_ptr(), draw.data_ptr(), scale.data_ptr(), 1.0, dlog.numel(), s)
         da = db = dscale = None
-        if ctx.needs_input_grad[0]:
+        n, m, d = a.shape[0], b.shape[0], a.shape[1]
+        if ctx.needs_input_grad[0]:                  # da = draw @ b      (n x m x d: tiny, any n / m)
             da = torch.empty_like(a)
-            Fn.gemm(draw, b, L.GEMM_NN, prec=L.PREC_F32, out_f32=da)
-        if ctx.needs_input_grad[1]:
+            L.call("hs_rowmix", draw.data_ptr(), b.data_ptr(), da.data_ptr(), n, m, d, m, d, d, 0, s)
+        if ctx.needs_input_grad[1]:                  # db = draw^T @ a
             db = torch.empty_like(b)
-            Fn.gemm(draw, a, L.GEMM_TN, prec=L.PREC_F32, out_f32=db)
+            L.call("hs_rowmix", draw.data_ptr(), a.data_ptr(), db.data_ptr(), m, n, d, m, d, d, 1, s)
         if ctx.needs_input_grad[2]:
             dscale = torch.zeros(1, dtype=torch.float32, device=dlog.device)
             L.call("hs_dot", dlog.data_ptr(), raw.data_ptr(), dscale.data_ptr(), 1.0, dlog.numel(), s)

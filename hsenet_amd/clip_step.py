@@ -153,10 +153,7 @@ class ClipStage2Engine(_Engine):
         ls = self.model.logit_scale
         L.call("hs_dot", self.dlog.data_ptr(), self.raw2.data_ptr(), ls.grad.data_ptr(), 1.0, n * n, s)            # d/d logit_scale
         L.call("hs_scale_dev", self.dlog.data_ptr(), self.draw.data_ptr(), ls.data_ptr(), 1.0, n * n, s)
-        g = L.GemmArgs()                                                                                          # d all_img = draw @ all_txt
-        g.A, g.B, g.M, g.N, g.K, g.lda, g.ldb, g.batch = self.draw.data_ptr(), self.all.data_ptr() + 4 * 3 * d, n, d, n, n, 4 * d, 1
-        g.out_f32, g.ldc, g.alpha, g.layout, g.split_k = self.dall.data_ptr(), d, 1.0, L.GEMM_NN, 1
-        L.call("hs_gemm", C.byref(g), L.PREC_F32, s)
+        L.call("hs_rowmix", self.draw.data_ptr(), self.all.data_ptr() + 4 * 3 * d, self.dall.data_ptr(), n, n, d, n, 4 * d, d, 0, s)   # d all_img = draw @ all_txt
         if self.world > 1:       # backward of the all-gather (torch.distributed.nn.all_gather): sum over ranks, keep this rank's rows
             dist.all_reduce(self.dall, op=dist.ReduceOp.SUM, group=self.group)
         L.call("hs_rows_copy", self.dall.data_ptr() + 4 * self.rank * B * d, d, self.h2.df.data_ptr(), None, d, B, 1, d, s)

@@ -594,6 +594,25 @@ extern "C" int hs_dot(const float* a, const float* b, float* out, float alpha, i
     HS_CHECK_LAUNCH();
     return HS_OK;
 }
+// out[i, :] = sum_j w(i, j) * X[j, :]  with w(i, j) = W[i*ldw + j] (trans = 0) or W[j*ldw + i] (trans = 1): the two backward products
+// of the logits GEMM (d img = dlogits @ txt, d txt = dlogits^T @ img) for ANY global batch n (the MFMA GEMM wants multiples of 4)
+__global__ __launch_bounds__(256) void rowmix_kernel(const float* __restrict__ W, const float* __restrict__ X, float* __restrict__ out,
+                                                     int n_in, int d, long ldw, long ldx, long ldo, int trans) {
+    const int col = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
+    if (col >= d) return;
+    float acc = 0.f;
+    for (int j = 0; j < n_in; ++j) acc += (trans ? W[(long)j * ldw + i] : W[(long)i * ldw + j]) * X[(long)j * ldx + col];
+    out[(long)i * ldo + col] = acc;
+}
+extern "C" int hs_rowmix(const float* W, const float* X, float* out, int n_out, int n_in, int d, int64_t ldw, int64_t ldx, int64_t ldo,
+                         int trans, void* stream) {
+    if (!W || !X || !out) return HS_ERR_ARG;
+    if (n_out < 1 || n_in < 1 || d < 1 || n_out > 65535) return HS_ERR_SHAPE;
+    hipLaunchKernelGGL(rowmix_kernel, dim3((d + 255) / 256, n_out), dim3(256), 0, (hipStream_t)stream, W, X, out, n_in, d, (long)ldw,
+                       (long)ldx, (long)ldo, trans);
+    HS_CHECK_LAUNCH();
+    return HS_OK;
+}
 // image_text_relation_regulation (CLIP_stage2.py:187-190) on one pair of logit matrices: loss[0] += mean((l - l_ref)^2);
 // dl (+)= weight * 2/n * (l - l_ref)
 __global__ __launch_bounds__(256) void relation_mse_kernel(const float* __restrict__ lref, const float* __restrict__ l, float* __restrict__ dl,

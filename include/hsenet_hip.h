@@ -318,8 +318,12 @@ int hs_rows_scatter(const float* src, float* dst, int B, int r0, int R, int Rt, 
  * hs_relation_mse: image_text_relation_regulation on ONE pair of logit matrices (CLIP_stage2.py:187-190): loss[0] += mean((l-l_ref)^2);
  *   dl = (accumulate ? dl : 0) + weight * 2/n * (l - l_ref)   (weight = the relation_loss_weight schedule, :141-149).
  * hs_ce_rows: F.cross_entropy(logits [rows][cols], labels = label0 + row), the local_loss branch (:173-177):
- *   loss[0] += weight * mean CE;  dlogits = (accumulate ? dlogits : 0) + weight * (softmax - onehot) / rows. */
+ *   loss[0] += weight * mean CE;  dlogits = (accumulate ? dlogits : 0) + weight * (softmax - onehot) / rows.
+ * hs_rowmix: out[i, :] = sum_j w(i,j) X[j, :], w(i,j) = W[i*ldw + j] (trans 0) or W[j*ldw + i] (trans 1); i < n_out, j < n_in: the
+ *   backward products of the logits GEMM (d img = dlogits @ txt, d txt = dlogits^T @ img) for any global batch (n x n x d, tiny). */
 int hs_scale_dev(const float* x, float* y, const float* alpha_dev, float alpha, int64_t n, void* stream);
+int hs_rowmix(const float* W, const float* X, float* out, int n_out, int n_in, int d, int64_t ldw, int64_t ldx, int64_t ldo, int trans,
+              void* stream);
 int hs_dot(const float* a, const float* b, float* out, float alpha, int64_t n, void* stream);
 int hs_relation_mse(const float* l_ref, const float* l, float* dl, float* loss, int64_t n, float weight, int accumulate, void* stream);
 int hs_ce_rows(const float* logits, float* dlogits, float* loss, int rows, int cols, int label0, float weight, int accumulate,

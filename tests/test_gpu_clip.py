@@ -20,7 +20,7 @@ def _feats(n, seed, d=768):
     return RC.synthetic_text_features(n, seed), RC.synthetic_text_features(n, seed + 1)
 
 
-@pytest.mark.parametrize("n", [4, 8, 80])
+@pytest.mark.parametrize("n", [1, 3, 8, 80])
 @pytest.mark.parametrize("local_loss", [False, True])
 def test_contrastive_and_relation_vs_oracle(dev, n, local_loss):
     """loss = CE(stage-2) + w * relation MSE against detached stage-1 logits; gradients to both feature sets and logit_scale."""
@@ -46,8 +46,9 @@ def test_contrastive_and_relation_vs_oracle(dev, n, local_loss):
     rm = clip.image_text_relation_regulation(c1, d1, c2, d2)
     (lm + w * rm).backward()
     assert rel(c2, a2.detach()) < 1e-5 and rel(d2, b2.detach()) < 1e-5
-    assert abs(float(lm) - float(lr_)) < 1e-5 * abs(float(lr_)) and abs(float(rm) - float(rr)) < 1e-4 * abs(float(rr)) + 1e-7
-    assert rel(im.grad, ir.grad) < 1e-4 and rel(tm.grad, tr.grad) < 1e-4
+    assert abs(float(lm) - float(lr_)) <= 1e-5 * abs(float(lr_)) + 1e-6 and abs(float(rm) - float(rr)) <= 1e-4 * abs(float(rr)) + 1e-6
+    assert float((im.grad.cpu() - ir.grad).abs().max()) <= 1e-4 * float(ir.grad.abs().max()) + 1e-6
+    assert float((tm.grad.cpu() - tr.grad).abs().max()) <= 1e-4 * float(tr.grad.abs().max()) + 1e-6
     assert abs(float(sm.grad) - float(sr.grad)) < 1e-4 * abs(float(sr.grad)) + 1e-6
     with pytest.raises(ValueError):
         clip.image_text_contrastive_learning(im, tm, sm, labels=torch.arange(n))
