@@ -179,8 +179,8 @@ def build_engine(workload, geom, batch, dev, group=None):
         pk = dict(grid=geom["grid"], kernel_size=geom["kernel"])
         p1 = H.VisualPacker_3d_phi_v3(img, patch, 768, OUT_DIM, "mlp", 2, **pk).to(dev)
         p2 = H.VisualPacker_3d_phi_v3(img, patch, 768, OUT_DIM, "mlp", 2, **pk).to(dev)
-        eng = DualEngine(tower, p1, p2, batch, lr=1e-4, weight_decay=0.1, group=group,
-                         two_streams=os.environ.get("HS_DUAL_STREAMS", "1") != "0")       # (env: A/B runs only)
+        ts = os.environ.get("HS_DUAL_STREAMS")                     # (env: A/B runs only; default = the engine's batch rule)
+        eng = DualEngine(tower, p1, p2, batch, lr=1e-4, weight_decay=0.1, group=group, two_streams=None if ts is None else ts != "0")
         pe = tower.vision_tower_stage1.patch_embedding
         return eng, pe, True
     if workload == "clip_c4a":

@@ -408,7 +408,8 @@ class DualEngine(_Engine):
     backward = packers -> 2E3 encoder -> 3D-ViT encoder, gradient ranges all-reduced as they complete."""
 
     def __init__(self, tower: ViT3DTower_dual_encoders, packer1: VisualPacker_3d_phi_v3, packer2: VisualPacker_3d_phi_v3, batch: int, *,
-                 lr=1e-4, weight_decay=0.1, max_grad_norm: Optional[float] = 1.0, n_buckets=4, group=None, two_streams: bool = True):
+                 lr=1e-4, weight_decay=0.1, max_grad_norm: Optional[float] = 1.0, n_buckets=4, group=None,
+                 two_streams: Optional[bool] = None):
         if tower.select_feature != "patch" or tower.remain_2d3d_ViT_type != "dual_vits":
             raise L.HsError("DualEngine drives the shipped configuration: select_feature='patch', remain_2d3d_ViT_type='dual_vits'")
         self.tower, self.B = tower, batch
@@ -444,7 +445,12 @@ class DualEngine(_Engine):
         self.dout = torch.empty_like(self.out)
         # The two encoder/packer chains are independent between the shared patchify and the loss: run the 2E3 chain on a side HIP
         # stream so the dispatcher can fill CUs one chain's launch leaves idle (small batches: a 4097-row GEMM has 153-204 tiles
-        # for 256 CUs, an attention launch 396 blocks for 512 slots).
+        # for 256 CUs, an attention launch 396 blocks for 512 slots).  Measured gain: +29 % at 1 volume per GPU, +24 % at 2, +17 % at
+        # 4, +10 % at 8, +6 % at 12, +1.7 % at 20.  Default: on below 16 volumes per GPU; from 16 up the chains run on ONE stream, so
+        # that per-kernel durations (HIP events, rocprofv3) are those of kernels running alone -- the roofline figures bench.py
+        # reports at its default batch are not inflated by a co-running kernel.
+        if two_streams is None:
+            two_streams = batch < 16
         self.two_streams = two_streams
         self.side = torch.cuda.Stream(device=self.dev) if two_streams else None
 
