@@ -13,7 +13,8 @@ random-init weights.  A "step" = one such train step over one batch.
         bench.py --gpus N --steps K --warmup W
 
 Other workloads: --workload vit256 (configs[1]: the 3D-ViT alone), clip_c4a (configs[3]: the reference's stage-2 CLIP step),
-native_dual (configs[2] at the reference's own 32x256x256 / 4x16x16 geometry).
+mrg_c5 (configs[4]: frozen towers + trainable packers spliced into a random-init HF Phi-4-mini-shaped decoder; reported, not
+roofline-scored: the LLM is outside the HIP path), native_dual (configs[2] at the reference's own 32x256x256 / 4x16x16 geometry).
 
 Prints ONE JSON line (rank 0).  Extra objects: `roofline` (dominant kernel class, measured with HIP events on the launch
 stream in a second, instrumented pass over the same steps), `cpu_baseline` (the CPU oracle — a plain-PyTorch fp32 port of the
@@ -44,7 +45,9 @@ GEOM = {
     "vit256": dict(img=(256, 256, 256), patch=(16, 16, 16), cfg="configs[1]"),
     "clip_c4a": dict(img=(256, 256, 256), patch=(16, 16, 16), cfg="configs[3]"),
     "native_dual": dict(img=(32, 256, 256), patch=(4, 16, 16), grid=(8, 16, 16), kernel=(1, 4, 4), cfg="configs[2] at the reference-native geometry"),
+    "mrg_c5": dict(img=(256, 256, 256), patch=(16, 16, 16), grid=(16, 16, 16), kernel=(2, 4, 4), cfg="configs[4]"),
 }
+SEQ_LEN = 800     # script/train_vlm_mrg.sh:11 --model_max_length 800
 OUT_DIM = 3072    # Phi-4-mini hidden size: the projector's output width (multimodal_projector/builder.py:99)
 
 
@@ -68,6 +71,8 @@ def flops_per_volume(workload, Np, Pd, d=768, L=12, ns=32, cells=128, out=OUT_DI
         return 3.0 * (2 * enc + sga + 2 * packer)
     if workload == "clip_c4a":      # frozen 3D-ViT forward + trainable 2E3 fwd+bwd (CLIP_stage2.py:119-151): 4 forward units
         return enc + 3.0 * (enc + sga)
+    if workload == "mrg_c5":        # vision side only: frozen towers forward, packers forward + backward (the LLM is not counted)
+        return 2 * enc + sga + 3.0 * 2 * packer
     return 3.0 * enc
 
 
@@ -192,9 +197,49 @@ def build_engine(workload, geom, batch, dev, group=None):
                for _ in range(2)]                                   # frozen text embeddings: normalize(N(0,1))
         eng.set_text_features(*txt)
         return eng, model.vision_encoder.patch_embedding, True
+    if workload == "mrg_c5":
+        return build_mrg(geom, batch, dev, group)
     model = H.ViT_stage1(in_channels=1, img_size=img, patch_size=patch, pos_embed="perceptron", classification=True).to(dev)
     eng = FlatEncoder(model, batch, lr=1e-4, weight_decay=0.1, group=group)
     return eng, model.patch_embedding, False
+
+
+def build_mrg(geom, batch, dev, group):
+    """BASELINE configs[4]: dual encoders (frozen) + two packers (trainable) spliced into a stock HF Phi-4-mini-shaped decoder
+    (random-init from its config -- no weights offline --, bf16, frozen; the LLM runs on PyTorch-ROCm and is OUT OF SCOPE of the HIP
+    path: it is there so that the step has the reference's shape, lamed_phi3.py:41-148)."""
+    import hsenet_amd as H
+    from hsenet_amd.mrg_step import MRGStepEngine
+    from transformers import Phi3Config, Phi3ForCausalLM
+    img, patch = geom["img"], geom["patch"]
+    tower = H.build_vision_tower(TowerCfg(img, patch)).to(dev)
+    pk = dict(grid=geom["grid"], kernel_size=geom["kernel"])
+    p1 = H.VisualPacker_3d_phi_v3(img, patch, 768, OUT_DIM, "mlp", 2, **pk).to(dev)
+    p2 = H.VisualPacker_3d_phi_v3(img, patch, 768, OUT_DIM, "mlp", 2, **pk).to(dev)
+    eng = MRGStepEngine(tower, p1, p2, batch, lr=1e-4, weight_decay=0.0, group=group)       # script/train_vlm_mrg.sh:14,26: lr 1e-4, wd 0
+    cfg = Phi3Config(hidden_size=OUT_DIM, intermediate_size=8192, num_hidden_layers=32, num_attention_heads=24, num_key_value_heads=8,
+                     vocab_size=200064, max_position_embeddings=4096, pad_token_id=0, bos_token_id=1, eos_token_id=2,
+                     tie_word_embeddings=True, attn_implementation="sdpa")
+    torch.manual_seed(99)
+    with torch.device(dev):
+        llm = Phi3ForCausalLM(cfg).to(torch.bfloat16)
+    llm.requires_grad_(False)
+    rng = np.random.default_rng(77 + int(os.environ.get("RANK", "0")))
+    ids = torch.from_numpy(rng.integers(3, 200064, (batch, SEQ_LEN))).to(dev)
+    labels = ids.clone()
+    labels[:, :1 + 256] = -100                                    # no LM loss on the bos + image-token positions
+    with torch.no_grad():
+        embeds = llm.get_input_embeddings()(ids)
+
+    def llm_loss(emb):
+        return llm(inputs_embeds=emb.to(torch.bfloat16), labels=labels).loss
+
+    class _Step:        # adapter to the bench loop's train_step(vol, slices)
+        flat = eng.flat
+
+        def train_step(self, vol, s2d):
+            eng.train_step(vol, s2d, embeds, llm_loss)
+    return _Step(), tower.vision_tower_stage1.patch_embedding, True
 
 
 def timed_run(eng, needs_2d, vols, slices, steps, warmup, sync):
@@ -225,7 +270,7 @@ def main():
     ap.add_argument("--no-batch1", action="store_true")
     a = ap.parse_args()
     if a.batch is None:
-        a.batch = 1 if a.workload == "clip_c4a" else 20
+        a.batch = 1 if a.workload in ("clip_c4a", "mrg_c5") else 20
 
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -311,6 +356,9 @@ def main():
         "vit256": "3D-ViT patch {p} 12 layers d=768 (N={N} tokens), fwd+bwd+grad all-reduce+clipped AdamW",
         "clip_c4a": "stage-2 CLIP step (CLIP_stage2.py:119-151): frozen 3D-ViT forward + 2E3-ViT fwd+bwd (patch {p}, N={N}), cls -> "
                     "mm_vision_proj -> normalize, all-gather, InfoNCE vs frozen text embeds + relation MSE, grad all-reduce+clipped AdamW",
+        "mrg_c5": "MRG finetune step: frozen dual encoders (patch {p}, N={N}) forward, two Spatial Packers fwd+bwd, 256 image tokens spliced "
+                  "into 800 token embeddings of a random-init frozen Phi-4-mini-shaped HF decoder (PyTorch-ROCm, out of the HIP path's scope; its "
+                  "FLOPs are NOT in model_tflops), LM loss, packer grad all-reduce+clipped AdamW",
     }[a.workload].format(p=patch, N=Np + 1)
     out = {
         "metric": METRIC, "value": round(vols_per_s, 3), "unit": "CT-volumes/sec",
@@ -338,7 +386,7 @@ def main():
         out["batch1"] = {"value": round(n1 / dt1, 3), "unit": "CT-volumes/sec", "ms_per_step": round(1e3 * dt1 / n1, 3), "steps": n1,
                          "mfma_roofline_frac_end_to_end": round(n1 / dt1 * fb / 1e12 / PEAK_BF16_TFLOPS, 4)}
         del eng1
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and a.workload != "mrg_c5":      # (the LLM-dominated step has no CPU leg)
         out["cpu_baseline"] = cpu_baseline(a.workload, geom)
     if rank == 0:
         print(json.dumps(out), flush=True)

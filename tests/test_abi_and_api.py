@@ -119,3 +119,40 @@ def test_wgrad_split_and_bucket_plan():
     assert bounds == [(1900, 2264), (1600, 1900), (1300, 1600), (0, 1300)]
     # buckets tile the flat buffer exactly once
     assert sorted(bounds)[0][0] == 0 and all(a[1] == b[0] for a, b in zip(sorted(bounds), sorted(bounds)[1:]))
+
+
+def test_fused_driver_descriptors_validate_without_a_gpu():
+    """hs_embed_* / hs_packer_* / hs_vit_* reject bad descriptors and null pointers with error codes before touching the device
+    (no compute call is made here), and their workspace sizes follow the geometry."""
+    import ctypes as C
+    from hsenet_amd import _lib as L
+    lib = L.load()
+    e = L.EmbedDesc(2, 4096, 4096, 768, 1, 1, 32, 1, 0.1)
+    big = lib.hs_embed_workspace_bytes(C.byref(e))
+    e0 = L.EmbedDesc(2, 4096, 4096, 768, 1, 0, 32, 1, 0.0)
+    small = lib.hs_embed_workspace_bytes(C.byref(e0))
+    assert big > small > 2 * 4096 * 768 * 4                       # the scorer's activations dominate; stage-1 keeps pe + dpe
+    e_eval = L.EmbedDesc(2, 4096, 4096, 768, 1, 1, 32, 0, 0.0)
+    assert lib.hs_embed_workspace_bytes(C.byref(e_eval)) < big       # forward-only / eval(): no backward scratch, no dropout maps
+    for bad in (L.EmbedDesc(0, 4096, 4096, 768, 1, 1, 32, 1, 0.0), L.EmbedDesc(2, 4096, 4095, 768, 1, 0, 32, 1, 0.0),
+                L.EmbedDesc(2, 4096, 4096, 770, 1, 0, 32, 1, 0.0), L.EmbedDesc(2, 4096, 4096, 768, 1, 1, 30, 1, 0.0),
+                L.EmbedDesc(2, 4096, 4096, 768, 1, 1, 32, 1, 1.5)):
+        assert lib.hs_embed_workspace_bytes(C.byref(bad)) == 0
+        assert lib.hs_embed_fwd(C.byref(bad), 1, 1, 1, 1, 1, 0, None) < 0
+    assert lib.hs_embed_fwd(C.byref(e), None, None, None, None, None, 0, None) == L.HS_ERR_ARG
+    assert lib.hs_embed_bwd(C.byref(e_eval), 1, 1, 1, 1, 1, 0, None) == L.HS_ERR_ARG      # backward needs save_for_bwd
+    T, d, out = 4096, 768, 3072
+    k = L.PackerDesc(2, 16, 16, 16, 2, 4, 4, d, out, 1, (T + 1) * d, 2 * 128 * out, 1, 0.0)
+    assert lib.hs_packer_workspace_bytes(C.byref(k)) > 2 * T * 2 * d * 4
+    for bad in (L.PackerDesc(2, 16, 16, 16, 4, 8, 8, d, out, 1, (T + 1) * d, 2 * 128 * out, 1, 0.0),       # 256 children > 64
+                L.PackerDesc(2, 16, 16, 16, 2, 4, 4, d, out, 1, T * d, 2 * 128 * out, 1, 0.0),             # batch stride too short for the row offset
+                L.PackerDesc(2, 16, 16, 16, 2, 4, 4, d, out, 1, (T + 1) * d, 100, 1, 0.0),                 # output stride < cells * out_dim
+                L.PackerDesc(2, 16, 16, 16, 2, 4, 4, d, 3070, 1, (T + 1) * d, 2 * 128 * 3070, 1, 0.0)):
+        assert lib.hs_packer_workspace_bytes(C.byref(bad)) == 0
+        assert lib.hs_packer_fwd(C.byref(bad), 1, 1, 1, 1, 0, None) < 0
+    assert lib.hs_packer_fwd(C.byref(k), None, None, None, None, 0, None) == L.HS_ERR_ARG
+    v = L.VitDesc(1, 4097, 768, 12, 3072, 12, L.PREC_BF16, 1, 0.0, None)
+    per_volume = lib.hs_vit_workspace_bytes(C.byref(v))
+    assert 1.0e9 < per_volume < 1.6e9                               # DESIGN.md section 1: ~1.2 GB of saved activations per 256^3 volume
+    assert lib.hs_vit_workspace_bytes(C.byref(L.VitDesc(1, 4097, 768, 11, 3072, 12, L.PREC_BF16, 1, 0.0, None))) == 0   # head dim != 64
+    assert lib.hs_sumsq(None, None, None, 8, None) == L.HS_ERR_ARG and lib.hs_rows_copy(None, 0, None, None, 0, 1, 1, 4, None) == L.HS_ERR_ARG

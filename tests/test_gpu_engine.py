@@ -209,3 +209,47 @@ def test_flat_encoder_stage2_vs_oracle(dev):
     assert errs[worst] < 5e-2, (worst, errs[worst])
     with pytest.raises(L.HsError):
         eng.forward(x.to(dev).transpose(3, 4), s.to(dev))          # non-contiguous volume: refused, not silently mis-read
+
+
+def test_mrg_step_engine_vs_oracle(dev):
+    """BASELINE configs[4] in miniature: frozen dual towers + trainable packers -> splice into the token embeddings of a tiny HF
+    Phi-3 decoder (the out-of-scope LLM, the same weights on both sides) -> LM loss; packer gradients vs the oracle's autograd,
+    no gradient for the towers, and one AdamW step moves only the packers."""
+    from transformers import Phi3Config, Phi3ForCausalLM
+    from hsenet_amd.mrg_step import MRGStepEngine
+    from oracle import ref_cpu as R, clip_cpu as RC
+    from test_gpu_parity import grad_errs
+    B, S = 2, 24
+    tr, p1r, p2r, sds, x, s = _oracle(B, 980)
+    tr.requires_grad_(False)
+    cfg = Phi3Config(hidden_size=OUT, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2, vocab_size=500,
+                     pad_token_id=0, bos_token_id=1, eos_token_id=2, attn_implementation="eager")
+    torch.manual_seed(3)
+    llm_r = Phi3ForCausalLM(cfg).eval()
+    llm_r.requires_grad_(False)
+    ids = torch.randint(3, 500, (B, S))
+    labels = ids.clone()
+    labels[:, :1 + 16] = -100
+    emb = llm_r.get_input_embeddings()(ids).detach()
+    feats_r = R.encode_images(tr, p1r, p2r, x, s)                              # (B, 16, OUT): 2 packers x 8 cells
+    loss_r = llm_r(inputs_embeds=RC.splice_image_features(emb, feats_r), labels=labels).loss
+    loss_r.backward()
+    tower, p1, p2 = _mine(sds, dev)
+    eng = MRGStepEngine(tower, p1, p2, B, lr=1e-3)
+    llm = Phi3ForCausalLM(cfg).eval()
+    llm.load_state_dict(llm_r.state_dict())
+    llm = llm.to(dev)
+    llm.requires_grad_(False)
+    before = {n: p.detach().clone() for n, p in _named(tower, p1, p2)}
+    eng.train_step(x.to(dev), s.to(dev), emb.to(dev), lambda e: llm(inputs_embeds=e, labels=labels.to(dev)).loss)
+    torch.cuda.synchronize()
+    assert abs(float(eng.last_loss) - float(loss_r)) < 2e-3 * abs(float(loss_r)), (float(eng.last_loss), float(loss_r))
+    mine = [(n, p) for n, p in _named(tower, p1, p2) if n.startswith("mm_projector")]
+    ref = [(n, p) for n, p in _named(tr, p1r, p2r) if n.startswith("mm_projector")]
+    errs = grad_errs(mine, ref)
+    worst = max(errs, key=errs.get)
+    print(f"MRG step: loss {float(eng.last_loss):.4f} vs {float(loss_r):.4f}; worst packer grad err {worst} {errs[worst]:.2e}")
+    assert errs[worst] < 5e-2, (worst, errs[worst])
+    for n, p in _named(tower, p1, p2):
+        moved = float((p.detach() - before[n]).abs().max())
+        assert (moved > 0) == n.startswith("mm_projector"), (n, moved)           # towers frozen, packers trained
