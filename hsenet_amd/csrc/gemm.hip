@@ -22,6 +22,7 @@ struct GemmP {
     int scale_cols; float scale_alpha;     // columns n < scale_cols carry the extra factor scale_alpha
     int nt;                                // streaming (nontemporal) output stores, see hs_gemm
     int nblocks;                           // tiles_m * tiles_n * zdim (the persistent kernel walks them with stride gridDim.x)
+    int gm;                                // row tiles per group of the tile order (chosen by hs_gemm, see tile_order)
     // diagnostic (tools/kbench, HS_GEMM_DBG): 1 = skip the epilogue, 2 = one K-tile only, 3 = epilogue without its stores, 4 = s_memtime
     // phase sums (hs_debug_gemm_stamps), 5 = every K-tile re-reads the first (cache hits), 7 = 3 + 4, 22 = per-block timeline
     // (hs_debug_gemm_trace).  0 in production.
@@ -532,13 +533,12 @@ __device__ __forceinline__ void keep_alive(const f32x16& v) { asm volatile("" ::
 __device__ __forceinline__ void keep4(const f32x4& v) { asm volatile("" ::"v"(v)); }
 
 // virtual block b of nb -> (row tile, column tile, slice): see the comment on the XCD-aware order in gemm_bf16_kernel
-__device__ __forceinline__ void tile_order(int b, int nb, int tiles_m, int tiles_n, int& tm, int& tn, int& z) {
+__device__ __forceinline__ void tile_order(int b, int nb, int tiles_m, int tiles_n, int& tm, int& tn, int& z, int GM) {
     const int q = nb >> 3, r = nb & 7, x = b & 7;
     int v = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
     const int tiles = tiles_m * tiles_n;
     z = v / tiles;
     v -= z * tiles;
-    const int GM = tiles_n >= 8 ? 4 : (tiles_n >= 4 ? 8 : 16);
     const int per_group = GM * tiles_n;
     const int g = v / per_group, w = v - g * per_group;
     const int gm = min(GM, tiles_m - g * GM);
@@ -695,10 +695,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmP p) {
     // Blocks are dealt round-robin over the 8 XCDs (b % 8 labels the blocks sharing an L2): give each XCD a
     // CONTIGUOUS range of a virtual order v (bijective form, cdna guide section 5); v walks split-K slices slowest
     // (blocks of one slice share A and B, different slices share nothing), and inside a slice groups of GM row tiles x
-    // all column tiles, column-major inside a group (GM wider when there are few column tiles, so weight tiles are
-    // shared by more blocks).  Placement only affects speed, never results.
+    // all column tiles, column-major inside a group (GM small: see hs_gemm).  Placement only affects speed, never results.
     int tm, tn, z;
-    tile_order(blockIdx.x, gridDim.x, p.tiles_m, p.tiles_n, tm, tn, z);
+    tile_order(blockIdx.x, gridDim.x, p.tiles_m, p.tiles_n, tm, tn, z, p.gm);
     const int m0 = tm * 256, n0 = tn * C::BN;
     const int bz = p.split_k > 1 ? 0 : z;
     const bf16_t* A = (const bf16_t*)p.A + bz * p.sA;
@@ -1068,7 +1067,7 @@ __device__ __forceinline__ void nt16p_body(const GemmP& p, char* smem) {
 
     int bb = blockIdx.x;
     int tm, tn, z;
-    tile_order(bb, p.nblocks, p.tiles_m, p.tiles_n, tm, tn, z);
+    tile_order(bb, p.nblocks, p.tiles_m, p.tiles_n, tm, tn, z, p.gm);
     unsigned va[4], vb[4], van[4], vbn[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -1090,7 +1089,7 @@ __device__ __forceinline__ void nt16p_body(const GemmP& p, char* smem) {
         const int bn = bb + (int)gridDim.x;
         const bool has_next = bn < p.nblocks;
         if (has_next) {
-            tile_order(bn, p.nblocks, p.tiles_m, p.tiles_n, tm, tn, z);
+            tile_order(bn, p.nblocks, p.tiles_m, p.tiles_n, tm, tn, z, p.gm);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 van[j] = dma_voff<false, true>(j, tm * 256, p.M, 0, 64, p.lda, wave, lane);
@@ -1193,7 +1192,7 @@ __device__ __forceinline__ void nt16w_body(const GemmP& p, char* smem) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int row0 = (wave >> 1) * 128, col0 = (wave & 1) * 128;
     int tm, tn, z;
-    tile_order(blockIdx.x, gridDim.x, p.tiles_m, p.tiles_n, tm, tn, z);
+    tile_order(blockIdx.x, gridDim.x, p.tiles_m, p.tiles_n, tm, tn, z, p.gm);
     const int m0 = tm * 256, n0 = tn * 256;
     const bf16_t* A = (const bf16_t*)p.A + z * p.sA;
     const bf16_t* B = (const bf16_t*)p.B + z * p.sB;
@@ -1437,10 +1436,12 @@ namespace {
 struct GemmEnv {
     bool no_nt, no_m16, persist, w4;
     char tile;      // 0, 'b' (big) or 's' (small)
+    int gm;         // 0, or the tile order's group height
     GemmEnv() : no_nt(getenv("HS_GEMM_NO_NT") != nullptr), no_m16(getenv("HS_GEMM_NO_M16") != nullptr),
                 persist(getenv("HS_GEMM_PERSIST") != nullptr), w4(getenv("HS_GEMM_W4") != nullptr), tile(0) {
         const char* t = getenv("HS_GEMM_TILE");
         if (t && (t[0] == 'b' || t[0] == 's')) tile = t[0];
+        gm = getenv("HS_GEMM_GM") ? atoi(getenv("HS_GEMM_GM")) : 0;
     }
 };
 const GemmEnv kEnv;
@@ -1473,6 +1474,7 @@ extern "C" int hs_gemm(const hs_gemm_args* a, int prec, void* stream) {
     p.aux_out = a->aux_out; p.colsum = a->colsum_out; p.alpha = a->alpha; p.flags = a->flags; p.split_k = a->split_k;
     p.scale_cols = a->scale_cols; p.scale_alpha = a->scale_cols_alpha;
     p.dbg = g_hs_dbg[3];
+    p.gm = 0;
     // Output stores of a GEMM whose result cannot stay in the caches anyway are issued as streaming (nontemporal) stores:
     // ordinary stores park 128 KiB of dirty lines per tile in the XCD's 4-MiB L2 -- 32 tiles per round = the whole L2 --
     // evicting the operand panels the other blocks are about to hit (measured on the 81940-row ViT-B shapes: main-loop vmcnt
@@ -1496,6 +1498,11 @@ extern "C" int hs_gemm(const hs_gemm_args* a, int prec, void* stream) {
         // (kEnv.tile: 'b' / 's' force the NT / NN tile for A/B runs; the TN kernel only exists with the 256x128 tile)
         const bool big = !(a->K & 63) && a->layout != HS_GEMM_TN && (kEnv.tile ? kEnv.tile == 'b' : 2 * big_blocks > ncu);
         p.tiles_n = (a->N + (big ? 255 : 127)) / (big ? 256 : 128);
+        // group height of the tile order: the column tiles that share an A row panel must run AT THE SAME TIME (they then pull
+        // each A K-tile into the XCD's L2 once); with few column tiles a tall group puts the sharers 16-32 dispatch slots apart and
+        // the N = 768 / K = 3072 shapes re-read their 1.5-MiB A panels (measured, tools/gm_sweep.sh at M = 81940: fc2 417 -> 380 us,
+        // dgrad fc1 446 -> 420, dgrad qkv 327 -> 315, fc2+resid 491 -> 460 with 2 instead of 16; 9-12 column tiles: 2..8 within noise)
+        p.gm = kEnv.gm > 0 ? kEnv.gm : (p.tiles_n >= 8 ? 4 : 2);
         dim3 grid(p.tiles_m * p.tiles_n * zdim, 1, 1);
         // epilogue specialisations (compile-time flags); anything else runs the generic kernel (EF = -1)
         const bool col8 = !(a->N & 7) && !(a->ldc & 7) && !(a->scale_cols & 7);
