@@ -21,7 +21,7 @@ struct GemmP {
     float alpha; int flags; int split_k; int tiles_m, tiles_n;
     int scale_cols; float scale_alpha;     // columns n < scale_cols carry the extra factor scale_alpha
     int nt;                                // streaming (nontemporal) output stores, see hs_gemm
-    int nblocks;                           // tiles_m * tiles_n * zdim (the persistent kernel walks them with stride gridDim.x)
+    int nblocks;                           // tiles_m * tiles_n * zdim
     int gm;                                // row tiles per group of the tile order (chosen by hs_gemm, see tile_order)
     // diagnostic (tools/kbench, HS_GEMM_DBG): 1 = skip the epilogue, 2 = one K-tile only, 3 = epilogue without its stores, 4 = s_memtime
     // phase sums (hs_debug_gemm_stamps), 5 = every K-tile re-reads the first (cache hits), 7 = 3 + 4, 22 = per-block timeline
@@ -106,17 +106,6 @@ __device__ __forceinline__ unsigned dma_voff(int j, int dim0, int DIM, int k0, i
 }
 __device__ __forceinline__ void dma_piece(__amdgpu_buffer_rsrc_t rs, char* lds_area, int j, int wave, unsigned voff, unsigned soff) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (LDS_PTR(void))(lds_area + (j * 8 + wave) * 1024), 16, voff, soff, 0, 0);
-}
-// the same images filled by a 4-wave block (gemm_nt16w): piece j of a wave is piece index j*4 + wave, 8 pieces per operand per wave
-template <bool PERMN>
-__device__ __forceinline__ unsigned dma_voff4(int j, int dim0, int DIM, long ld, int wave, int lane) {
-    const int row = (j * 4 + wave) * 8 + (lane >> 3);
-    const int c = (lane & 7) ^ swzR16(row);
-    const int gi = dim0 + (PERMN ? permN(row) : row);
-    return gi < DIM ? (unsigned)(((long)gi * ld + c * 8) * 2) : HS_OOB_OFF;
-}
-__device__ __forceinline__ void dma_piece4(__amdgpu_buffer_rsrc_t rs, char* lds_area, int j, int wave, unsigned voff, unsigned soff) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (LDS_PTR(void))(lds_area + (j * 4 + wave) * 1024), 16, voff, soff, 0, 0);
 }
 // fragment of the 32-wide block starting at `sub` (0..255) of an operand image, k-step ks
 #ifdef HS_ABLATE_TR   // ablation build only: read T images with plain row reads (wrong data, same bytes)
@@ -988,344 +977,6 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmP p) {
 }
 
 // ------------------------------------------------------------------------------------------------------
-// Persistent form of the 256x256 NT 16x16x32 kernel.  One block per CU walks the virtual block order with stride
-// gridDim.x (the same XCD-aware order: at any time the chip works on the tiles the one-tile-per-block grid would).  The
-// K-tile stream never drains: the last two K-steps of a tile prefetch the NEXT tile's K-tiles 0 and 1 (the register
-// epilogue leaves the LDS ring free), the epilogue's stores are issued behind those loads and retire under the next
-// tile's first K-steps -- a block that ends instead pays the store drain, the block launch and the first DMA round
-// trip in the open (measured timeline: 5.8k + 6k of a 45.5k-cycle tile period at K = 768).
-//   per tile:  k-step 0          no DMA in phase 0 (B of K-tile 1 is already in flight); the tile barrier waits for K-tile 1
-//                                 with a COUNTED vmcnt that leaves the previous tile's stores in flight
-//              k-steps 1..KT-3    as big_mainloop16
-//              k-step KT-2        phase 3 issues A of the next tile's K-tile 0
-//              k-step KT-1        phase 0 issues B of the next tile's K-tile 0, phase 3 A and B of its K-tile 1
-// Requires K % 64 == 0, K >= 192, batch == 1 (hs_gemm picks the one-tile kernel otherwise).
-// ------------------------------------------------------------------------------------------------------
-// the phases of a k-step are hand-placed: nothing may be scheduled across their seams (without the branches of the one-tile
-// kernel the whole k-step is one basic block and hipcc shuffles the MFMAs over the waits and the barrier: -7 %)
-#define SB() __builtin_amdgcn_sched_barrier(0)
-template <int NST>
-__device__ __forceinline__ void wait_tile_counted() {
-    // the newest NST vector-memory operations (the previous tile's stores) may stay in flight
-    if (NST == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    else if (NST == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-    else if (NST == 48) asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-template <int EF>
-__device__ __forceinline__ void nt16p_body(const GemmP& p, char* smem) {
-    constexpr int STAGE = 65536;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int row0 = (wave >> 2) * 128, col0 = (wave & 3) * 64;
-    const int KT = p.K >> 6;
-    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.A, (size_t)p.M * p.lda * 2);
-    const __amdgpu_buffer_rsrc_t rsB = make_rsrc(p.B, (size_t)p.N * p.ldb * 2);
-    // stores one wave issues per FULL tile (rows all inside M): what the counted wait may leave in flight
-    const int nst = (p.out_bf16 ? 16 : 0) + (p.out_f32 ? 32 : 0) + (((EF & HS_EPI_GELU) && p.aux_out) ? 16 : 0);
-
-    const int r = lane & 15, q = lane >> 4, f = swzR16(r);
-    unsigned ab0[2], bb0[2];
-#pragma unroll
-    for (int st = 0; st < 2; ++st) {
-        ab0[st] = lds_off(smem) + (row0 + r) * 128 + (((4 * st + q) ^ f) << 4);
-        bb0[st] = lds_off(smem) + 32768 + (col0 + r) * 128 + (((4 * st + q) ^ f) << 4);
-    }
-    u32x4 fa[2][4], fb[2][4];
-    f32x4 acc[8][4];
-    auto rdA = [&](auto set_tag, auto st_tag, auto hf_tag, unsigned so) {
-        constexpr int S = decltype(set_tag)::value, ST = decltype(st_tag)::value, HF = decltype(hf_tag)::value;
-        const unsigned a = ab0[ST] + so;
-        ldsr128<(HF * 4 + 0) * 2048>(fa[S][0], a); ldsr128<(HF * 4 + 1) * 2048>(fa[S][1], a);
-        ldsr128<(HF * 4 + 2) * 2048>(fa[S][2], a); ldsr128<(HF * 4 + 3) * 2048>(fa[S][3], a);
-    };
-    auto rdB = [&](auto set_tag, auto st_tag, unsigned so) {
-        constexpr int S = decltype(set_tag)::value, ST = decltype(st_tag)::value;
-        const unsigned b = bb0[ST] + so;
-        ldsr128<0>(fb[S][0], b); ldsr128<2048>(fb[S][1], b); ldsr128<4096>(fb[S][2], b); ldsr128<6144>(fb[S][3], b);
-    };
-    auto mma = [&](auto aset_tag, auto bset_tag, auto hf_tag) {
-        constexpr int SA = decltype(aset_tag)::value, SB = decltype(bset_tag)::value, HF = decltype(hf_tag)::value;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[HF * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(fb[SB][j]), as_frag(fa[SA][i]), acc[HF * 4 + i][j], 0, 0, 0);
-    };
-    auto dmaA = [&](const unsigned (&v)[4], int kt, unsigned so) {
-#pragma unroll
-        for (int pc = 0; pc < 4; ++pc) dma_piece(rsA, smem + so, pc, wave, v[pc], (unsigned)kt * 128u);
-    };
-    auto dmaB = [&](const unsigned (&v)[4], int kt, unsigned so) {
-#pragma unroll
-        for (int pc = 0; pc < 4; ++pc) dma_piece(rsB, smem + so + 32768, pc, wave, v[pc], (unsigned)kt * 128u);
-    };
-    typedef std::integral_constant<int, 0> I0;
-    typedef std::integral_constant<int, 1> I1;
-    typedef std::integral_constant<int, 2> I2;
-    typedef std::integral_constant<int, 3> I3;
-
-    int bb = blockIdx.x;
-    int tm, tn, z;
-    tile_order(bb, p.nblocks, p.tiles_m, p.tiles_n, tm, tn, z, p.gm);
-    unsigned va[4], vb[4], van[4], vbn[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        va[j] = dma_voff<false, true>(j, tm * 256, p.M, 0, 64, p.lda, wave, lane);
-        vb[j] = dma_voff<false, true, true>(j, tn * 256, p.N, 0, 64, p.ldb, wave, lane);
-    }
-    dmaA(va, 0, 0u); dmaB(vb, 0, 0u);
-    dmaA(va, 1, (unsigned)STAGE); dmaB(vb, 1, (unsigned)STAGE);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    unsigned so = 0;
-    bool counted = false;               // the tile barrier of k-step 0 may leave `nst` stores in flight
-    for (;;) {
-        if (p.dbg == 22 && threadIdx.x == 0 && bb < 4096) {
-            g_gemm_trace[bb * 4 + 0] = __builtin_amdgcn_s_memtime();
-            g_gemm_trace[bb * 4 + 3] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
-        }
-        const int m0 = tm * 256, n0 = tn * 256;
-        const int bn = bb + (int)gridDim.x;
-        const bool has_next = bn < p.nblocks;
-        if (has_next) {
-            tile_order(bn, p.nblocks, p.tiles_m, p.tiles_n, tm, tn, z, p.gm);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                van[j] = dma_voff<false, true>(j, tm * 256, p.M, 0, 64, p.lda, wave, lane);
-                vbn[j] = dma_voff<false, true, true>(j, tn * 256, p.N, 0, 64, p.ldb, wave, lane);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        rdA(I0{}, I0{}, I0{}, so);
-        rdB(I0{}, I0{}, so);
-        // MODE 0: first k-step of a tile, 1: middle, 2: last but one, 3: last
-        auto kstep = [&](auto mode_tag, int kt) {
-            constexpr int MODE = decltype(mode_tag)::value;
-            const unsigned so1 = so ^ (unsigned)STAGE;
-            rdA(I1{}, I0{}, I1{}, so);
-            lds_wait8g<4>(fa[0][0], fa[0][1], fa[0][2], fa[0][3], fb[0][0], fb[0][1], fb[0][2], fb[0][3]);
-            SB(); mma(I0{}, I0{}, I0{}); SB();
-            if (MODE == 1 || MODE == 2) dmaB(vb, kt + 1, so1);
-            if (MODE == 3 && has_next) dmaB(vbn, 0, so1);
-            rdA(I0{}, I1{}, I0{}, so);
-            rdB(I1{}, I1{}, so);
-            lds_wait4<8>(fa[1][0], fa[1][1], fa[1][2], fa[1][3]);
-            SB(); mma(I1{}, I0{}, I1{}); SB();
-            rdA(I1{}, I1{}, I1{}, so);
-            lds_wait8g<4>(fa[0][0], fa[0][1], fa[0][2], fa[0][3], fb[1][0], fb[1][1], fb[1][2], fb[1][3]);
-            SB(); mma(I0{}, I1{}, I0{}); SB();
-            lds_wait4<0>(fa[1][0], fa[1][1], fa[1][2], fa[1][3]);       // every read of this stage has landed
-            if (MODE == 0 && counted) {
-                if (nst == 16) wait_tile_counted<16>(); else if (nst == 32) wait_tile_counted<32>();
-                else if (nst == 48) wait_tile_counted<48>(); else wait_tile_counted<0>();
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            __builtin_amdgcn_s_barrier();
-            SB();
-            if (MODE != 3) { rdA(I0{}, I0{}, I0{}, so1); rdB(I0{}, I0{}, so1); }
-            SB(); mma(I1{}, I1{}, I1{}); SB();
-            if (MODE == 0 || MODE == 1) dmaA(va, kt + 2, so);
-            if (MODE == 2 && has_next) dmaA(van, 0, so);
-            if (MODE == 3 && has_next) { dmaA(van, 1, so); dmaB(vbn, 1, so); }
-            so = so1;
-        };
-        kstep(I0{}, 0);
-        for (int kt = 1; kt < KT - 2; ++kt) kstep(I1{}, kt);
-        kstep(I2{}, KT - 2);
-        kstep(I3{}, KT - 1);
-        if (p.dbg == 22 && threadIdx.x == 0 && bb < 4096) g_gemm_trace[bb * 4 + 1] = __builtin_amdgcn_s_memtime();
-        epilogue16<EF>(p, acc, m0 + row0, n0 + col0, 0l, lane);
-        if (p.dbg == 22 && threadIdx.x == 0 && bb < 4096) g_gemm_trace[bb * 4 + 2] = __builtin_amdgcn_s_memtime();
-        if (!has_next) break;
-        counted = m0 + 256 <= p.M && n0 + 256 <= p.N && p.dbg != 3;     // a full tile: every wave issued exactly `nst` stores
-        bb = bn;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { va[j] = van[j]; vb[j] = vbn[j]; }
-    }
-}
-__global__ __launch_bounds__(512) void gemm_nt16p_e0_kernel(GemmP p) {
-    __shared__ __attribute__((aligned(16))) char smem[131072];
-    nt16p_body<0>(p, smem);
-}
-__global__ __launch_bounds__(512) void gemm_nt16p_e9_kernel(GemmP p) {
-    __shared__ __attribute__((aligned(16))) char smem[131072];
-    nt16p_body<HS_EPI_BIAS | HS_EPI_RESID>(p, smem);
-}
-__global__ __launch_bounds__(512) void gemm_nt16p_e67_kernel(GemmP p) {
-    __shared__ __attribute__((aligned(16))) char smem[131072];
-    nt16p_body<HS_EPI_BIAS | HS_EPI_GELU | HS_EPI_SAVE_DGELU>(p, smem);
-}
-
-// ------------------------------------------------------------------------------------------------------
-// 256x256 NT tile on FOUR waves (2 x 2, wave tile 128x128 = 8 x 8 tiles of 16x16x32, one wave per SIMD, 256 accumulator
-// registers).  Why: with eight waves of 128x64 every K-tile costs the CU's LDS port 192 KiB of fragment reads + 64 KiB of DMA
-// writes = 2048 cycles at 128 B/clk -- exactly the 2048 MFMA cycles of the K-tile, so the eight-wave loop is LDS-bound by
-// construction (measured: 73 % MFMA-busy in the main loop).  The 128x128 wave tile reuses every fragment twice as often:
-// 128 + 64 KiB = 1536 cycles.  Same images, same swapped-operand accumulator and register epilogue as gemm_bf16_kernel<M16>.
-//   per K-tile (stage so), four phases of 32 MFMAs; a phase = wait for the reads issued one phase ago (lgkmcnt(0): they had 512
-//   MFMA cycles), issue the next phase's reads (never more than 12 in flight), MFMAs with the DMA pieces spread between them:
-//     P0 (k 0-31, rows 0-63)     reads A(k 0-31, rows 64-127)
-//     P1 (k 0-31, rows 64-127)   reads A(k 32-63, rows 0-63), B(k 32-63)
-//     P2 (k 32-63, rows 0-63)    reads A(k 32-63, rows 64-127)
-//     lgkmcnt(0), vmcnt(0), s_barrier
-//     P3 (k 32-63, rows 64-127)  reads of tile t+1: A(k 0-31, rows 0-63), B(k 0-31)   DMA: all 16 pieces of tile t+2 -> this stage
-//   (the DMA runs a full K-tile ahead; issued in P0 as in the eight-wave loop, the B pieces were late at the tile barrier)
-// ------------------------------------------------------------------------------------------------------
-template <class F, int... I>
-__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
-template <int N, class F>
-__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
-// the 256 accumulator registers of the 128x128 wave tile are pinned to AGPRs ("+a"): left to the register allocator, part of
-// them lives in VGPRs and 96 v_accvgpr copies per K-tile shuttle them back and forth
-__device__ __forceinline__ void mfma16_agpr(f32x4& c, const u32x4& b, const u32x4& a) {
-    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(b), "v"(a));
-}
-template <int EF>
-__device__ __forceinline__ void nt16w_body(const GemmP& p, char* smem) {
-    constexpr int STAGE = 65536;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int row0 = (wave >> 1) * 128, col0 = (wave & 1) * 128;
-    int tm, tn, z;
-    tile_order(blockIdx.x, gridDim.x, p.tiles_m, p.tiles_n, tm, tn, z, p.gm);
-    const int m0 = tm * 256, n0 = tn * 256;
-    const bf16_t* A = (const bf16_t*)p.A + z * p.sA;
-    const bf16_t* B = (const bf16_t*)p.B + z * p.sB;
-    const long cz = z * p.sC;
-    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(A, (size_t)p.M * p.lda * 2);
-    const __amdgpu_buffer_rsrc_t rsB = make_rsrc(B, (size_t)p.N * p.ldb * 2);
-    const int KT = p.dbg == 2 ? 1 : (p.K >> 6);
-    if (p.dbg == 22 && tid == 0 && blockIdx.x < 4096) {
-        g_gemm_trace[blockIdx.x * 4 + 0] = __builtin_amdgcn_s_memtime();
-        g_gemm_trace[blockIdx.x * 4 + 3] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
-    }
-    unsigned va[8], vb[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        va[j] = dma_voff4<false>(j, m0, p.M, p.lda, wave, lane);
-        vb[j] = dma_voff4<true>(j, n0, p.N, p.ldb, wave, lane);
-    }
-    const int r = lane & 15, q = lane >> 4, f = swzR16(r);
-    unsigned ab0[2], bb0[2];
-#pragma unroll
-    for (int st = 0; st < 2; ++st) {
-        ab0[st] = lds_off(smem) + (row0 + r) * 128 + (((4 * st + q) ^ f) << 4);
-        bb0[st] = lds_off(smem) + 32768 + (col0 + r) * 128 + (((4 * st + q) ^ f) << 4);
-    }
-    u32x4 fa[2][4], fb[2][8];
-    f32x4 acc[8][8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    auto settle_all = [&]() {   // every LDS read issued so far has landed; the fragment registers are pinned below the wait
-        lds_wait8g<0>(fa[0][0], fa[0][1], fa[0][2], fa[0][3], fa[1][0], fa[1][1], fa[1][2], fa[1][3]);
-        lds_wait8g<0>(fb[0][0], fb[0][1], fb[0][2], fb[0][3], fb[0][4], fb[0][5], fb[0][6], fb[0][7]);
-        lds_wait8g<0>(fb[1][0], fb[1][1], fb[1][2], fb[1][3], fb[1][4], fb[1][5], fb[1][6], fb[1][7]);
-    };
-    // prologue: K-tile 0 -> stage 0, K-tile 1 -> stage 1
-#pragma unroll
-    for (int j = 0; j < 8; ++j) dma_piece4(rsA, smem, j, wave, va[j], 0u);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) dma_piece4(rsB, smem + 32768, j, wave, vb[j], 0u);
-    if (KT > 1) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) dma_piece4(rsA, smem + STAGE, j, wave, va[j], 128u);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) dma_piece4(rsB, smem + STAGE + 32768, j, wave, vb[j], 128u);
-        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();
-    {
-        const unsigned a = ab0[0], b = bb0[0];
-        ldsr128<0>(fa[0][0], a); ldsr128<2048>(fa[0][1], a); ldsr128<4096>(fa[0][2], a); ldsr128<6144>(fa[0][3], a);
-        ldsr128<0>(fb[0][0], b); ldsr128<2048>(fb[0][1], b); ldsr128<4096>(fb[0][2], b); ldsr128<6144>(fb[0][3], b);
-        ldsr128<8192>(fb[0][4], b); ldsr128<10240>(fb[0][5], b); ldsr128<12288>(fb[0][6], b); ldsr128<14336>(fb[0][7], b);
-    }
-    unsigned so = 0;
-    for (int kt = 0; kt < KT; ++kt) {
-        const bool has1 = kt + 1 < KT, has2 = kt + 2 < KT;
-        const unsigned so1 = so ^ (unsigned)STAGE;
-        const unsigned k2 = (unsigned)(kt + 2) * 128u;
-        // One non-MFMA instruction behind each MFMA (the matrix pipe takes a new 16x16x32 every 16 cycles: an LDS read or a DMA piece
-        // issues in that shadow; with one wave per SIMD whatever is issued in bulk between MFMA groups is exposed).  MFMA X of a phase =
-        // A tile X / 8 of the phase's row half x B tile X % 8.
-        // P0: k 0-31, rows 0-63 (fa[0], fb[0]); reads A(k 0-31, rows 64-127) -> fa[1]
-        settle_all();
-        static_for<32>([&](auto x_tag) {
-            constexpr int X = decltype(x_tag)::value;
-            mfma16_agpr(acc[X >> 3][X & 7], fb[0][X & 7], fa[0][X >> 3]);
-            if constexpr (X < 4) ldsr128<(4 + X) * 2048>(fa[1][X], ab0[0] + so);
-            SB();
-        });
-        // P1: k 0-31, rows 64-127 (fa[1], fb[0]); reads A(k 32-63, rows 0-63) -> fa[0], B(k 32-63) -> fb[1]
-        settle_all();
-        static_for<32>([&](auto x_tag) {
-            constexpr int X = decltype(x_tag)::value;
-            mfma16_agpr(acc[4 + (X >> 3)][X & 7], fb[0][X & 7], fa[1][X >> 3]);
-            if constexpr (X < 4) ldsr128<X * 2048>(fa[0][X], ab0[1] + so);
-            else if constexpr (X < 12) ldsr128<(X - 4) * 2048>(fb[1][X - 4], bb0[1] + so);
-            SB();
-        });
-        // P2: k 32-63, rows 0-63 (fa[0], fb[1]); reads A(k 32-63, rows 64-127) -> fa[1]
-        settle_all();
-        static_for<32>([&](auto x_tag) {
-            constexpr int X = decltype(x_tag)::value;
-            mfma16_agpr(acc[X >> 3][X & 7], fb[1][X & 7], fa[0][X >> 3]);
-            if constexpr (X < 4) ldsr128<(4 + X) * 2048>(fa[1][X], ab0[1] + so);
-            SB();
-        });
-        settle_all();                                      // every read of this stage has landed
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile kt+1 has landed
-        __builtin_amdgcn_s_barrier();
-        SB();
-        // P3: k 32-63, rows 64-127 (fa[1], fb[1]); reads of tile kt+1: A(k 0-31, rows 0-63) -> fa[0], B(k 0-31) -> fb[0];
-        //     DMA: the 16 pieces of tile kt+2 -> this stage
-        static_for<32>([&](auto x_tag) {
-            constexpr int X = decltype(x_tag)::value;
-            mfma16_agpr(acc[4 + (X >> 3)][X & 7], fb[1][X & 7], fa[1][X >> 3]);
-            if constexpr (X < 4) { if (has1) ldsr128<X * 2048>(fa[0][X], ab0[0] + so1); }
-            else if constexpr (X < 12) { if (has1) ldsr128<(X - 4) * 2048>(fb[0][X - 4], bb0[0] + so1); }
-            else if constexpr (X < 20) { if (has2) dma_piece4(rsA, smem + so, X - 12, wave, va[X - 12], k2); }
-            else if constexpr (X < 28) { if (has2) dma_piece4(rsB, smem + so + 32768, X - 20, wave, vb[X - 20], k2); }
-            SB();
-        });
-        so = so1;
-    }
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // the asm MFMAs are opaque to the hazard recogniser: let the last ones retire
-    if (p.dbg == 22 && tid == 0 && blockIdx.x < 4096) g_gemm_trace[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memtime();
-    if (p.dbg == 1) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) keep4(acc[i][j]);
-        return;
-    }
-    epilogue16<EF, 8, 0>(p, acc, m0 + row0, n0 + col0, cz, lane);
-    epilogue16<EF, 8, 4>(p, acc, m0 + row0, n0 + col0 + 64, cz, lane);
-    if (p.dbg == 22 && tid == 0 && blockIdx.x < 4096) g_gemm_trace[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memtime();
-}
-__global__ __launch_bounds__(256) void gemm_nt16w_e0_kernel(GemmP p) {
-    __shared__ __attribute__((aligned(16))) char smem[131072];
-    nt16w_body<0>(p, smem);
-}
-__global__ __launch_bounds__(256) void gemm_nt16w_e9_kernel(GemmP p) {
-    __shared__ __attribute__((aligned(16))) char smem[131072];
-    nt16w_body<HS_EPI_BIAS | HS_EPI_RESID>(p, smem);
-}
-__global__ __launch_bounds__(256) void gemm_nt16w_e67_kernel(GemmP p) {
-    __shared__ __attribute__((aligned(16))) char smem[131072];
-    nt16w_body<HS_EPI_BIAS | HS_EPI_GELU | HS_EPI_SAVE_DGELU>(p, smem);
-}
-
-// ------------------------------------------------------------------------------------------------------
 // f32 (parity mode): 64x64x32 tile, 4 waves each one 32x32 block; k order inside a group of 8 is permuted
 // identically for A and B (lane half h takes k = 8s+4h+e for MFMA step e), which leaves the sum unchanged.
 // ------------------------------------------------------------------------------------------------------
@@ -1434,11 +1085,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmP p) {
 // A/B switches of tools/kbench and tools/bench_gemm.py, read ONCE (none is set in production; hs_gemm runs ~900 times per step)
 namespace {
 struct GemmEnv {
-    bool no_nt, no_m16, persist, w4;
+    bool no_nt, no_m16;
     char tile;      // 0, 'b' (big) or 's' (small)
     int gm;         // 0, or the tile order's group height
-    GemmEnv() : no_nt(getenv("HS_GEMM_NO_NT") != nullptr), no_m16(getenv("HS_GEMM_NO_M16") != nullptr),
-                persist(getenv("HS_GEMM_PERSIST") != nullptr), w4(getenv("HS_GEMM_W4") != nullptr), tile(0) {
+    GemmEnv() : no_nt(getenv("HS_GEMM_NO_NT") != nullptr), no_m16(getenv("HS_GEMM_NO_M16") != nullptr), tile(0) {
         const char* t = getenv("HS_GEMM_TILE");
         if (t && (t[0] == 'b' || t[0] == 's')) tile = t[0];
         gm = getenv("HS_GEMM_GM") ? atoi(getenv("HS_GEMM_GM")) : 0;
@@ -1515,22 +1165,8 @@ extern "C" int hs_gemm(const hs_gemm_args* a, int prec, void* stream) {
         const bool m16 = big && a->layout == HS_GEMM_NT && !a->colsum_out && !kEnv.no_m16;
 #define HS_LAUNCH_M16(EF) hipLaunchKernelGGL((gemm_bf16_kernel<false, false, true, EF, true>), grid, dim3(512), 0, s, p)
         p.nblocks = (int)grid.x;
-        // the persistent variant is a measured dead end kept for A/B runs (tools/kbench, HS_GEMM_PERSIST=1): it hides the block
-        // launch gap but the store issue of the epilogue stalls just as long
-        const bool no_persist = !kEnv.persist;
-        const bool w4 = kEnv.w4 && p.dbg != 4 && p.dbg != 7;
         const bool m16_ok = m16 && col8 && (f == 0 || f == (HS_EPI_BIAS | HS_EPI_RESID) || f == (HS_EPI_BIAS | HS_EPI_GELU | HS_EPI_SAVE_DGELU));
-        if (m16_ok && zdim == 1 && a->K >= 192 && (int)grid.x > ncu && !no_persist && p.dbg != 1 && p.dbg != 2 && p.dbg != 4 && p.dbg != 7) {
-            // persistent: one block per CU, a multiple of 8 so that block b stays on XCD b % 8
-            dim3 pgrid((unsigned)(ncu & ~7), 1, 1);
-            if (f == 0) hipLaunchKernelGGL(gemm_nt16p_e0_kernel, pgrid, dim3(512), 0, s, p);
-            else if (f == (HS_EPI_BIAS | HS_EPI_RESID)) hipLaunchKernelGGL(gemm_nt16p_e9_kernel, pgrid, dim3(512), 0, s, p);
-            else hipLaunchKernelGGL(gemm_nt16p_e67_kernel, pgrid, dim3(512), 0, s, p);
-        } else if (m16_ok && w4) {
-            if (f == 0) hipLaunchKernelGGL(gemm_nt16w_e0_kernel, grid, dim3(256), 0, s, p);
-            else if (f == (HS_EPI_BIAS | HS_EPI_RESID)) hipLaunchKernelGGL(gemm_nt16w_e9_kernel, grid, dim3(256), 0, s, p);
-            else hipLaunchKernelGGL(gemm_nt16w_e67_kernel, grid, dim3(256), 0, s, p);
-        } else if (m16_ok) {
+        if (m16_ok) {
             if (f == 0) HS_LAUNCH_M16(0);
             else if (f == (HS_EPI_BIAS | HS_EPI_RESID)) HS_LAUNCH_M16(HS_EPI_BIAS | HS_EPI_RESID);
             else HS_LAUNCH_M16(HS_EPI_BIAS | HS_EPI_GELU | HS_EPI_SAVE_DGELU);
