@@ -572,6 +572,180 @@ __global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const float* __restri
 }
 
 // ------------------------------------------------------------------------------------------------------
+// backward, exact f32 (parity mode).  Same two sweeps as the bf16 kernels below, built like attn_fwd_f32_kernel on
+// v_mfma_f32_32x32x2_f32 with scalar operands: the STATIONARY rows (queries for dQ, keys for dK/dV) keep their two 64-float
+// vectors in registers as B operands, the STREAMED rows (keys / queries) arrive in 64-row tiles in LDS and are read as rows (A of
+// the S and dP products) and as scalars (A of the accumulation products), and an accumulator register of S / dS is directly the B
+// scalar of the accumulation product (its key/query index = acc_row(r, h) = the k index of that MFMA step).
+//   MODE 0 (dQ):     X = q, Y = dO of the block's 128 queries; tiles T1 = K, T2 = V;   S^T = T1 X^T, dP^T = T2 Y^T,
+//                    dS^T = exp2(S^T c2 - lse') (dP^T - delta)  [row constants per LANE];      dQ^T += T1^T dS^T
+//   MODE 1 (dK, dV): X = k, Y = v of the block's 128 keys;     tiles T1 = Q, T2 = dO;  S = T1 X^T, dP = T2 Y^T,
+//                    P = exp2(S c2 - lse'_q), dS = P (dP - delta_q)  [row constants per REGISTER, from the tile's LDS copy];
+//                    dV^T += T2^T P, dK^T += T1^T dS
+// ws: [0] = -delta, [1] = -lse * log2(e), each [B][H][N] (attn_stats_f32_kernel).  No rounding anywhere: fp32 end to end.
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_stats_f32_kernel(const float* __restrict__ o, const float* __restrict__ d_o,
+                                                             const float* __restrict__ lse, float* __restrict__ ws, int B, int N, int H) {
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;          // 16 lanes per (b, n, head) row of 64 floats
+    const long total = (long)B * N * H * 16;
+    float acc = 0.f;
+    const bool ok = gid < total;
+    if (ok) {
+        const f32x4 a = *(const f32x4*)(o + gid * 4), g = *(const f32x4*)(d_o + gid * 4);
+        acc = a[0] * g[0] + a[1] * g[1] + a[2] * g[2] + a[3] * g[3];
+    }
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    acc += __shfl_xor(acc, 4, 64);
+    acc += __shfl_xor(acc, 8, 64);
+    if (ok && (threadIdx.x & 15) == 0) {
+        const long row = gid >> 4;                                  // (b*N + n)*H + head
+        const int head = (int)(row % H);
+        const long bn = row / H;
+        const int n = (int)(bn % N), b = (int)(bn / N);
+        const long i = ((long)b * H + head) * N + n;
+        ws[i] = -acc;
+        ws[(long)B * H * N + i] = -lse[i] * 1.44269504088896341f;
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void attn_bwd_f32_kernel(const float* __restrict__ qkv, const float* __restrict__ d_o,
+                                                           const float* __restrict__ ws, float* __restrict__ dqkv, int B, int N, int H,
+                                                           float c2, float out_mul) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * 32768 + 2 * 512];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, c = lane & 31;
+    const int b = blockIdx.z, head = blockIdx.y, r0 = blockIdx.x * 128 + wave * 32;
+    const int Dm = H * 64, D3 = 3 * Dm;
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(qkv + (long)b * N * D3, (size_t)N * D3 * 4);
+    const __amdgpu_buffer_rsrc_t rsd = make_rsrc(d_o + (long)b * N * Dm, (size_t)N * Dm * 4);
+    const float* nd = ws + ((long)b * H + head) * N;                 // -delta
+    const float* nl = nd + (long)B * H * N;                          // -lse * log2(e)
+    const int srow = min(r0 + c, N - 1);
+    f32x4 xf[8], yf[8];
+#pragma unroll
+    for (int s8 = 0; s8 < 8; ++s8) {
+        const unsigned col = (unsigned)(head * 64 + 8 * s8 + 4 * h);
+        if (MODE == 0) {
+            xf[s8] = __builtin_bit_cast(f32x4, buf_load16(rs, (unsigned)(((long)srow * D3 + col) * 4)));
+            yf[s8] = __builtin_bit_cast(f32x4, buf_load16(rsd, (unsigned)(((long)srow * Dm + col) * 4)));
+        } else {
+            xf[s8] = __builtin_bit_cast(f32x4, buf_load16(rs, (unsigned)(((long)srow * D3 + Dm + col) * 4)));
+            yf[s8] = __builtin_bit_cast(f32x4, buf_load16(rs, (unsigned)(((long)srow * D3 + 2 * Dm + col) * 4)));
+        }
+    }
+    const float cnl = nl[srow], cnd = nd[srow];                      // MODE 0: the stationary query's row constants
+    u32x4 r1[4], r2[4];
+    float rc = 0.f;
+    auto gload = [&](int t) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int idx = it * 256 + tid, row = t * 64 + (idx >> 4), ch = idx & 15;
+            if (MODE == 0) {
+                const unsigned off = row < N ? (unsigned)(((long)row * D3 + Dm + head * 64 + ch * 4) * 4) : HS_OOB_OFF;
+                r1[it] = buf_load16(rs, off);
+                r2[it] = buf_load16(rs, row < N ? off + Dm * 4 : HS_OOB_OFF);
+            } else {
+                r1[it] = buf_load16(rs, row < N ? (unsigned)(((long)row * D3 + head * 64 + ch * 4) * 4) : HS_OOB_OFF);
+                r2[it] = buf_load16(rsd, row < N ? (unsigned)(((long)row * Dm + head * 64 + ch * 4) * 4) : HS_OOB_OFF);
+            }
+        }
+        if (MODE == 1 && tid < 128) {
+            const int j = t * 64 + (tid & 63);
+            rc = j < N ? (tid < 64 ? nl[j] : nd[j]) : 0.f;
+        }
+    };
+    auto swrite = [&](int st) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int idx = it * 256 + tid, o_ = offF(idx >> 4, idx & 15);
+            *(u32x4*)(smem + st * 32768 + o_) = r1[it];
+            *(u32x4*)(smem + st * 32768 + 16384 + o_) = r2[it];
+        }
+        if (MODE == 1 && tid < 128) ((float*)(smem + 65536 + st * 512))[tid] = rc;
+    };
+    f32x16 acc0[2] = {zero16(), zero16()}, acc1[2] = {zero16(), zero16()};
+    const int nt = (N + 63) >> 6;
+    gload(0);
+    swrite(0);
+    __syncthreads();
+    int cur = 0;
+    for (int t = 0; t < nt; ++t) {
+        const bool more = t + 1 < nt;
+        if (more) gload(t + 1);
+        const char* T1 = smem + cur * 32768;
+        const char* T2 = T1 + 16384;
+        const float* cst = (const float*)(smem + 65536 + cur * 512);
+        f32x16 s[2] = {zero16(), zero16()}, dp[2] = {zero16(), zero16()};
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int s8 = 0; s8 < 8; ++s8) {
+                const f32x4 a1 = *(const f32x4*)(T1 + offF(kb * 32 + c, 2 * s8 + h));
+                const f32x4 a2 = *(const f32x4*)(T2 + offF(kb * 32 + c, 2 * s8 + h));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    s[kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], xf[s8][e], s[kb], 0, 0, 0);
+                    dp[kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[e], yf[s8][e], dp[kb], 0, 0, 0);
+                }
+            }
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int jl = kb * 32 + acc_row(r, h);                // streamed row inside the tile
+                const bool valid = t * 64 + jl < N;
+                const float l_ = MODE == 0 ? cnl : cst[jl], d_ = MODE == 0 ? cnd : cst[64 + jl];
+                const float p = valid ? exp2f(s[kb][r] * c2 + l_) : 0.f;
+                s[kb][r] = p;
+                dp[kb][r] = p * (dp[kb][r] + d_);
+            }
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = kb * 32 + acc_row(r, h);
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    const int d = db * 32 + c;
+                    const float a1 = *(const float*)(T1 + offF(row, d >> 2) + (d & 3) * 4);
+                    if (MODE == 0) {
+                        acc0[db] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, dp[kb][r], acc0[db], 0, 0, 0);      // dQ^T += K^T dS^T
+                    } else {
+                        const float a2 = *(const float*)(T2 + offF(row, d >> 2) + (d & 3) * 4);
+                        acc0[db] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, s[kb][r], acc0[db], 0, 0, 0);       // dV^T += dO^T P
+                        acc1[db] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, dp[kb][r], acc1[db], 0, 0, 0);      // dK^T += Q^T dS
+                    }
+                }
+            }
+        if (more) swrite(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+    const int srow_out = r0 + c;
+    if (srow_out < N) {
+        float* out = dqkv + ((long)b * N + srow_out) * D3 + head * 64;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                f32x4 v0, v1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v0[e] = acc0[db][4 * g4 + e]; v1[e] = acc1[db][4 * g4 + e] * out_mul; }
+                const int col = db * 32 + 8 * g4 + 4 * h;
+                if (MODE == 0) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v0[e] *= out_mul;
+                    *(f32x4*)(out + col) = v0;                           // dQ
+                } else {
+                    *(f32x4*)(out + 2 * Dm + col) = v0;                  // dV
+                    *(f32x4*)(out + Dm + col) = v1;                      // dK
+                }
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
 // backward, bf16
 // ------------------------------------------------------------------------------------------------------
 // ------------------------------------------------------------------------------------------------------
@@ -1056,10 +1230,25 @@ extern "C" int hs_attn_bwd(const void* qkv, const void* o, const void* d_o, cons
                            int B, int N, int H, int dh, int flags, void* stream) {
     if (!qkv || !o || !d_o || !lse || !dqkv || !delta_ws) return HS_ERR_ARG;
     if (dh != 64 || B < 1 || N < 1 || H < 1) return HS_ERR_SHAPE;
-    if (flags & ~HS_ATTN_Q_PRESCALED) return HS_ERR_ARG;
-    if ((size_t)N * 3 * H * 64 * 2 >= HS_MAX_RECORDS) return HS_ERR_SHAPE;
+    if (flags & ~(HS_ATTN_Q_PRESCALED | HS_ATTN_F32)) return HS_ERR_ARG;
     if (((uintptr_t)qkv | (uintptr_t)o | (uintptr_t)d_o | (uintptr_t)dqkv) & 15) return HS_ERR_SHAPE;
     const float scale = 0.125f, LOG2E = 1.44269504088896341f;
+    if (flags & HS_ATTN_F32) {           // parity mode: every tensor fp32, raw (unscaled) q
+        if (flags & HS_ATTN_Q_PRESCALED) return HS_ERR_ARG;
+        if ((size_t)N * 3 * H * 64 * 4 >= HS_MAX_RECORDS) return HS_ERR_SHAPE;
+        hipStream_t s = (hipStream_t)stream;
+        const long tot = (long)B * N * H * 16;
+        hipLaunchKernelGGL(attn_stats_f32_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, (const float*)o, (const float*)d_o,
+                           lse, delta_ws, B, N, H);
+        dim3 g((N + 127) / 128, H, B);
+        hipLaunchKernelGGL(attn_bwd_f32_kernel<1>, g, dim3(256), 0, s, (const float*)qkv, (const float*)d_o, delta_ws, (float*)dqkv, B, N, H,
+                           scale * LOG2E, scale);
+        hipLaunchKernelGGL(attn_bwd_f32_kernel<0>, g, dim3(256), 0, s, (const float*)qkv, (const float*)d_o, delta_ws, (float*)dqkv, B, N, H,
+                           scale * LOG2E, scale);
+        HS_CHECK_LAUNCH();
+        return HS_OK;
+    }
+    if ((size_t)N * 3 * H * 64 * 2 >= HS_MAX_RECORDS) return HS_ERR_SHAPE;
     const bool pre = (flags & HS_ATTN_Q_PRESCALED) != 0;
     const float c2 = pre ? 1.0f : scale * LOG2E;
     const float dk_mul = pre ? 1.0f / LOG2E : scale;        // dK = dh^-0.5 dS^T q = dS^T q' / log2(e)

@@ -30,9 +30,10 @@ inline int gemm(int prec, int layout, const void* A, const void* Bm, int M, int 
 
 // split-K factor for a wgrad whose output has ceil(Mo/256)*ceil(No/128) tiles and K reduction rows: pick the split
 // that minimises (rounds over 256 CUs) x (K-tiles per block + a fixed per-block cost ~ the atomic epilogue).
-inline int wgrad_split(int Mo, int No, int K) {
-    const int tiles = ((Mo + 255) / 256) * ((No + 127) / 128);
-    const int kt = (K + 63) / 64;
+inline int wgrad_split(int Mo, int No, int K, int prec = HS_PREC_BF16) {
+    const bool bf = prec == HS_PREC_BF16;                       // exact-f32 GEMM: 64x64 tiles, 32-row K-tiles
+    const int tiles = bf ? ((Mo + 255) / 256) * ((No + 127) / 128) : ((Mo + 63) / 64) * ((No + 63) / 64);
+    const int kt = bf ? (K + 63) / 64 : (K + 31) / 32;
     int best = 1;
     long best_cost = -1;
     for (int s = 1; s <= 32 && s <= kt; ++s) {

@@ -42,13 +42,13 @@ Layout make_layout(const hs_vit_desc& c) {
     L.a = take(Ls * M * mlp * es);
     L.stats = take(Ls * 4 * M * 4);
     L.fstats = take(2 * M * 4);
-    const bool bwd = c.save_for_bwd && c.prec == HS_PREC_BF16;
+    const bool bwd = c.save_for_bwd != 0;
     L.dx = take(bwd ? M * d * 4 : 0);
-    L.dh = take(bwd ? M * d * 2 : 0);      // dgrad outputs feeding LN backward: bf16 (autocast's Linear backward dtype)
-    L.dxb = take(bwd ? M * d * 2 : 0);
-    L.dob = take(bwd ? M * d * 2 : 0);
-    L.dz = take(bwd ? M * mlp * 2 : 0);
-    L.dqkv = take(bwd ? M * 3 * d * 2 : 0);
+    L.dh = take(bwd ? M * d * es : 0);     // dgrad outputs feeding LN backward: bf16 (autocast's Linear backward dtype) / f32 in parity mode
+    L.dxb = take(bwd && c.prec == HS_PREC_BF16 ? M * d * 2 : 0);     // bf16 copy of the residual-stream gradient (GEMM operand)
+    L.dob = take(bwd ? M * d * es : 0);
+    L.dz = take(bwd ? M * mlp * es : 0);
+    L.dqkv = take(bwd ? M * 3 * d * es : 0);
     L.delta = take(bwd ? (size_t)c.B * c.H * c.N * 4 * 2 : 0);   // hs_attn_bwd scratch: -delta | -lse*log2e
     L.qb = take(c.qkv_bias ? (size_t)3 * d * 4 : 0);               // one layer's qkv bias with its q third pre-scaled
     L.total = off;
@@ -159,7 +159,7 @@ extern "C" int hs_vit_blocks_bwd(const hs_vit_desc* desc, const float* x0, const
                                  size_t ws_bytes, int l_hi, int l_lo, void* stream) {
     RC(check_desc(desc));
     const hs_vit_desc& c = *desc;
-    if (c.prec != HS_PREC_BF16 || !c.save_for_bwd || c.qkv_bias) return HS_ERR_ARG;
+    if (!c.save_for_bwd || c.qkv_bias) return HS_ERR_ARG;
     if (!x0 || !lp || !np || !lg || !hidden || !ws) return HS_ERR_ARG;
     if (l_lo < 0 || l_hi > c.L || l_lo >= l_hi) return HS_ERR_SHAPE;
     if (l_hi == c.L && (!dy || !ng)) return HS_ERR_ARG;
@@ -169,14 +169,22 @@ extern "C" int hs_vit_blocks_bwd(const hs_vit_desc* desc, const float* x0, const
     char* w = (char*)ws;
     const int M = c.B * c.N, d = c.d, mlp = c.mlp;
     const size_t Md = (size_t)M * d;
+    // bf16 (the reference's autocast policy): GEMM operands / dgrad outputs bf16, residual-stream gradient fp32 + a bf16 copy.
+    // f32 (parity mode): everything fp32, exact-f32 MFMA GEMMs and attention -- the same sequence, no bf16 copy, bias gradient of
+    // fc1 by a separate column-sum pass (the fused one lives in the bf16 GEMM epilogue).
+    const bool bf = c.prec == HS_PREC_BF16;
+    const size_t es = bf ? 2 : 4;
+    const int P = c.prec;
     float* dx = (float*)(w + L.dx);
-    bf16_t* dh = (bf16_t*)(w + L.dh);
-    bf16_t* dxb = (bf16_t*)(w + L.dxb);
-    bf16_t* dob = (bf16_t*)(w + L.dob);
-    bf16_t* dz = (bf16_t*)(w + L.dz);
-    bf16_t* dqkv = (bf16_t*)(w + L.dqkv);
+    char* dh = w + L.dh;
+    bf16_t* dxb = bf ? (bf16_t*)(w + L.dxb) : nullptr;
+    char* dob = w + L.dob;
+    char* dz = w + L.dz;
+    char* dqkv = w + L.dqkv;
     float* delta = (float*)(w + L.delta);
-    const int P = HS_PREC_BF16;
+    const void* dxop = bf ? (const void*)dxb : (const void*)dx;       // the residual-stream gradient as a GEMM operand
+    auto f32o = [&](char* p) { return bf ? nullptr : (float*)p; };
+    auto bfo = [&](char* p) { return bf ? (void*)p : nullptr; };
 
     if (l_hi == c.L) {
         const float* fs = (const float*)(w + L.fstats);
@@ -189,37 +197,43 @@ extern "C" int hs_vit_blocks_bwd(const hs_vit_desc* desc, const float* x0, const
         float* const* g = lg + (size_t)l * P_COUNT;
         const float* xin = l == 0 ? x0 : hidden + (size_t)(l - 1) * Md;
         const float* xmid = (const float*)(w + L.xmid) + (size_t)l * Md;
-        const bf16_t* h1 = (const bf16_t*)(w + L.h1) + (size_t)l * Md;
-        const bf16_t* h2 = (const bf16_t*)(w + L.h2) + (size_t)l * Md;
-        const bf16_t* qkv = (const bf16_t*)(w + L.qkv) + (size_t)l * Md * 3;
-        const bf16_t* o = (const bf16_t*)(w + L.o) + (size_t)l * Md;
+        const char* h1 = w + L.h1 + (size_t)l * Md * es;
+        const char* h2 = w + L.h2 + (size_t)l * Md * es;
+        const char* qkv = w + L.qkv + (size_t)l * Md * 3 * es;
+        const char* o = w + L.o + (size_t)l * Md * es;
         const float* lse = (const float*)(w + L.lse) + (size_t)l * c.B * c.H * c.N;
-        const bf16_t* z = (const bf16_t*)(w + L.z) + (size_t)l * M * mlp;
-        const bf16_t* a = (const bf16_t*)(w + L.a) + (size_t)l * M * mlp;
+        const char* z = w + L.z + (size_t)l * M * mlp * es;
+        const char* a = w + L.a + (size_t)l * M * mlp * es;
         const float* st = (const float*)(w + L.stats) + (size_t)l * 4 * M;
-        const bf16_t* wl = (const bf16_t*)(w + L.wbf) + (size_t)l * L.per_w;
-        const bf16_t *wqkv = wl, *wo = wl + 3 * d * d, *w1 = wl + 4 * d * d, *w2 = wl + 4 * d * d + (size_t)mlp * d;
+        const void *wqkv, *wo, *w1, *w2;
+        if (bf) {
+            const bf16_t* wl = (const bf16_t*)(w + L.wbf) + (size_t)l * L.per_w;
+            wqkv = wl; wo = wl + 3 * d * d; w1 = wl + 4 * d * d; w2 = wl + 4 * d * d + (size_t)mlp * d;
+        } else {
+            wqkv = p[P_WQKV]; wo = p[P_WO]; w1 = p[P_W1]; w2 = p[P_W2];
+        }
 
         // ---- MLP branch: x' = xm + W2 gelu(W1 h2 + b1) + b2        (db2 came with the dx that entered this layer)
-        RC(gemm(P, HS_GEMM_TN, dxb, a, d, mlp, M, d, mlp, g[P_W2], nullptr, mlp, nullptr, nullptr, nullptr, nullptr, HS_EPI_ATOMIC,
-                wgrad_split(d, mlp, M), stream));
-        RC(gemm(P, HS_GEMM_NN, dxb, w2, M, mlp, d, d, mlp, nullptr, dz, mlp, nullptr, nullptr, z, nullptr,
-                HS_EPI_GELU_BWD | HS_EPI_SAVE_DGELU, 1, stream, g[P_B1]));                 // db1 = colsum(dz), fused
+        RC(gemm(P, HS_GEMM_TN, dxop, a, d, mlp, M, d, mlp, g[P_W2], nullptr, mlp, nullptr, nullptr, nullptr, nullptr, HS_EPI_ATOMIC,
+                wgrad_split(d, mlp, M, P), stream));
+        RC(gemm(P, HS_GEMM_NN, dxop, w2, M, mlp, d, d, mlp, f32o(dz), bfo(dz), mlp, nullptr, nullptr, z, nullptr,
+                HS_EPI_GELU_BWD | HS_EPI_SAVE_DGELU, 1, stream, bf ? g[P_B1] : nullptr));  // db1 = colsum(dz), fused in the bf16 epilogue
+        if (!bf) RC(hs_colsum(dz, 0, g[P_B1], M, mlp, mlp, stream));
         RC(gemm(P, HS_GEMM_TN, dz, h2, mlp, d, M, mlp, d, g[P_W1], nullptr, d, nullptr, nullptr, nullptr, nullptr, HS_EPI_ATOMIC,
-                wgrad_split(mlp, d, M), stream));
-        RC(gemm(P, HS_GEMM_NN, dz, w1, M, d, mlp, mlp, d, nullptr, dh, d, nullptr, nullptr, nullptr, nullptr, 0, 1, stream));
-        RC(hs_layernorm_bwd(dh, 1, xmid, nullptr, p[P_N2W], st + 2 * M, st + 3 * M, dx, dx, dxb, g[P_N2W], g[P_N2B], g[P_BO], M, d, stream));
+                wgrad_split(mlp, d, M, P), stream));
+        RC(gemm(P, HS_GEMM_NN, dz, w1, M, d, mlp, mlp, d, f32o(dh), bfo(dh), d, nullptr, nullptr, nullptr, nullptr, 0, 1, stream));
+        RC(hs_layernorm_bwd(dh, bf ? 1 : 0, xmid, nullptr, p[P_N2W], st + 2 * M, st + 3 * M, dx, dx, dxb, g[P_N2W], g[P_N2B], g[P_BO], M, d, stream));
         // ---- attention branch: xm = x + Wo attn(LN1 x) + bo         (dbo came from the LN2 backward just above)
-        RC(gemm(P, HS_GEMM_TN, dxb, o, d, d, M, d, d, g[P_WO], nullptr, d, nullptr, nullptr, nullptr, nullptr, HS_EPI_ATOMIC,
-                wgrad_split(d, d, M), stream));
-        RC(gemm(P, HS_GEMM_NN, dxb, wo, M, d, d, d, d, nullptr, dob, d, nullptr, nullptr, nullptr, nullptr, 0, 1, stream));
-        RC(hs_attn_bwd(qkv, o, dob, lse, dqkv, delta, c.B, c.N, c.H, 64, HS_ATTN_Q_PRESCALED, stream));
+        RC(gemm(P, HS_GEMM_TN, dxop, o, d, d, M, d, d, g[P_WO], nullptr, d, nullptr, nullptr, nullptr, nullptr, HS_EPI_ATOMIC,
+                wgrad_split(d, d, M, P), stream));
+        RC(gemm(P, HS_GEMM_NN, dxop, wo, M, d, d, d, d, f32o(dob), bfo(dob), d, nullptr, nullptr, nullptr, nullptr, 0, 1, stream));
+        RC(hs_attn_bwd(qkv, o, dob, lse, dqkv, delta, c.B, c.N, c.H, 64, bf ? HS_ATTN_Q_PRESCALED : HS_ATTN_F32, stream));
         RC(gemm(P, HS_GEMM_TN, dqkv, h1, 3 * d, d, M, 3 * d, d, g[P_WQKV], nullptr, d, nullptr, nullptr, nullptr, nullptr, HS_EPI_ATOMIC,
-                wgrad_split(3 * d, d, M), stream));
-        RC(gemm(P, HS_GEMM_NN, dqkv, wqkv, M, d, 3 * d, 3 * d, d, nullptr, dh, d, nullptr, nullptr, nullptr, nullptr, 0, 1, stream));
+                wgrad_split(3 * d, d, M, P), stream));
+        RC(gemm(P, HS_GEMM_NN, dqkv, wqkv, M, d, 3 * d, 3 * d, d, f32o(dh), bfo(dh), d, nullptr, nullptr, nullptr, nullptr, 0, 1, stream));
         float* dxo = (l == 0) ? dx0 : dx;
         float* b2_below = (l == 0) ? nullptr : lg[(size_t)(l - 1) * P_COUNT + P_B2];
-        RC(hs_layernorm_bwd(dh, 1, xin, nullptr, p[P_N1W], st, st + M, dx, dxo, l == 0 ? nullptr : dxb, g[P_N1W], g[P_N1B], b2_below, M, d, stream));
+        RC(hs_layernorm_bwd(dh, bf ? 1 : 0, xin, nullptr, p[P_N1W], st, st + M, dx, dxo, l == 0 ? nullptr : dxb, g[P_N1W], g[P_N1B], b2_below, M, d, stream));
     }
     return HS_OK;
 }

@@ -18,7 +18,7 @@ _default_precision = "bf16"
 
 def set_precision(p: str) -> None:
     """'bf16' (default; the reference's autocast policy: bf16 MFMA inputs, fp32 accumulate/residual) or
-    'f32' (exact-f32 MFMA parity mode, forward-only for the block stack)."""
+    'f32' (exact-f32 MFMA parity mode: forward and backward, no bf16 rounding anywhere)."""
     global _default_precision
     if p not in _PREC:
         raise ValueError(f"precision must be one of {list(_PREC)}")
@@ -132,12 +132,16 @@ def attn_fwd(qkv: torch.Tensor, H: int, prec: int, q_prescaled: bool = False):
 
 
 def attn_bwd(qkv, o, d_o, lse, H: int, q_prescaled: bool = False):
+    """dqkv from (qkv, o, dO, lse): bf16 tensors, or fp32 ones (exact-f32 parity mode, raw q)."""
     _need(qkv, o, d_o, lse)
     B, N, _ = qkv.shape
+    if not (qkv.dtype == o.dtype == d_o.dtype) or qkv.dtype not in (torch.bfloat16, torch.float32):
+        raise L.HsError("attn_bwd: qkv, o, dO must all be bf16 or all fp32")
+    flags = (L.ATTN_Q_PRESCALED if q_prescaled else 0) | (L.ATTN_F32 if qkv.dtype == torch.float32 else 0)
     dqkv = torch.empty_like(qkv)
     delta = torch.empty(2, B, H, N, dtype=torch.float32, device=qkv.device)   # row constants -delta | -lse*log2e
     L.call("hs_attn_bwd", qkv.data_ptr(), o.data_ptr(), d_o.data_ptr(), lse.data_ptr(), dqkv.data_ptr(), delta.data_ptr(),
-           B, N, H, 64, L.ATTN_Q_PRESCALED if q_prescaled else 0, _s())
+           B, N, H, 64, flags, _s())
     return dqkv
 
 
@@ -536,8 +540,6 @@ class BlocksFn(torch.autograd.Function):
         Ln = (len(params) - 2) // 11
         # need_grad is decided by the caller (grad mode is off inside Function.forward, and
         # ctx.needs_input_grad ignores torch.no_grad())
-        if need_grad and prec != L.PREC_BF16:
-            raise L.HsError("the fused block stack differentiates in bf16 mode only (f32 is the forward parity mode)")
         desc = L.VitDesc(B, N, d, H, mlp, Ln, prec, int(need_grad), 0.0, None)
         nbytes = L.load().hs_vit_workspace_bytes(C.byref(desc))
         if nbytes == 0:

@@ -114,9 +114,10 @@ int hs_layernorm_bwd(const void* dy, int dy_is_bf16, const float* x, const float
  * that way, one rounding); without it the bf16 kernels apply that factor to their register fragments (a second
  * bf16 rounding of q).  o, lse and dqkv mean the same either way (dqkv is the gradient of the UNSCALED q, k, v). */
 #define HS_ATTN_Q_PRESCALED 1
+#define HS_ATTN_F32 2          /* hs_attn_bwd only: qkv, o, d_o, dqkv are fp32 (exact-f32 MFMA parity mode; raw q) */
 int hs_attn_fwd(const void* qkv, void* o, float* lse, int B, int N, int H, int dh, int prec, int flags, void* stream);
 /* dqkv from (qkv, o, do, lse); delta_ws: fp32 scratch 2 x [B][H][N] (row constants -sum(dO*O) and -lse*log2(e)).
- * bf16 only. */
+ * bf16 tensors, or fp32 ones with HS_ATTN_F32 (parity mode: the same two sweeps on v_mfma_f32_32x32x2_f32, no rounding). */
 int hs_attn_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv, float* delta_ws,
                 int B, int N, int H, int dh, int flags, void* stream);
 
@@ -224,7 +225,7 @@ typedef struct hs_vit_desc {
 size_t hs_vit_workspace_bytes(const hs_vit_desc* desc);
 int hs_vit_blocks_fwd(const hs_vit_desc* desc, const float* x0, const float* const* layer_params,
                       const float* const* norm_params, float* y, float* hidden, void* ws, size_t ws_bytes, void* stream);
-/* backward of the above (bf16 mode, save_for_bwd=1 forward must have run on the same ws).
+/* backward of the above (either precision; the save_for_bwd=1 forward must have run on the same ws).
  * dy: [B][N][d] fp32.  dx0: [B][N][d] fp32 out.  layer_grads / norm_grads: same order as the params; written
  * (weights) or accumulated atomically (biases, LN): the caller zeroes all gradient buffers before the call.
  * Layers are processed from l_hi-1 down to l_lo (inclusive), so a caller can interleave gradient all-reduce

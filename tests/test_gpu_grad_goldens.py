@@ -29,6 +29,9 @@ class Cfg:
         self.image_size, self.patch_size = img, patch
 
 
+TOL_F32 = 1e-3          # north_star: within 1e-3 of the reference (the f32 parity mode lands at ~1e-5)
+
+
 def check_grads(named_mine, g, what, tol=TOL):
     names, norms = [str(n) for n in g["grad_names"]], g["grad_norms"]
     mine = {n: p.grad.detach().double().cpu() for n, p in named_mine}
@@ -57,10 +60,10 @@ def check_grads(named_mine, g, what, tol=TOL):
         den = max(float(ref.norm()), floor, 1e-4 * big * (ref.numel() / gm.numel()) ** 0.5)
         e = float((got - ref).norm()) / den
         n_vals += 1
-        if rn < 1e-2 * big:
+        if rn < 1e-2 * big and tol >= TOL:
             assert e < TOL_SMALL_SIGNAL, (what, n, e, "small-signal tensor")
             continue
-        if rk in g.files:
+        if rk in g.files and tol >= TOL:
             e /= 1.5          # three stored rows of a large matrix: a SAMPLE of the tensor's error (its norm is checked in full above)
         if e > worst_val[1]:
             worst_val = (n, e)
@@ -150,3 +153,43 @@ def test_vit256_stage1_vs_reference_gradients(dev, golden, path):
         (y * w).sum().backward()
     torch.cuda.synchronize()
     check_grads(list(m.named_parameters()), g, f"ViT_stage1 256^3 ({path})")
+
+
+def test_f32_parity_mode_gradients_native_dual(dev, golden):
+    """exact-f32 mode (set_precision('f32'): f32 MFMA GEMMs, f32 attention forward AND backward, no bf16 anywhere) through the
+    module API at the reference-native geometry: every gradient within north_star's 1e-3 of the reference's own autograd --
+    which shows that the bf16 mode's 1e-2-level gradient differences are the autocast policy's rounding, not an algorithmic one."""
+    import hsenet_amd as H
+    g = golden("grad_native_dual.npz")
+    tower, p1, p2, x, s, w = _dual_modules(g, dev)
+    H.set_precision("f32")
+    try:
+        out = H.encode_images(tower, p1, p2, x, s)
+        rows = [int(r) for r in g["out_rows_idx"]]
+        assert _rel(out[:, rows], g["out_rows"]) < 1e-5
+        (out * w).sum().backward()
+        torch.cuda.synchronize()
+    finally:
+        H.set_precision("bf16")
+    check_grads(_named(tower, p1, p2), g, "f32 parity mode, native dual", tol=TOL_F32)
+
+
+def test_f32_parity_mode_gradients_vit256(dev, golden):
+    """the same at BASELINE's 256^3 (N = 4097, 12 layers): ViT_stage1 forward + backward in exact f32 vs the reference's gradients."""
+    import hsenet_amd as H
+    from oracle import ref_cpu as R
+    g = golden("grad_vit256_stage1.npz")
+    img, patch = (256,) * 3, (16,) * 3
+    m = H.ViT_stage1(in_channels=1, img_size=img, patch_size=patch, pos_embed="perceptron", classification=True).eval()
+    m.load_state_dict(R.seeded_state_dict(m, int(g["seed_w"])))
+    m.to(dev)
+    x = R.synthetic_volume((1, 1) + img, int(g["seed_x"])).to(dev)
+    w = torch.from_numpy(np.random.default_rng(int(g["seed_dy"])).standard_normal((1, 4097, 768), dtype=np.float32)).to(dev)
+    H.set_precision("f32")
+    try:
+        y, _ = m(x)
+        (y * w).sum().backward()
+        torch.cuda.synchronize()
+    finally:
+        H.set_precision("bf16")
+    check_grads(list(m.named_parameters()), g, "f32 parity mode, ViT_stage1 256^3", tol=TOL_F32)

@@ -201,6 +201,29 @@ def test_attn_bwd(dev, N):
         assert e < 1.5e-2, (name, e)
 
 
+@pytest.mark.parametrize("N", [1, 9, 64, 65, 200, 513, 2049])
+def test_attn_bwd_f32(dev, N):
+    """the exact-f32 backward (parity mode: v_mfma_f32_32x32x2_f32, no bf16 rounding) vs fp64 autograd: 1e-5."""
+    from hsenet_amd import functional as Fn, _lib as L
+    B, H = 2, 3
+    qkv = rnd((B, N, 3 * H * 64), 70 + N, dev, 1.2)
+    d_o = rnd((B, N, H * 64), 71 + N, dev)
+    o, lse = Fn.attn_fwd(qkv, H, L.PREC_F32)
+    dqkv = Fn.attn_bwd(qkv, o, d_o, lse, H)
+    assert dqkv.dtype == torch.float32
+    x = qkv.double().requires_grad_()
+    ro, _ = sdpa_ref(x, H)
+    (g,) = torch.autograd.grad((ro * d_o.double()).sum(), x)
+    D = H * 64
+    gn = float(g.norm())
+    for name, sl in (("dq", slice(0, D)), ("dk", slice(D, 2 * D)), ("dv", slice(2 * D, 3 * D))):
+        # (at N = 1 the softmax is constant: dq = dk = 0 exactly, so the error is taken relative to the whole gradient there)
+        e = float((dqkv[..., sl].double() - g[..., sl]).norm()) / max(float(g[..., sl].norm()), 1e-3 * gn)
+        assert e < 1e-5, (name, N, e)
+    with pytest.raises(L.HsError):
+        Fn.attn_bwd(qkv, o.bfloat16(), d_o, lse, H)              # mixed dtypes are refused
+
+
 @pytest.mark.parametrize("N", [2049, 4097])
 def test_attn_bwd_full_length_vs_fp64(dev, N):
     """the sequence lengths the encoders actually run (native 2049, 256^3 4097) against an fp64 statement of SABlock's core:
