@@ -155,12 +155,14 @@ def test_vit256_stage1_vs_reference_gradients(dev, golden, path):
     check_grads(list(m.named_parameters()), g, f"ViT_stage1 256^3 ({path})")
 
 
-def test_f32_parity_mode_gradients_native_dual(dev, golden):
+@pytest.mark.parametrize("name", ["grad_native_dual.npz", "grad_dual256.npz"])
+def test_f32_parity_mode_gradients_dual(dev, golden, name):
     """exact-f32 mode (set_precision('f32'): f32 MFMA GEMMs, f32 attention forward AND backward, no bf16 anywhere) through the
-    module API at the reference-native geometry: every gradient within north_star's 1e-3 of the reference's own autograd --
+    module API at the reference-native geometry and at BASELINE configs[2] (256^3): every gradient within north_star's 1e-3 of the
+    reference's own autograd --
     which shows that the bf16 mode's 1e-2-level gradient differences are the autocast policy's rounding, not an algorithmic one."""
     import hsenet_amd as H
-    g = golden("grad_native_dual.npz")
+    g = golden(name)
     tower, p1, p2, x, s, w = _dual_modules(g, dev)
     H.set_precision("f32")
     try:
@@ -171,7 +173,7 @@ def test_f32_parity_mode_gradients_native_dual(dev, golden):
         torch.cuda.synchronize()
     finally:
         H.set_precision("bf16")
-    check_grads(_named(tower, p1, p2), g, "f32 parity mode, native dual", tol=TOL_F32)
+    check_grads(_named(tower, p1, p2), g, f"f32 parity mode, {name}", tol=TOL_F32)
 
 
 def test_f32_parity_mode_gradients_vit256(dev, golden):

@@ -217,8 +217,9 @@ def test_attn_bwd_f32(dev, N):
     D = H * 64
     gn = float(g.norm())
     for name, sl in (("dq", slice(0, D)), ("dk", slice(D, 2 * D)), ("dv", slice(2 * D, 3 * D))):
-        # (at N = 1 the softmax is constant: dq = dk = 0 exactly, so the error is taken relative to the whole gradient there)
-        e = float((dqkv[..., sl].double() - g[..., sl]).norm()) / max(float(g[..., sl].norm()), 1e-3 * gn)
+        # (at N = 1 the softmax is constant: dq = dk = 0 exactly and ours is fp32 cancellation noise, ~1e-7 of the gradient's
+        # norm; the error is therefore taken relative to at least 5 % of the whole gradient)
+        e = float((dqkv[..., sl].double() - g[..., sl]).norm()) / max(float(g[..., sl].norm()), 5e-2 * gn)
         assert e < 1e-5, (name, N, e)
     with pytest.raises(L.HsError):
         Fn.attn_bwd(qkv, o.bfloat16(), d_o, lse, H)              # mixed dtypes are refused
