@@ -17,8 +17,9 @@ import torch.distributed as dist
 
 
 class GradBuckets:
-    def __init__(self, flat_grad: torch.Tensor, bounds: Sequence[Tuple[int, int]], group=None):
-        """bounds: [(start, end)] element ranges of ``flat_grad`` in the order the backward pass completes them."""
+    def __init__(self, flat_grad: torch.Tensor, bounds: Sequence[Tuple[int, int]], group=None, always: bool = False):
+        """bounds: [(start, end)] element ranges of ``flat_grad`` in the order the backward pass completes them.
+        always: launch the collectives even at world size 1 (tests: exercises the backend's asynchronous path on one GPU)."""
         self.flat = flat_grad
         self.bounds = [(int(a), int(b)) for a, b in bounds]
         for a, b in self.bounds:
@@ -26,6 +27,7 @@ class GradBuckets:
                 raise ValueError(f"bucket ({a},{b}) outside the flat gradient of {flat_grad.numel()} elements")
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.always = always and dist.is_available() and dist.is_initialized()
         self._pending: List = []
 
     @property
@@ -35,7 +37,7 @@ class GradBuckets:
 
     def reduce(self, i: int) -> None:
         """launch the all-reduce of bucket i (no-op at world size 1)."""
-        if self.world == 1:
+        if self.world == 1 and not self.always:
             return
         a, b = self.bounds[i]
         self._pending.append(dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
