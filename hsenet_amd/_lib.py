@@ -61,6 +61,7 @@ SIGNATURES = {
     "hs_version": [],
     "hs_device_check": [_i],
     "hs_gemm": [C.POINTER(GemmArgs), _i, _vp],
+    "hs_gemm_group": [C.POINTER(GemmArgs), _i, _vp],
     "hs_patchify": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "hs_assemble_tokens": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "hs_assemble_tokens_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],

@@ -44,6 +44,23 @@ inline int wgrad_split(int Mo, int No, int K, int prec = HS_PREC_BF16) {
     return best;
 }
 
+// common split-K factor of a GROUP of bf16 wgrads (hs_gemm_group) with output shapes mn[i] = {Mo, No} and K reduction rows: the
+// same cost model over the group's total tile count -- at one volume per GPU (K = 4097 rows, 216 tiles for a ViT-B layer) that is
+// ONE round of unsplit tiles instead of four launches of 5-22 K-tiles each behind an atomic epilogue.
+inline int wgrad_group_split(const int (*mn)[2], int count, int K) {
+    long tiles = 0;
+    for (int i = 0; i < count; ++i) tiles += (long)((mn[i][0] + 255) / 256) * ((mn[i][1] + 127) / 128);
+    const int kt = (K + 63) / 64;
+    int best = 1;
+    long best_cost = -1;
+    for (int s = 1; s <= 32 && s <= kt; ++s) {
+        const long rounds = (tiles * s + 255) / 256;
+        const long cost = rounds * ((kt + s - 1) / s + 16);
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = s; }
+    }
+    return best;
+}
+
 // dW[No_rows = n_out][n_in] += dY^T X   (dY bf16 [rows][ldy] columns [0, n_out), X bf16 [rows][ldx]); dW zeroed by the caller
 inline int wgrad(const void* dy, long ldy, const void* x, long ldx, float* dw, int n_out, int n_in, int rows, void* s) {
     return gemm(HS_PREC_BF16, HS_GEMM_TN, dy, x, n_out, n_in, rows, ldy, ldx, dw, nullptr, n_in, nullptr, nullptr, nullptr, nullptr,

@@ -670,8 +670,9 @@ static_assert(EF >= 0, "the 16x16x32 kernels are launched with compile-time epil
 // EF >= 0: the epilogue flags as a compile-time constant (the launcher checked p.flags == EF and the 8-column
 // conditions): the flag tests fold away.  Run-time flags (EF = -1) cost ~1500 cycles of branches per epilogue step --
 // 24k cycles per 256x256 tile, more than half of a K = 768 main loop.
+// (the body is shared by the one-problem kernel and the grouped one: b = this block's index among the nb blocks of problem p)
 template <bool ATR, bool BTR, bool BIG, int EF, bool M16 = false>
-__global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmP p) {
+__device__ __forceinline__ void gemm_bf16_body(const GemmP& p, const int b_, const int nb_) {
     static_assert(!M16 || (BIG && !ATR && !BTR), "the 16x16x32 main loop exists for the 256x256 NT tile");
     typedef GCfg<BIG> C;
     __shared__ __attribute__((aligned(16))) char smem[C::SMEM];
@@ -686,7 +687,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmP p) {
     // (blocks of one slice share A and B, different slices share nothing), and inside a slice groups of GM row tiles x
     // all column tiles, column-major inside a group (GM small: see hs_gemm).  Placement only affects speed, never results.
     int tm, tn, z;
-    tile_order(blockIdx.x, gridDim.x, p.tiles_m, p.tiles_n, tm, tn, z, p.gm);
+    tile_order(b_, nb_, p.tiles_m, p.tiles_n, tm, tn, z, p.gm);
     const int m0 = tm * 256, n0 = tn * C::BN;
     const int bz = p.split_k > 1 ? 0 : z;
     const bf16_t* A = (const bf16_t*)p.A + bz * p.sA;
@@ -976,6 +977,28 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmP p) {
     TRACE(2);
 }
 
+template <bool ATR, bool BTR, bool BIG, int EF, bool M16 = false>
+__global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmP p) {
+    gemm_bf16_body<ATR, BTR, BIG, EF, M16>(p, blockIdx.x, gridDim.x);
+}
+
+// Grouped launch: up to HS_GEMM_GROUP_MAX problems of one kernel variant in ONE grid (hs_gemm_group: the four weight-gradient
+// GEMMs of a transformer layer).  Problem i owns blocks [first[i], first[i+1]); every range starts at a multiple of 8 so that
+// (local block index) % 8 is still the XCD the block runs on, which is what tile_order builds on.
+struct GemmGroup {
+    GemmP p[HS_GEMM_GROUP_MAX];
+    int first[HS_GEMM_GROUP_MAX + 1];
+    int count;
+};
+template <bool ATR, bool BTR, bool BIG, int EF>
+__global__ __launch_bounds__(512) void gemm_bf16_group_kernel(GemmGroup g) {
+    int i = 0;
+    while (i + 1 < g.count && (int)blockIdx.x >= g.first[i + 1]) ++i;
+    const int b = (int)blockIdx.x - g.first[i];
+    if (b >= g.p[i].nblocks) return;                                    // padding up to the next multiple of 8
+    gemm_bf16_body<ATR, BTR, BIG, EF>(g.p[i], b, g.p[i].nblocks);
+}
+
 // ------------------------------------------------------------------------------------------------------
 // f32 (parity mode): 64x64x32 tile, 4 waves each one 32x32 block; k order inside a group of 8 is permuted
 // identically for A and B (lane half h takes k = 8s+4h+e for MFMA step e), which leaves the sum unchanged.
@@ -1096,6 +1119,42 @@ struct GemmEnv {
 };
 const GemmEnv kEnv;
 }  // namespace
+
+extern "C" int hs_gemm_group(const hs_gemm_args* args, int count, void* stream) {
+    if (!args || count < 1 || count > HS_GEMM_GROUP_MAX) return HS_ERR_ARG;
+    GemmGroup g = {};
+    double flops = 0, bytes = 0;
+    int nblocks = 0;
+    for (int i = 0; i < count; ++i) {
+        const hs_gemm_args* a = args + i;
+        if (!a->A || !a->B || !a->out_f32 || a->out_bf16) return HS_ERR_ARG;
+        if (a->layout != HS_GEMM_TN || a->flags != HS_EPI_ATOMIC || a->batch != 1 || a->split_k < 1) return HS_ERR_ARG;
+        if (a->M <= 0 || a->N <= 0 || a->K <= 0 || a->scale_cols || a->colsum_out) return HS_ERR_SHAPE;
+        if ((a->M & 7) || (a->N & 7) || (a->lda & 7) || (a->ldb & 7)) return HS_ERR_SHAPE;
+        if (((uintptr_t)a->A | (uintptr_t)a->B) & 15) return HS_ERR_SHAPE;
+        if ((size_t)a->K * a->lda * 2 >= HS_MAX_RECORDS || (size_t)a->K * a->ldb * 2 >= HS_MAX_RECORDS) return HS_ERR_SHAPE;
+        GemmP& p = g.p[i];
+        p.A = a->A; p.B = a->B; p.M = a->M; p.N = a->N; p.K = a->K;
+        p.lda = a->lda; p.ldb = a->ldb; p.sA = 0; p.sB = 0; p.sC = 0; p.ldc = a->ldc;
+        p.out_f32 = a->out_f32; p.out_bf16 = nullptr; p.bias = nullptr; p.resid = nullptr; p.aux = nullptr; p.aux_out = nullptr;
+        p.colsum = nullptr; p.alpha = a->alpha; p.flags = a->flags; p.split_k = a->split_k;
+        p.scale_cols = 0; p.scale_alpha = 1.0f; p.nt = 0; p.dbg = 0;
+        p.tiles_m = (a->M + 255) / 256;
+        p.tiles_n = (a->N + 127) / 128;
+        p.gm = kEnv.gm > 0 ? kEnv.gm : (p.tiles_n >= 8 ? 4 : 2);
+        p.nblocks = p.tiles_m * p.tiles_n * a->split_k;
+        g.first[i] = nblocks;
+        nblocks += (p.nblocks + 7) & ~7;
+        flops += 2.0 * a->M * a->N * a->K;
+        bytes += ((double)a->M + a->N) * a->K * 2 + (double)a->M * a->N * 4;
+    }
+    g.first[count] = nblocks;
+    g.count = count;
+    ProfScope prof(HS_PROF_GEMM_NT + HS_GEMM_TN, stream, flops, bytes);
+    hipLaunchKernelGGL((gemm_bf16_group_kernel<true, true, false, HS_EPI_ATOMIC>), dim3(nblocks), dim3(512), 0, (hipStream_t)stream, g);
+    HS_CHECK_LAUNCH();
+    return HS_OK;
+}
 
 extern "C" int hs_gemm(const hs_gemm_args* a, int prec, void* stream) {
     if (!a || !a->A || !a->B || (!a->out_f32 && !a->out_bf16)) return HS_ERR_ARG;

@@ -45,7 +45,10 @@ Layout make_layout(const hs_vit_desc& c) {
     const bool bwd = c.save_for_bwd != 0;
     L.dx = take(bwd ? M * d * 4 : 0);
     L.dh = take(bwd ? M * d * es : 0);     // dgrad outputs feeding LN backward: bf16 (autocast's Linear backward dtype) / f32 in parity mode
-    L.dxb = take(bwd && c.prec == HS_PREC_BF16 ? M * d * 2 : 0);     // bf16 copy of the residual-stream gradient (GEMM operand)
+    // bf16 copies of the residual-stream gradient (GEMM operand): THREE rotating buffers -- a layer's backward produces two new ones
+    // (after LN2 and after LN1 backward) and its four weight-gradient GEMMs, launched as ONE group at the end of the layer, still
+    // read the previous two.  Copy j (j = 0 entering the top layer, two per layer) lives in buffer j % 3, so chunked calls agree.
+    L.dxb = take(bwd && c.prec == HS_PREC_BF16 ? 3 * al256(M * d * 2) : 0);
     L.dob = take(bwd ? M * d * es : 0);
     L.dz = take(bwd ? M * mlp * es : 0);
     L.dqkv = take(bwd ? M * 3 * d * es : 0);
@@ -213,7 +216,41 @@ extern "C" int hs_vit_blocks_bwd(const hs_vit_desc* desc, const float* x0, const
             wqkv = p[P_WQKV]; wo = p[P_WO]; w1 = p[P_W1]; w2 = p[P_W2];
         }
 
-        // ---- MLP branch: x' = xm + W2 gelu(W1 h2 + b1) + b2        (db2 came with the dx that entered this layer)
+        if (bf) {
+            // bf16: dgrad chain first, the four weight gradients as one grouped launch at the end of the layer
+            const int j = 2 * (c.L - 1 - l);
+            const size_t dxs = al256(Md * 2);
+            const bf16_t* dx_in = (const bf16_t*)(w + L.dxb + (size_t)(j % 3) * dxs);
+            bf16_t* dx_mid = (bf16_t*)(w + L.dxb + (size_t)((j + 1) % 3) * dxs);
+            bf16_t* dx_out = (bf16_t*)(w + L.dxb + (size_t)((j + 2) % 3) * dxs);
+            // ---- MLP branch: x' = xm + W2 gelu(W1 h2 + b1) + b2        (db2 came with the dx that entered this layer)
+            RC(gemm(P, HS_GEMM_NN, dx_in, w2, M, mlp, d, d, mlp, nullptr, dz, mlp, nullptr, nullptr, z, nullptr,
+                    HS_EPI_GELU_BWD | HS_EPI_SAVE_DGELU, 1, stream, g[P_B1]));               // db1 = colsum(dz), fused in the epilogue
+            RC(gemm(P, HS_GEMM_NN, dz, w1, M, d, mlp, mlp, d, nullptr, dh, d, nullptr, nullptr, nullptr, nullptr, 0, 1, stream));
+            RC(hs_layernorm_bwd(dh, 1, xmid, nullptr, p[P_N2W], st + 2 * M, st + 3 * M, dx, dx, dx_mid, g[P_N2W], g[P_N2B], g[P_BO], M, d, stream));
+            // ---- attention branch: xm = x + Wo attn(LN1 x) + bo         (dbo came from the LN2 backward just above)
+            RC(gemm(P, HS_GEMM_NN, dx_mid, wo, M, d, d, d, d, nullptr, dob, d, nullptr, nullptr, nullptr, nullptr, 0, 1, stream));
+            RC(hs_attn_bwd(qkv, o, dob, lse, dqkv, delta, c.B, c.N, c.H, 64, HS_ATTN_Q_PRESCALED, stream));
+            RC(gemm(P, HS_GEMM_NN, dqkv, wqkv, M, d, 3 * d, 3 * d, d, nullptr, dh, d, nullptr, nullptr, nullptr, nullptr, 0, 1, stream));
+            float* dxo = (l == 0) ? dx0 : dx;
+            float* b2_below = (l == 0) ? nullptr : lg[(size_t)(l - 1) * P_COUNT + P_B2];
+            RC(hs_layernorm_bwd(dh, 1, xin, nullptr, p[P_N1W], st, st + M, dx, dxo, l == 0 ? nullptr : dx_out, g[P_N1W], g[P_N1B], b2_below, M, d, stream));
+            // ---- dW2 = dx'^T a, dW1 = dz^T h2, dWqkv = dqkv^T h1, dWo = dxm^T o (largest first)
+            const int mn[4][2] = {{d, mlp}, {mlp, d}, {3 * d, d}, {d, d}};
+            const int split = wgrad_group_split(mn, 4, M);
+            hs_gemm_args wg[4] = {};
+            const void* dys[4] = {dx_in, dz, dqkv, dx_mid};
+            const void* xs[4] = {a, h2, h1, o};
+            float* dws[4] = {g[P_W2], g[P_W1], g[P_WQKV], g[P_WO]};
+            for (int i = 0; i < 4; ++i) {
+                wg[i].A = dys[i]; wg[i].B = xs[i]; wg[i].M = mn[i][0]; wg[i].N = mn[i][1]; wg[i].K = M;
+                wg[i].lda = mn[i][0]; wg[i].ldb = mn[i][1]; wg[i].ldc = mn[i][1]; wg[i].batch = 1; wg[i].out_f32 = dws[i];
+                wg[i].alpha = 1.0f; wg[i].flags = HS_EPI_ATOMIC; wg[i].layout = HS_GEMM_TN; wg[i].split_k = split;
+            }
+            RC(hs_gemm_group(wg, 4, stream));
+            continue;
+        }
+        // ---- f32 parity mode: the same sequence with exact-f32 kernels, weight gradients where their operands appear
         RC(gemm(P, HS_GEMM_TN, dxop, a, d, mlp, M, d, mlp, g[P_W2], nullptr, mlp, nullptr, nullptr, nullptr, nullptr, HS_EPI_ATOMIC,
                 wgrad_split(d, mlp, M, P), stream));
         RC(gemm(P, HS_GEMM_NN, dxop, w2, M, mlp, d, d, mlp, f32o(dz), bfo(dz), mlp, nullptr, nullptr, z, nullptr,

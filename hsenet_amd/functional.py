@@ -88,6 +88,25 @@ def gemm(A: torch.Tensor, Bm: torch.Tensor, layout: int, *, prec: int, out_f32: 
     L.call("hs_gemm", C.byref(g), prec, _s())
 
 
+def wgrad_group(dys, xs, outs, split_k: int = 1) -> None:
+    """outs[i] += dys[i]^T @ xs[i] for up to 4 (dY [rows][n_out], X [rows][n_in]) bf16 pairs in ONE launch (hs_gemm_group);
+    outs: fp32 [n_out][n_in], accumulated with float atomics (the caller zeroes them)."""
+    n = len(dys)
+    if not (1 <= n <= 4) or len(xs) != n or len(outs) != n:
+        raise L.HsError("wgrad_group takes 1..4 (dY, X, out) triples")
+    arr = (L.GemmArgs * n)()
+    for g, dy, x, o in zip(arr, dys, xs, outs):
+        _need(dy, x, o)
+        if dy.dtype != torch.bfloat16 or x.dtype != torch.bfloat16 or o.dtype != torch.float32:
+            raise L.HsError("wgrad_group: bf16 operands, fp32 outputs")
+        if dy.dim() != 2 or x.dim() != 2 or dy.shape[0] != x.shape[0] or tuple(o.shape) != (dy.shape[1], x.shape[1]):
+            raise L.HsError("wgrad_group: shape mismatch")
+        g.A, g.B, g.M, g.N, g.K = dy.data_ptr(), x.data_ptr(), dy.shape[1], x.shape[1], dy.shape[0]
+        g.lda, g.ldb, g.ldc, g.batch = dy.shape[1], x.shape[1], x.shape[1], 1
+        g.out_f32, g.alpha, g.flags, g.layout, g.split_k = o.data_ptr(), 1.0, L.EPI_ATOMIC, L.GEMM_TN, split_k
+    L.call("hs_gemm_group", arr, n, _s())
+
+
 def cast_bf16(x: torch.Tensor) -> torch.Tensor:
     _need(x)
     y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)

@@ -79,6 +79,11 @@ int hs_device_check(int dev);
  * (call sites multimodal_encoder/vit.py:428-443), regular_attention (vit.py:39-45,57-62),
  * resolution_attention_v3 + proj_mpls (multimodal_projector/spatial_pooling_projector.py:51-57,73-82,127-131). */
 int hs_gemm(const hs_gemm_args* args, int prec, void* stream);
+/* `count` (1..HS_GEMM_GROUP_MAX) independent weight-gradient GEMMs in ONE launch: every problem bf16, HS_GEMM_TN, flags ==
+ * HS_EPI_ATOMIC, batch 1 (the four dW = dY^T X of a transformer layer, vit.py:467's TransformerBlock backward).  Results equal
+ * `count` hs_gemm calls; at one volume per GPU a lone wgrad cannot fill the chip without a deep split-K, the group can. */
+#define HS_GEMM_GROUP_MAX 4
+int hs_gemm_group(const hs_gemm_args* args, int count, void* stream);
 
 /* ---- K1: 3D patch embedding.  Replaces x.clone() + einops 'b c (h p1)(w p2)(d p3) -> b (h w d)(p1 p2 p3 c)'
  * (vit.py:437,455) = the A operand of the patch-embed Linear.  out: [B*Np][Pd] bf16 (prec 0) / float (prec 1). */

@@ -99,6 +99,26 @@ def test_gemm_batched_f32(dev):
     assert rel(out, 0.25 * a.double() @ b.double().transpose(1, 2)) < 1e-6
 
 
+@pytest.mark.parametrize("rows,split", [(4097, 1), (4097, 3), (520, 2), (64, 1)])
+def test_gemm_group_equals_separate_wgrads(dev, rows, split):
+    """hs_gemm_group (the four weight-gradient GEMMs of a layer in one launch) against fp32 matmuls and, unsplit, bit-for-bit
+    against four hs_gemm calls (one atomic add per element onto zero: no order dependence)."""
+    from hsenet_amd import functional as Fn, _lib as L
+    shapes = [(768, 3072), (3072, 768), (2304, 768), (768, 768)]
+    dys = [rnd((rows, m), 11 + i, dev).bfloat16() for i, (m, n) in enumerate(shapes)]
+    xs = [rnd((rows, n), 21 + i, dev).bfloat16() for i, (m, n) in enumerate(shapes)]
+    outs = [torch.zeros(m, n, device=dev) for m, n in shapes]
+    Fn.wgrad_group(dys, xs, outs, split)
+    for dy, x, o in zip(dys, xs, outs):
+        assert rel(o, dy.float().t() @ x.float()) < 2e-3
+        if split == 1:
+            sep = torch.zeros_like(o)
+            Fn.gemm(dy, x, L.GEMM_TN, prec=L.PREC_BF16, out_f32=sep, flags=L.EPI_ATOMIC, split_k=1)
+            assert torch.equal(o, sep)
+    with pytest.raises(L.HsError):
+        Fn.wgrad_group(dys * 2, xs * 2, outs * 2)
+
+
 def sdpa_ref(qkv, H):
     B, N, D3 = qkv.shape
     q, k, v = qkv.double().view(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
