@@ -172,22 +172,18 @@ extern "C" int hs_vit_blocks_bwd(const hs_vit_desc* desc, const float* x0, const
     char* w = (char*)ws;
     const int M = c.B * c.N, d = c.d, mlp = c.mlp;
     const size_t Md = (size_t)M * d;
-    // bf16 (the reference's autocast policy): GEMM operands / dgrad outputs bf16, residual-stream gradient fp32 + a bf16 copy.
-    // f32 (parity mode): everything fp32, exact-f32 MFMA GEMMs and attention -- the same sequence, no bf16 copy, bias gradient of
-    // fc1 by a separate column-sum pass (the fused one lives in the bf16 GEMM epilogue).
+    // bf16 (the reference's autocast policy): GEMM operands / dgrad outputs bf16, residual-stream gradient fp32 + bf16 copies.
+    // f32 (parity mode): everything fp32, exact-f32 MFMA GEMMs and attention.
     const bool bf = c.prec == HS_PREC_BF16;
     const size_t es = bf ? 2 : 4;
     const int P = c.prec;
     float* dx = (float*)(w + L.dx);
     char* dh = w + L.dh;
-    bf16_t* dxb = bf ? (bf16_t*)(w + L.dxb) : nullptr;
+    bf16_t* dxb = bf ? (bf16_t*)(w + L.dxb) : nullptr;            // copy 0 (entering the top layer)
     char* dob = w + L.dob;
     char* dz = w + L.dz;
     char* dqkv = w + L.dqkv;
     float* delta = (float*)(w + L.delta);
-    const void* dxop = bf ? (const void*)dxb : (const void*)dx;       // the residual-stream gradient as a GEMM operand
-    auto f32o = [&](char* p) { return bf ? nullptr : (float*)p; };
-    auto bfo = [&](char* p) { return bf ? (void*)p : nullptr; };
 
     if (l_hi == c.L) {
         const float* fs = (const float*)(w + L.fstats);
@@ -250,27 +246,28 @@ extern "C" int hs_vit_blocks_bwd(const hs_vit_desc* desc, const float* x0, const
             RC(hs_gemm_group(wg, 4, stream));
             continue;
         }
-        // ---- f32 parity mode: the same sequence with exact-f32 kernels, weight gradients where their operands appear
-        RC(gemm(P, HS_GEMM_TN, dxop, a, d, mlp, M, d, mlp, g[P_W2], nullptr, mlp, nullptr, nullptr, nullptr, nullptr, HS_EPI_ATOMIC,
+        // ---- f32 parity mode: the same sequence with exact-f32 kernels, every buffer fp32, weight gradients where their operands
+        // appear, bias gradient of fc1 by a separate column-sum pass (the fused one lives in the bf16 GEMM epilogue)
+        float* dzf = (float*)dz; float* dhf = (float*)dh; float* dobf = (float*)dob;
+        RC(gemm(P, HS_GEMM_TN, dx, a, d, mlp, M, d, mlp, g[P_W2], nullptr, mlp, nullptr, nullptr, nullptr, nullptr, HS_EPI_ATOMIC,
                 wgrad_split(d, mlp, M, P), stream));
-        RC(gemm(P, HS_GEMM_NN, dxop, w2, M, mlp, d, d, mlp, f32o(dz), bfo(dz), mlp, nullptr, nullptr, z, nullptr,
-                HS_EPI_GELU_BWD | HS_EPI_SAVE_DGELU, 1, stream, bf ? g[P_B1] : nullptr));  // db1 = colsum(dz), fused in the bf16 epilogue
-        if (!bf) RC(hs_colsum(dz, 0, g[P_B1], M, mlp, mlp, stream));
+        RC(gemm(P, HS_GEMM_NN, dx, w2, M, mlp, d, d, mlp, dzf, nullptr, mlp, nullptr, nullptr, z, nullptr,
+                HS_EPI_GELU_BWD | HS_EPI_SAVE_DGELU, 1, stream));
+        RC(hs_colsum(dz, 0, g[P_B1], M, mlp, mlp, stream));
         RC(gemm(P, HS_GEMM_TN, dz, h2, mlp, d, M, mlp, d, g[P_W1], nullptr, d, nullptr, nullptr, nullptr, nullptr, HS_EPI_ATOMIC,
                 wgrad_split(mlp, d, M, P), stream));
-        RC(gemm(P, HS_GEMM_NN, dz, w1, M, d, mlp, mlp, d, f32o(dh), bfo(dh), d, nullptr, nullptr, nullptr, nullptr, 0, 1, stream));
-        RC(hs_layernorm_bwd(dh, bf ? 1 : 0, xmid, nullptr, p[P_N2W], st + 2 * M, st + 3 * M, dx, dx, dxb, g[P_N2W], g[P_N2B], g[P_BO], M, d, stream));
-        // ---- attention branch: xm = x + Wo attn(LN1 x) + bo         (dbo came from the LN2 backward just above)
-        RC(gemm(P, HS_GEMM_TN, dxop, o, d, d, M, d, d, g[P_WO], nullptr, d, nullptr, nullptr, nullptr, nullptr, HS_EPI_ATOMIC,
+        RC(gemm(P, HS_GEMM_NN, dz, w1, M, d, mlp, mlp, d, dhf, nullptr, d, nullptr, nullptr, nullptr, nullptr, 0, 1, stream));
+        RC(hs_layernorm_bwd(dh, 0, xmid, nullptr, p[P_N2W], st + 2 * M, st + 3 * M, dx, dx, nullptr, g[P_N2W], g[P_N2B], g[P_BO], M, d, stream));
+        RC(gemm(P, HS_GEMM_TN, dx, o, d, d, M, d, d, g[P_WO], nullptr, d, nullptr, nullptr, nullptr, nullptr, HS_EPI_ATOMIC,
                 wgrad_split(d, d, M, P), stream));
-        RC(gemm(P, HS_GEMM_NN, dxop, wo, M, d, d, d, d, f32o(dob), bfo(dob), d, nullptr, nullptr, nullptr, nullptr, 0, 1, stream));
-        RC(hs_attn_bwd(qkv, o, dob, lse, dqkv, delta, c.B, c.N, c.H, 64, bf ? HS_ATTN_Q_PRESCALED : HS_ATTN_F32, stream));
+        RC(gemm(P, HS_GEMM_NN, dx, wo, M, d, d, d, d, dobf, nullptr, d, nullptr, nullptr, nullptr, nullptr, 0, 1, stream));
+        RC(hs_attn_bwd(qkv, o, dob, lse, dqkv, delta, c.B, c.N, c.H, 64, HS_ATTN_F32, stream));
         RC(gemm(P, HS_GEMM_TN, dqkv, h1, 3 * d, d, M, 3 * d, d, g[P_WQKV], nullptr, d, nullptr, nullptr, nullptr, nullptr, HS_EPI_ATOMIC,
                 wgrad_split(3 * d, d, M, P), stream));
-        RC(gemm(P, HS_GEMM_NN, dqkv, wqkv, M, d, 3 * d, 3 * d, d, f32o(dh), bfo(dh), d, nullptr, nullptr, nullptr, nullptr, 0, 1, stream));
+        RC(gemm(P, HS_GEMM_NN, dqkv, wqkv, M, d, 3 * d, 3 * d, d, dhf, nullptr, d, nullptr, nullptr, nullptr, nullptr, 0, 1, stream));
         float* dxo = (l == 0) ? dx0 : dx;
         float* b2_below = (l == 0) ? nullptr : lg[(size_t)(l - 1) * P_COUNT + P_B2];
-        RC(hs_layernorm_bwd(dh, bf ? 1 : 0, xin, nullptr, p[P_N1W], st, st + M, dx, dxo, l == 0 ? nullptr : dxb, g[P_N1W], g[P_N1B], b2_below, M, d, stream));
+        RC(hs_layernorm_bwd(dh, 0, xin, nullptr, p[P_N1W], st, st + M, dx, dxo, nullptr, g[P_N1W], g[P_N1B], b2_below, M, d, stream));
     }
     return HS_OK;
 }
