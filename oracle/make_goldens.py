@@ -322,6 +322,32 @@ def grads(vit, spp):
     print(f"grad_vit256_stage1 ok (restatement vs reference gradients: worst {worst:.1e})")
 
 
+def clip_c4a():
+    """BASELINE configs[3] at full geometry (256^3 / 16^3, L = 12), 2 volumes, global step 1000: loss pieces, logits and the gradient
+    fixture of every trainable tensor of the stage-2 CLIP step, from the ORACLE's restatement (oracle/clip_cpu.py — CLIP_stage2.py
+    itself cannot be imported, see that file's header: this fixture pins the HIP step to the oracle at full size, it does not pin
+    the oracle's ~40 lines of loss glue to the reference; the encoders inside are the classes the fixtures above validate)."""
+    from oracle import clip_cpu as RC
+    img, patch, B, step = (256, 256, 256), (16, 16, 16), 2, 1000
+    m = RC.M3DCLIPVision_stage2(img, patch).eval()
+    sd = R.seeded_state_dict(m, 91)
+    sd["logit_scale"] = torch.tensor(float(np.log(1 / 0.07)))
+    sd["stage1_pretrained_CLIP.logit_scale"] = torch.tensor(float(np.log(1 / 0.07)))
+    m.load_state_dict(sd)
+    x, s = R.synthetic_volume((B, 1) + img, 92), R.synthetic_slices(B, 93)
+    t1, t2 = RC.synthetic_text_features(B, 94), RC.synthetic_text_features(B, 95)
+    out = m(x, t1, t2, s, global_step=step)
+    out["loss"].backward()
+    named = [(n, p) for n, p in m.named_parameters() if p.requires_grad]
+    fx = _grad_fixture(named, "grad")
+    fx.update(img=np.array(img), patch=np.array(patch), batch=B, global_step=step, seed_w=91, seed_x=92, seed_s=93, seed_t1=94, seed_t2=95,
+              loss=float(out["loss"]), loss_cl=float(out["loss_CL_stage2"]), loss_relation=float(out["loss_relation"]),
+              logits=out["logits"].detach().numpy())
+    np.savez_compressed(os.path.join(OUT, "clip_c4a_256.npz"), **fx)
+    print(f"clip_c4a_256 ok: loss {float(out['loss']):.6f} (CL {float(out['loss_CL_stage2']):.6f}, relation {float(out['loss_relation']):.6f}), "
+          f"{len(named)} trainable tensors")
+
+
 @torch.no_grad()
 def plumbing(vit):
     """BASELINE configs[0]: one 128^3 volume, ViT-small (6 layers, d=384, 6 heads, mlp 1536), fwd only."""
@@ -341,7 +367,7 @@ def plumbing(vit):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-big", action="store_true")
-    ap.add_argument("--only", default=None, choices=["grads"], help="regenerate only this group of fixtures")
+    ap.add_argument("--only", default=None, choices=["grads", "clip"], help="regenerate only this group of fixtures")
     a = ap.parse_args()
     if not os.path.isdir(REF):
         sys.exit("reference not present (this script only runs in the build container)")
@@ -351,12 +377,16 @@ def main():
     if a.only == "grads":
         grads(vit, spp)
         return
+    if a.only == "clip":
+        clip_c4a()
+        return
     tiny_encoders(vit)
     packer(spp)
     plumbing(vit)
     if not a.skip_big:
         big(vit, spp)
         grads(vit, spp)
+        clip_c4a()
 
 
 if __name__ == "__main__":
