@@ -119,6 +119,44 @@ def test_dual_engine_vs_reference_gradients(dev, golden, name):
     check_grads(_named(tower, p1, p2), g, f"DualEngine {name}")
 
 
+class _Subset:
+    """view of a gradient fixture restricted to the parameter names accepted by `keep` (same interface as the npz)"""
+
+    def __init__(self, g, keep):
+        self.g = g
+        idx = [i for i, n in enumerate(g["grad_names"]) if keep(str(n))]
+        self.over = {"grad_names": g["grad_names"][idx], "grad_norms": g["grad_norms"][idx]}
+        self.files = [f for f in g.files if not f.startswith(("grad_g/", "grad_r/")) or keep(f.split("/", 1)[1])]
+
+    def __getitem__(self, k):
+        return self.over[k] if k in self.over else self.g[k]
+
+
+@pytest.mark.parametrize("name", ["grad_native_dual.npz", "grad_dual256.npz"])
+def test_mrg_step_engine_vs_reference_packer_gradients(dev, golden, name):
+    """BASELINE configs[4]'s vision side at full size through MRGStepEngine (frozen dual towers, fused packers, splice into the
+    token embeddings, backward from d(inputs_embeds)): with the stand-in "LLM" loss sum(emb[:, 1:257] * w) the packers see exactly the
+    output gradient of the reference fixture, so their gradients must equal the REFERENCE modules' autograd (the towers get none)."""
+    from hsenet_amd.mrg_step import MRGStepEngine
+    g = golden(name)
+    tower, p1, p2, x, s, w = _dual_modules(g, dev)
+    eng = MRGStepEngine(tower, p1, p2, 1, lr=1e-6)
+    emb = torch.zeros(1, 300, 3072, device=dev)
+    seen = {}
+
+    def llm_loss(e):
+        seen["emb"] = e
+        return (e[:, 1:257, :] * w).sum()
+    eng.train_step(x, s, emb, llm_loss)
+    torch.cuda.synchronize()
+    out = seen["emb"][:, 1:257, :].detach()
+    rows = [int(r) for r in g["out_rows_idx"]]
+    assert _rel(out[:, rows], g["out_rows"]) < TOL and float(seen["emb"][:, 257:].abs().max()) == 0
+    packers = [(n, p) for n, p in _named(tower, p1, p2) if n.startswith("mm_projector")]
+    check_grads(packers, _Subset(g, lambda n: n.startswith("mm_projector")), f"MRGStepEngine {name}")
+    assert all(p.grad is None or float(p.grad.abs().max()) == 0 for p in tower.parameters())
+
+
 def test_dual_module_path_vs_reference_gradients(dev, golden):
     """the drop-in module API (autograd Functions) at the reference-native geometry."""
     import hsenet_amd as H
