@@ -117,9 +117,12 @@ SIGNATURES = {
     "hs_relation_mse": [_vp, _vp, _vp, _vp, _i64, _f, _i, _vp],
     "hs_ce_rows": [_vp, _vp, _vp, _i, _i, _i, _f, _i, _vp],
     "hs_debug_set": [_i, _i],
+    "hs_debug_gemm_stamps": [_vp, _i],
+    "hs_debug_gemm_trace": [_vp, _i],
 }
 _RESTYPE = {"hs_vit_workspace_bytes": _sz, "hs_embed_workspace_bytes": _sz, "hs_packer_workspace_bytes": _sz,
-            "hs_prof_name": C.c_char_p, "hs_debug_set": None}
+            "hs_prof_name": C.c_char_p, "hs_debug_set": None, "hs_debug_gemm_stamps": None,
+            "hs_debug_gemm_trace": None}
 
 _lib = None
 _lock = threading.Lock()

@@ -337,6 +337,11 @@ int hs_ce_rows(const float* logits, float* dlogits, float* loss, int rows, int c
 
 /* diagnostic: selects a kernel variant per class for tools/kbench A/B runs (every key defaults to 0 = the shipped kernel) */
 void hs_debug_set(int key, int value);
+/* diagnostic (hs_debug_set(3, 4 | 7) / (3, 22), tools/kbench only): s_memtime phase sums of the bf16 GEMM's blocks (8 counters;
+ * reset != 0 clears them) / the per-block timeline {tile start, main loop end, epilogue end, HW_ID | XCC_ID << 32} of the first
+ * min(nblocks, 4096) blocks of the last launch */
+void hs_debug_gemm_stamps(unsigned long long* out, int reset);
+void hs_debug_gemm_trace(unsigned long long* out, int nblocks);
 
 #ifdef __cplusplus
 }

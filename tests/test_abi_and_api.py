@@ -28,6 +28,8 @@ def test_library_exports_every_declared_symbol():
     exported = set(re.findall(r" T (hs_[a-z0-9_]+)", out))
     missing = [n for n in names if n not in exported]
     assert not missing, f"declared in include/hsenet_hip.h but not exported: {missing}"
+    undeclared = sorted(exported - set(names))
+    assert not undeclared, f"exported by the library but not declared in include/hsenet_hip.h: {undeclared}"
     lib = _lib.load()
     assert sorted(_lib.SIGNATURES) == names, "hsenet_amd/_lib.py SIGNATURES must mirror the header one to one"
     assert lib.hs_version() >= 1
