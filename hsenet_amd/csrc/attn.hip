@@ -965,37 +965,39 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void attn_bwd_dq2_kernel(
     if (query < N) store_dT(dqkv + ((long)b * N + query) * D3 + head * 64, dq, out_mul, h);
 }
 
-template <int CNT>
-__device__ __forceinline__ void lds_wait8(u32x4& a, u32x4& b, u32x4& c, u32x4& d, u32x4& e, u32x4& f, u32x4& g, u32x4& i) {
-#if HS_ABL & 8
-    asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(i) : "i"(CNT) : "memory");
-#else
-    asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(i) : "i"(CNT) : "memory");
-#endif
-}
-__device__ __forceinline__ f32x16 cat16(u32x4 a, u32x4 b, u32x4 c, u32x4 d) {
-    f32x16 r;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        r[e] = __uint_as_float(a[e]); r[4 + e] = __uint_as_float(b[e]);
-        r[8 + e] = __uint_as_float(c[e]); r[12 + e] = __uint_as_float(d[e]);
-    }
-    return r;
-}
+// Image R16: the same [rows][64 bf16] tile with the swizzle the 16x16x32 operand maps need: 16-B chunk c of row r at chunk
+// c ^ (r & 6).  ds_read_b128 of the 16-row x 4-chunk operand: a hardware lane group {0-3,12-15,20-27} (and its three siblings) holds
+// rows {0-3,12-15} with chunk k and rows {4-11} with chunk k^1; slot = 8(r&1) + (chunk ^ (r&6)) is then a bijection onto the 16
+// 16-B slots of the bank row.  ds_read_b64_tr_b16 (banking per 32-lane half = 8 rows x two chunks 2di, 2di+1): rows of one parity
+// land on the four chunk pairs di ^ ((r>>1)&3).  Both conflict-free (SQ_LDS_BANK_CONFLICT = 0); with swzR the row read was 2-way.
+__device__ __forceinline__ int swz16(int r) { return r & 6; }
+__device__ __forceinline__ int offR16(int r, int c) { return r * 128 + ((c ^ swz16(r)) << 4); }
 
-// dK, dV v2: NW waves x 32 keys per block (K, V fragments and the dK^T, dV^T accumulators stay in registers), sweeping the
-// queries in 64-row tiles that arrive by LDS-DMA: Q' image | dO image | -lse*log2e [64] | -delta [64] per stage, 3-stage
-// ring.  Per 32-query block: S' = Q' K^T + (-lse*log2e)[q], dP' = dO V^T + (-delta)[q] (row constants preloaded as the
-// accumulators, read from the stage), P = exp2(S'), dS = P * dP'; dV^T += dO^T P, dK^T += Q'^T dS (Q', dO read
-// transposed from the same images).  Query rows >= N arrive as zeros (range-checked DMA): P = 1 there but dO = 0 and
-// dP' = 0, so they add nothing.  Every LDS read is issued from asm in chunks ahead of use, with counted waits.
+// dK, dV: NW waves x 32 keys per block (K, V fragments and the dK^T, dV^T accumulators stay in registers), sweeping the queries in
+// 64-row tiles that arrive by LDS-DMA: Q' image | dO image | -lse*log2e [64] | -delta [64] per stage, 3-stage ring.  Per 32-query
+// block: S' = Q' K^T + (-lse*log2e)[q], dP' = dO V^T + (-delta)[q] (row constants preloaded as the accumulators, read from the stage),
+// P = exp2(S'), dS = P * dP'; dV^T += dO^T P, dK^T += Q'^T dS (Q', dO read transposed from the same images).  Query rows >= N arrive as
+// zeros (range-checked DMA): P = 1 there but dO = 0 and dP' = 0, so they add nothing.  Every LDS read is issued from asm in chunks
+// ahead of use, with counted waits.
+// Built on v_mfma_f32_16x16x32_bf16 -- the shape the chip runs 7 % faster at the power cap for this instruction mix (DESIGN.md
+// section 4, tools/micro/mfma_mix.cpp); the 32x32x16 version of round 1 (git history) had the same block shape, stage layout, DMA ring
+// and LDS byte counts.  The 32-query x 32-key block of a wave is 2 x 2 tiles of 16 x 16:
+//   S'(qi,ki)  = sum over 2 k-steps of  A = Q' rows 16qi + (lane & 15), d = 32ks + 8g..8g+7   (row fragment: chunk 4ks + g of the row)
+//                                       B = K  key  16ki + (lane & 15), same d                 (registers, loaded once)
+//                accumulator: lane (key column lane & 15, g = lane >> 4) holds query rows 16qi + 4g + r, r = 0..3, so the row
+//                constants of a tile are ONE broadcast 16-B read (they enter as the C operand of the first k-step: no moves)
+//   P / dS as the B operand of dV^T / dK^T (k = query): the two stacked tiles (qi = 0, 1) of key tile ki give a lane its 8 k-slots:
+//                slot j < 4 <-> query 4g + j, slot j >= 4 <-> query 16 + 4g + (j - 4)
+//   A = dO^T / Q'^T tile di (16 d columns): two ds_read_b64_tr_b16 per fragment, 16-lane group g reading rows 4g..4g+3 and
+//                16+4g..16+4g+3 of the 32-query block at columns 16di..16di+15 -- the same k-slot order
+//   dV^T(di,ki), dK^T(di,ki): lane (key, g) holds d = 16di + 4g + r -> four consecutive d per 8-byte store.
 template <int NW>
-__device__ __forceinline__ void attn_bwd_dkdv2_body(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
-                                                    const float* __restrict__ ws, bf16_t* __restrict__ dqkv, int B,
-                                                    int N, int H, float kmul, float dk_mul) {
+__device__ __forceinline__ void attn_bwd_dkdv16_body(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
+                                                     const float* __restrict__ ws, bf16_t* __restrict__ dqkv, int B,
+                                                     int N, int H, float kmul, float dk_mul) {
     constexpr int STG = 16896, KBK = NW * 32, NP = 8 / NW;
     __shared__ __attribute__((aligned(16))) char smem[3 * STG];
-    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31;
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int blk, head, b;
     attn_block_coords((N + KBK - 1) / KBK, H, blk, head, b);
@@ -1004,14 +1006,13 @@ __device__ __forceinline__ void attn_bwd_dkdv2_body(const bf16_t* __restrict__ q
     const int Dm = H * 64, D3 = 3 * Dm;
     const __amdgpu_buffer_rsrc_t rs = make_rsrc(qkv + (long)b * N * D3, (size_t)N * D3 * 2);
     const __amdgpu_buffer_rsrc_t rsd = make_rsrc(d_o + (long)b * N * Dm, (size_t)N * Dm * 2);
-    // waves 0 / 1 also bring the tile's 64 row constants (4 B per lane): -lse*log2e (ws[1]) / -delta (ws[0])
     const __amdgpu_buffer_rsrc_t rst_ = make_rsrc(ws + (wave == 0 ? (long)B * H * N : 0) + ((long)b * H + head) * N, (size_t)N * 4);
     const int nt = (N + 63) >> 6;
     unsigned vq[NP], vd[NP], vql[NP], vdl[NP];
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
         const int row = (wave * NP + j) * 8 + (lane >> 3);
-        const int ch = (lane & 7) ^ swzR(row);
+        const int ch = (lane & 7) ^ swz16(row);
         vq[j] = (unsigned)(((long)row * D3 + head * 64 + ch * 8) * 2);
         vd[j] = (unsigned)(((long)row * Dm + head * 64 + ch * 8) * 2);
         const bool in = (nt - 1) * 64 + row < N;
@@ -1035,105 +1036,125 @@ __device__ __forceinline__ void attn_bwd_dkdv2_body(const bf16_t* __restrict__ q
     issue(0, 0);
     if (nt > 1) issue(1, 1);
 
-    const int key = k0 + c;
-    bf16x8 kf[4], vf[4];
+    bf16x8 kf[2][2], vf[2][2];                                   // [key tile ki][k-step ks]
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        const unsigned off = key < N ? (unsigned)(((long)key * D3 + Dm + head * 64 + ks * 16 + 8 * h) * 2) : HS_OOB_OFF;
-        kf[ks] = scale_frag(buf_load16(rs, off), kmul);
-        vf[ks] = __builtin_bit_cast(bf16x8, buf_load16(rs, key < N ? off + Dm * 2 : HS_OOB_OFF));
-    }
-    unsigned rb0[4], tb0[2][2];
+    for (int ki = 0; ki < 2; ++ki) {
+        const int key = k0 + 16 * ki + c;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) rb0[ks] = lds_addr(smem) + offR(c, 2 * ks + h);
-    {
-        const int g = lane >> 4, p = lane & 3, q = (lane >> 2) & 3;
-#pragma unroll
-        for (int db = 0; db < 2; ++db) {
-            const int col = db * 32 + 16 * (g & 1) + 4 * p;
-            tb0[db][0] = lds_addr(smem) + offR(4 * h + q, col >> 3) + 8 * (p & 1);
-            tb0[db][1] = lds_addr(smem) + offR(4 * h + q + 8, col >> 3) + 8 * (p & 1);
+        for (int ks = 0; ks < 2; ++ks) {
+            const unsigned off = key < N ? (unsigned)(((long)key * D3 + Dm + head * 64 + ks * 32 + 8 * g) * 2) : HS_OOB_OFF;
+            kf[ki][ks] = scale_frag(buf_load16(rs, off), kmul);
+            vf[ki][ks] = __builtin_bit_cast(bf16x8, buf_load16(rs, key < N ? off + Dm * 2 : HS_OOB_OFF));
         }
     }
-    const unsigned sb0 = lds_addr(smem) + 16384 + 16 * h;      // row constants of rows 4h..4h+3 (+32 B per 8 rows)
+    unsigned rb0[2], tb0[4][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) rb0[ks] = lds_addr(smem) + offR16(c, 4 * ks + g);     // rows +16 / +32: same swizzle (bits 1-2)
+    {
+        const int p = lane & 3, q = (lane >> 2) & 3;
+#pragma unroll
+        for (int di = 0; di < 4; ++di) {
+            tb0[di][0] = lds_addr(smem) + offR16(4 * g + q, 2 * di + (p >> 1)) + 8 * (p & 1);
+            tb0[di][1] = lds_addr(smem) + offR16(4 * g + q + 16, 2 * di + (p >> 1)) + 8 * (p & 1);
+        }
+    }
+    const unsigned sb0 = lds_addr(smem) + 16384 + 16 * g;        // row constants of rows 4g..4g+3 of a 16-row tile
 
-    f32x16 dk[2] = {zero16(), zero16()}, dv[2] = {zero16(), zero16()};
+    f32x4 dk[4][2], dv[4][2];                                     // [d tile di][key tile ki]
+#pragma unroll
+    for (int di = 0; di < 4; ++di)
+#pragma unroll
+        for (int ki = 0; ki < 2; ++ki) { dk[di][ki] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[di][ki] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     typedef std::integral_constant<int, 0> I0;
     typedef std::integral_constant<int, 1> I1;
     auto tile = [&](auto stage_tag, int rst) {
         constexpr int ST = decltype(stage_tag)::value;            // -1: run-time stage (last tile)
         constexpr int SB = ST < 0 ? 0 : ST * STG;
         const unsigned dyn = ST < 0 ? (unsigned)rst * STG : 0u;
-        unsigned rbase[4], tb[2][2];
+        unsigned rbase[2], tb[4][2];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) rbase[ks] = rb0[ks] + dyn;
+        for (int ks = 0; ks < 2; ++ks) rbase[ks] = rb0[ks] + dyn;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) tb[i][j] = tb0[i][j] + dyn;
         const unsigned sbase = sb0 + dyn;
-        u32x4 c1[2][8];                                      // row constants [qb][{lse x4, delta x4}]
-        u32x4 ra[4], rb_[4];                                 // row fragments {Q ks, dO ks, Q ks+1, dO ks+1}
-        u32x4 ta[4], tc[4];                                  // transposed fragments {dO^T db0, dO^T db1, Q^T db0, Q^T db1} of one q-step
-        f32x16 s[2], dp[2];
+        u32x4 c1[2][4];                                      // row constants [qb][{lse qi0, delta qi0, lse qi1, delta qi1}]
+        u32x4 ra[4], rb_[4];                                 // row fragments of one 16-query tile {Q ks0, dO ks0, Q ks1, dO ks1}
+        u32x4 ta[4], tc[4];                                  // transposed fragments {dO^T di, dO^T di+1, Q^T di, Q^T di+1}
+        f32x4 s[2][2][2], dp[2][2][2];                       // [qb][qi][ki]
         auto stats = [&](auto qb_tag) {
             constexpr int QB = decltype(qb_tag)::value, O = SB + QB * 128;
-            ldsr128<O>(c1[QB][0], sbase); ldsr128<O + 32>(c1[QB][1], sbase); ldsr128<O + 64>(c1[QB][2], sbase); ldsr128<O + 96>(c1[QB][3], sbase);
-            ldsr128<O + 256>(c1[QB][4], sbase); ldsr128<O + 288>(c1[QB][5], sbase); ldsr128<O + 320>(c1[QB][6], sbase); ldsr128<O + 352>(c1[QB][7], sbase);
+            ldsr128<O>(c1[QB][0], sbase); ldsr128<O + 256>(c1[QB][1], sbase);
+            ldsr128<O + 64>(c1[QB][2], sbase); ldsr128<O + 320>(c1[QB][3], sbase);
         };
-        auto rows = [&](u32x4 (&r)[4], auto qb_tag, auto half_tag) {
+        auto rows = [&](u32x4 (&r)[4], auto qb_tag, auto qi_tag) {
+            constexpr int OFF = SB + decltype(qb_tag)::value * 4096 + decltype(qi_tag)::value * 2048;
+            ldsr128<OFF>(r[0], rbase[0]);
+            ldsr128<OFF + 8192>(r[1], rbase[0]);
+            ldsr128<OFF>(r[2], rbase[1]);
+            ldsr128<OFF + 8192>(r[3], rbase[1]);
+        };
+        auto trs = [&](u32x4 (&f)[4], auto qb_tag, auto half_tag) {
             constexpr int OFF = SB + decltype(qb_tag)::value * 4096, HF = decltype(half_tag)::value;
-            ldsr128<OFF>(r[0], rbase[2 * HF]);
-            ldsr128<OFF + 8192>(r[1], rbase[2 * HF]);
-            ldsr128<OFF>(r[2], rbase[2 * HF + 1]);
-            ldsr128<OFF + 8192>(r[3], rbase[2 * HF + 1]);
+            trR_issue<OFF + 8192>(f[0], tb[2 * HF][0], tb[2 * HF][1]);
+            trR_issue<OFF + 8192>(f[1], tb[2 * HF + 1][0], tb[2 * HF + 1][1]);
+            trR_issue<OFF>(f[2], tb[2 * HF][0], tb[2 * HF][1]);
+            trR_issue<OFF>(f[3], tb[2 * HF + 1][0], tb[2 * HF + 1][1]);
         };
-        auto trs = [&](u32x4 (&f)[4], auto qb_tag, auto sp_tag) {
-            constexpr int OFF = SB + decltype(qb_tag)::value * 4096 + decltype(sp_tag)::value * 2048;
-            trR_issue<OFF + 8192>(f[0], tb[0][0], tb[0][1]);
-            trR_issue<OFF + 8192>(f[1], tb[1][0], tb[1][1]);
-            trR_issue<OFF>(f[2], tb[0][0], tb[0][1]);
-            trR_issue<OFF>(f[3], tb[1][0], tb[1][1]);
-        };
-        auto sdp = [&](u32x4 (&r)[4], int qb, int half) {
+        auto sdp = [&](u32x4 (&r)[4], int qb, int qi) {           // 8 MFMAs: both key tiles, both k-steps; constants enter as C of ks = 0
+            const f32x4 cl = __builtin_bit_cast(f32x4, c1[qb][2 * qi]), cd = __builtin_bit_cast(f32x4, c1[qb][2 * qi + 1]);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                s[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, r[2 * i]), kf[2 * half + i], s[qb], 0, 0, 0);
-                dp[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, r[2 * i + 1]), vf[2 * half + i], dp[qb], 0, 0, 0);
+            for (int ki = 0; ki < 2; ++ki) {
+                s[qb][qi][ki] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, r[0]), kf[ki][0], cl, 0, 0, 0);
+                dp[qb][qi][ki] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, r[1]), vf[ki][0], cd, 0, 0, 0);
+            }
+#pragma unroll
+            for (int ki = 0; ki < 2; ++ki) {
+                s[qb][qi][ki] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, r[2]), kf[ki][1], s[qb][qi][ki], 0, 0, 0);
+                dp[qb][qi][ki] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, r[3]), vf[ki][1], dp[qb][qi][ki], 0, 0, 0);
             }
         };
         auto valu = [&](int qb) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = HS_BWD_EXP2(s[qb][r]);
-                s[qb][r] = p;
-                dp[qb][r] = p * dp[qb][r];
-            }
-        };
-        auto dvdk = [&](u32x4 (&f)[4], int qb, int sp) {
-            const bf16x8 pf = pack8(s[qb], sp), dsf = pack8(dp[qb], sp);
+            for (int qi = 0; qi < 2; ++qi)
 #pragma unroll
-            for (int db = 0; db < 2; ++db) {
-                dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f[db]), pf, dv[db], 0, 0, 0);
-                dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f[2 + db]), dsf, dk[db], 0, 0, 0);
+                for (int ki = 0; ki < 2; ++ki)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float p = HS_BWD_EXP2(s[qb][qi][ki][r]);
+                        s[qb][qi][ki][r] = p;
+                        dp[qb][qi][ki][r] = p * dp[qb][qi][ki][r];
+                    }
+        };
+        auto pack = [&](const f32x4& lo, const f32x4& hi) {       // k-slots 0..3 <- tile qi = 0, 4..7 <- tile qi = 1
+            u32x4 u;
+            u[0] = pack2bf(lo[0], lo[1]); u[1] = pack2bf(lo[2], lo[3]); u[2] = pack2bf(hi[0], hi[1]); u[3] = pack2bf(hi[2], hi[3]);
+            return __builtin_bit_cast(bf16x8, u);
+        };
+        auto dvdk = [&](u32x4 (&f)[4], int qb, int half) {         // 8 MFMAs: d tiles 2half, 2half+1 x both key tiles
+#pragma unroll
+            for (int ki = 0; ki < 2; ++ki) {
+                const bf16x8 pf = pack(s[qb][0][ki], s[qb][1][ki]), dsf = pack(dp[qb][0][ki], dp[qb][1][ki]);
+#pragma unroll
+                for (int d2 = 0; d2 < 2; ++d2) {
+                    dv[2 * half + d2][ki] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, f[d2]), pf, dv[2 * half + d2][ki], 0, 0, 0);
+                    dk[2 * half + d2][ki] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, f[2 + d2]), dsf, dk[2 * half + d2][ki], 0, 0, 0);
+                }
             }
         };
         // never more than 15 LDS reads in flight (lgkmcnt is a 4-bit counter); counts in brackets = in flight after the line
-        stats(I0{});                                                                                 // [8]
-        rows(ra, I0{}, I0{});                                                                        // [12]
-        lds_wait8<4>(c1[0][0], c1[0][1], c1[0][2], c1[0][3], c1[0][4], c1[0][5], c1[0][6], c1[0][7]);
-        s[0] = cat16(c1[0][0], c1[0][1], c1[0][2], c1[0][3]);
-        dp[0] = cat16(c1[0][4], c1[0][5], c1[0][6], c1[0][7]);
+        stats(I0{});                                                                                 // [4]
+        rows(ra, I0{}, I0{});                                                                        // [8]
+        lds_wait4<4>(c1[0][0], c1[0][1], c1[0][2], c1[0][3]);
         rows(rb_, I0{}, I1{});                                                                       // [8]
         lds_wait4<4>(ra[0], ra[1], ra[2], ra[3]);
         sdp(ra, 0, 0);
-        stats(I1{});                                                                                 // [12]
-        lds_wait4<8>(rb_[0], rb_[1], rb_[2], rb_[3]);
+        stats(I1{});                                                                                 // [8]
+        lds_wait4<4>(rb_[0], rb_[1], rb_[2], rb_[3]);
         sdp(rb_, 0, 1);
-        rows(ra, I1{}, I0{});                                                                        // [12]
-        lds_wait8<4>(c1[1][0], c1[1][1], c1[1][2], c1[1][3], c1[1][4], c1[1][5], c1[1][6], c1[1][7]);
-        s[1] = cat16(c1[1][0], c1[1][1], c1[1][2], c1[1][3]);
-        dp[1] = cat16(c1[1][4], c1[1][5], c1[1][6], c1[1][7]);
+        rows(ra, I1{}, I0{});                                                                        // [8]
+        lds_wait4<4>(c1[1][0], c1[1][1], c1[1][2], c1[1][3]);
         rows(rb_, I1{}, I1{});                                                                       // [8]
         valu(0);
         lds_wait4<4>(ra[0], ra[1], ra[2], ra[3]);
@@ -1177,18 +1198,30 @@ __device__ __forceinline__ void attn_bwd_dkdv2_body(const bf16_t* __restrict__ q
     __builtin_amdgcn_s_barrier();
     if (!active) return;
     tile(IR{}, rst);
-    if (key < N) {
-        bf16_t* row = dqkv + ((long)b * N + key) * D3 + head * 64;
-        store_dT(row + Dm, dk, dk_mul, h);
-        store_dT(row + 2 * Dm, dv, 1.0f, h);
+#pragma unroll
+    for (int ki = 0; ki < 2; ++ki) {
+        const int key = k0 + 16 * ki + c;
+        if (key < N) {
+            bf16_t* row = dqkv + ((long)b * N + key) * D3 + head * 64;
+#pragma unroll
+            for (int di = 0; di < 4; ++di) {
+                u32x2 v;
+                v[0] = pack2bf(dk[di][ki][0] * dk_mul, dk[di][ki][1] * dk_mul);
+                v[1] = pack2bf(dk[di][ki][2] * dk_mul, dk[di][ki][3] * dk_mul);
+                *(u32x2*)(row + Dm + 16 * di + 4 * g) = v;
+                v[0] = pack2bf(dv[di][ki][0], dv[di][ki][1]);
+                v[1] = pack2bf(dv[di][ki][2], dv[di][ki][3]);
+                *(u32x2*)(row + 2 * Dm + 16 * di + 4 * g) = v;
+            }
+        }
     }
 }
 
-// (thin non-template kernels: hipcc's host pass silently dropped the launch stub of the templated __global__ form)
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv2_w4_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
-                                                                  const float* __restrict__ ws, bf16_t* __restrict__ dqkv, int B,
-                                                                  int N, int H, float kmul, float dk_mul) {
-    attn_bwd_dkdv2_body<4>(qkv, d_o, ws, dqkv, B, N, H, kmul, dk_mul);
+// (thin non-template kernel: hipcc's host pass silently dropped the launch stub of the templated __global__ form)
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv16_w4_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
+                                                                   const float* __restrict__ ws, bf16_t* __restrict__ dqkv, int B,
+                                                                   int N, int H, float kmul, float dk_mul) {
+    attn_bwd_dkdv16_body<4>(qkv, d_o, ws, dqkv, B, N, H, kmul, dk_mul);
 }
 
 extern "C" int hs_attn_fwd(const void* qkv, void* o, float* lse, int B, int N, int H, int dh, int prec, int flags, void* stream) {
@@ -1268,7 +1301,7 @@ extern "C" int hs_attn_bwd(const void* qkv, const void* o, const void* d_o, cons
     dim3 grid((unsigned)(((N + 127) / 128) * H * B));
     {
         ProfScope prof(HS_PROF_ATTN_DKDV, stream, 6.0 * nn, 6 * io);
-        hipLaunchKernelGGL(attn_bwd_dkdv2_w4_kernel, grid, dim3(256), 0, s, (const bf16_t*)qkv, (const bf16_t*)d_o, nstat,
+        hipLaunchKernelGGL(attn_bwd_dkdv16_w4_kernel, grid, dim3(256), 0, s, (const bf16_t*)qkv, (const bf16_t*)d_o, nstat,
                            (bf16_t*)dqkv, B, N, H, c2, dk_mul);
     }
     {
