@@ -793,6 +793,14 @@ __device__ __forceinline__ f32x16 splat16(float v) {
     return z;
 }
 
+// Image R16: the same [rows][64 bf16] tile with the swizzle the 16x16x32 operand maps need: 16-B chunk c of row r at chunk
+// c ^ (r & 6).  ds_read_b128 of the 16-row x 4-chunk operand: a hardware lane group {0-3,12-15,20-27} (and its three siblings) holds
+// rows {0-3,12-15} with chunk k and rows {4-11} with chunk k^1; slot = 8(r&1) + (chunk ^ (r&6)) is then a bijection onto the 16
+// 16-B slots of the bank row.  ds_read_b64_tr_b16 (banking per 32-lane half = 8 rows x two chunks 2di, 2di+1): rows of one parity
+// land on the four chunk pairs di ^ ((r>>1)&3).  Both conflict-free (SQ_LDS_BANK_CONFLICT = 0); with swzR the row read was 2-way.
+__device__ __forceinline__ int swz16(int r) { return r & 6; }
+__device__ __forceinline__ int offR16(int r, int c) { return r * 128 + ((c ^ swz16(r)) << 4); }
+
 // dQ v2: NW waves x 32 queries per block; K/V tiles by LDS-DMA (3-stage ring, prefetch distance 2).  Per 32-key block:
 // S'^T = K q'^T + (-lse*log2e), dP'^T = V dO^T + (-delta)  (row constants = splat accumulators, loop-invariant here),
 // dS^T = exp2(S'^T) * dP'^T -> bf16 -> dQ^T[d][q] += K^T dS^T (K read transposed from the same image).
@@ -964,14 +972,6 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void attn_bwd_dq2_kernel(
     const int query = q0 + c;
     if (query < N) store_dT(dqkv + ((long)b * N + query) * D3 + head * 64, dq, out_mul, h);
 }
-
-// Image R16: the same [rows][64 bf16] tile with the swizzle the 16x16x32 operand maps need: 16-B chunk c of row r at chunk
-// c ^ (r & 6).  ds_read_b128 of the 16-row x 4-chunk operand: a hardware lane group {0-3,12-15,20-27} (and its three siblings) holds
-// rows {0-3,12-15} with chunk k and rows {4-11} with chunk k^1; slot = 8(r&1) + (chunk ^ (r&6)) is then a bijection onto the 16
-// 16-B slots of the bank row.  ds_read_b64_tr_b16 (banking per 32-lane half = 8 rows x two chunks 2di, 2di+1): rows of one parity
-// land on the four chunk pairs di ^ ((r>>1)&3).  Both conflict-free (SQ_LDS_BANK_CONFLICT = 0); with swzR the row read was 2-way.
-__device__ __forceinline__ int swz16(int r) { return r & 6; }
-__device__ __forceinline__ int offR16(int r, int c) { return r * 128 + ((c ^ swz16(r)) << 4); }
 
 // dK, dV: NW waves x 32 keys per block (K, V fragments and the dK^T, dV^T accumulators stay in registers), sweeping the queries in
 // 64-row tiles that arrive by LDS-DMA: Q' image | dO image | -lse*log2e [64] | -delta [64] per stage, 3-stage ring.  Per 32-query
