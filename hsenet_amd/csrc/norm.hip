@@ -74,14 +74,16 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 // through LDS and issues one float atomic per column.
 // NCH = 256-column chunks per row actually used (d <= NCH*256): sizes the register arrays and the LDS reduction
 // buffer, which set the occupancy of this HBM-bound kernel (NCH=4 for every d cost 200 VGPRs / 48 KiB: 2 waves/SIMD).
-template <bool DYBF, int NCH>
-__global__ __launch_bounds__(256, 4) void layernorm_bwd_kernel(const void* __restrict__ dy_, const float* __restrict__ x,
+// WPB = waves per block: 4, or 8 for small row counts (one volume per GPU: 4097 rows) where a wave's rows are a serial chain of
+// load latencies -- 16 rows per block then take 2 steps per wave instead of 4 while the block's 3 x d reduction atomics stay the same.
+template <bool DYBF, int NCH, int WPB = 4>
+__global__ __launch_bounds__(WPB * 64, 16 / WPB) void layernorm_bwd_kernel(const void* __restrict__ dy_, const float* __restrict__ x,
                                                             const float* __restrict__ resid, const float* __restrict__ gamma,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ dx_in, float* __restrict__ dx,
                                                             bf16_t* __restrict__ dxb, float* __restrict__ dgamma,
                                                             float* __restrict__ dbeta, float* __restrict__ dxsum, int rows, int d) {
-    __shared__ float red[3][4][NCH * 256];
+    __shared__ float red[3][WPB][NCH * 256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nch = d >> 2;
     f32x4 g[NCH], dg[NCH], db[NCH], ds[NCH];
@@ -92,14 +94,18 @@ __global__ __launch_bounds__(256, 4) void layernorm_bwd_kernel(const void* __res
         for (int e = 0; e < 4; ++e) { dg[i][e] = 0.f; db[i][e] = 0.f; g[i][e] = 0.f; ds[i][e] = 0.f; }
         if (ch < nch) g[i] = *(const f32x4*)(gamma + ch * 4);
     }
-    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
-        const float mu = mean[row], rs = rstd[row];
-        f32x4 xh[NCH], gy[NCH];
-        float s1 = 0.f, s2 = 0.f;
+    // (WPB = 8) two rows per trip: both rows' operands are requested before either is reduced, so a wave's serial chain is half as
+    // many memory round trips (it matters at 4097 rows, where a wave owns 4 rows; at 81 940 the kernel is bandwidth-bound either way)
+    struct Row { f32x4 xh[NCH], gy[NCH], di[NCH]; float s1, s2, rs; };
+    auto phase1 = [&](int row, Row& R) {
+        const float mu = mean[row];
+        R.rs = rstd[row];
+        R.s1 = 0.f; R.s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int ch = lane + 64 * i;
             if (ch < nch) {
+                R.di[i] = dx_in ? *(const f32x4*)(dx_in + (long)row * d + ch * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
                 f32x4 xv = *(const f32x4*)(x + (long)row * d + ch * 4);
                 if (resid) xv += *(const f32x4*)(resid + (long)row * d + ch * 4);
                 f32x4 dv;
@@ -112,24 +118,26 @@ __global__ __launch_bounds__(256, 4) void layernorm_bwd_kernel(const void* __res
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    xh[i][e] = (xv[e] - mu) * rs;
-                    gy[i][e] = dv[e] * g[i][e];
-                    s1 += gy[i][e];
-                    s2 += gy[i][e] * xh[i][e];
-                    dg[i][e] += dv[e] * xh[i][e];
+                    R.xh[i][e] = (xv[e] - mu) * R.rs;
+                    R.gy[i][e] = dv[e] * g[i][e];
+                    R.s1 += R.gy[i][e];
+                    R.s2 += R.gy[i][e] * R.xh[i][e];
+                    dg[i][e] += dv[e] * R.xh[i][e];
                     db[i][e] += dv[e];
                 }
             }
         }
-        const float c1 = wave_sum(s1) / d, c2 = wave_sum(s2) / d;
+    };
+    auto phase2 = [&](int row, const Row& R) {
+        const float c1 = wave_sum(R.s1) / d, c2 = wave_sum(R.s2) / d;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int ch = lane + 64 * i;
             if (ch < nch) {
                 f32x4 o;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = rs * (gy[i][e] - c1 - xh[i][e] * c2);
-                if (dx_in) o += *(const f32x4*)(dx_in + (long)row * d + ch * 4);
+                for (int e = 0; e < 4; ++e) o[e] = R.rs * (R.gy[i][e] - c1 - R.xh[i][e] * c2);
+                o += R.di[i];
                 ds[i] += o;
                 if (dx) *(f32x4*)(dx + (long)row * d + ch * 4) = o;
                 if (dxb) {
@@ -137,6 +145,68 @@ __global__ __launch_bounds__(256, 4) void layernorm_bwd_kernel(const void* __res
                     pk[0] = pack2bf(o[0], o[1]);
                     pk[1] = pack2bf(o[2], o[3]);
                     *(u32x2*)(dxb + (long)row * d + ch * 4) = pk;
+                }
+            }
+        }
+    };
+    const int stride = gridDim.x * WPB;
+    if constexpr (WPB == 8) {            // the few-rows variant: registers for two rows in flight (one block of 8 waves per CU)
+        for (int row = blockIdx.x * WPB + wave; row < rows; row += 2 * stride) {
+            Row A, Bq;
+            const int row_b = row + stride;
+            phase1(row, A);
+            if (row_b < rows) phase1(row_b, Bq);
+            phase2(row, A);
+            if (row_b < rows) phase2(row_b, Bq);
+        }
+    } else {                             // one row per trip, written out (through the lambdas hipcc spills at the 128-register budget)
+        for (int row = blockIdx.x * WPB + wave; row < rows; row += stride) {
+            const float mu = mean[row], rs = rstd[row];
+            f32x4 xh[NCH], gy[NCH], di[NCH];
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const int ch = lane + 64 * i;
+                if (ch < nch) {
+                    di[i] = dx_in ? *(const f32x4*)(dx_in + (long)row * d + ch * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    f32x4 xv = *(const f32x4*)(x + (long)row * d + ch * 4);
+                    if (resid) xv += *(const f32x4*)(resid + (long)row * d + ch * 4);
+                    f32x4 dv;
+                    if (DYBF) {
+                        const u32x2 pk = *(const u32x2*)((const bf16_t*)dy_ + (long)row * d + ch * 4);
+                        dv[0] = __uint_as_float(pk[0] << 16); dv[1] = __uint_as_float(pk[0] & 0xffff0000u);
+                        dv[2] = __uint_as_float(pk[1] << 16); dv[3] = __uint_as_float(pk[1] & 0xffff0000u);
+                    } else {
+                        dv = *(const f32x4*)((const float*)dy_ + (long)row * d + ch * 4);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        xh[i][e] = (xv[e] - mu) * rs;
+                        gy[i][e] = dv[e] * g[i][e];
+                        s1 += gy[i][e];
+                        s2 += gy[i][e] * xh[i][e];
+                        dg[i][e] += dv[e] * xh[i][e];
+                        db[i][e] += dv[e];
+                    }
+                }
+            }
+            const float c1 = wave_sum(s1) / d, c2 = wave_sum(s2) / d;
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const int ch = lane + 64 * i;
+                if (ch < nch) {
+                    f32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = rs * (gy[i][e] - c1 - xh[i][e] * c2);
+                    o += di[i];
+                    ds[i] += o;
+                    if (dx) *(f32x4*)(dx + (long)row * d + ch * 4) = o;
+                    if (dxb) {
+                        u32x2 pk;
+                        pk[0] = pack2bf(o[0], o[1]);
+                        pk[1] = pack2bf(o[2], o[3]);
+                        *(u32x2*)(dxb + (long)row * d + ch * 4) = pk;
+                    }
                 }
             }
         }
@@ -151,10 +221,10 @@ __global__ __launch_bounds__(256, 4) void layernorm_bwd_kernel(const void* __res
             red[2][wave][(lane + 64 * i) * 4 + e] = ds[i][e];
         }
     __syncthreads();
-    for (int col = threadIdx.x; col < d; col += 256) {
-        const float a = red[0][0][col] + red[0][1][col] + red[0][2][col] + red[0][3][col];
-        const float b = red[1][0][col] + red[1][1][col] + red[1][2][col] + red[1][3][col];
-        const float c = red[2][0][col] + red[2][1][col] + red[2][2][col] + red[2][3][col];
+    for (int col = threadIdx.x; col < d; col += WPB * 64) {
+        float a = 0.f, b = 0.f, c = 0.f;
+#pragma unroll
+        for (int w = 0; w < WPB; ++w) { a += red[0][w][col]; b += red[1][w][col]; c += red[2][w][col]; }
         if (dgamma) atomicAdd(&dgamma[col], a);
         if (dbeta) atomicAdd(&dbeta[col], b);
         if (dxsum) atomicAdd(&dxsum[col], c);     // column sums of the produced dx: the bias gradient of the Linear
@@ -183,11 +253,21 @@ extern "C" int hs_layernorm_bwd(const void* dy, int dy_is_bf16, const float* x, 
     int blocks = (rows + 3) / 4;
     if (blocks > 2048) blocks = 2048;
     if (rows / 16 >= 256 && (rows + 15) / 16 < blocks) blocks = (rows + 15) / 16;
+    // few rows (one or two volumes per GPU): the block's 3 x d float atomics onto the SAME 3 x d addresses from every block are the
+    // serial part (257 blocks at 4097 rows) -- 8 waves x 4 rows per block halve the block count at the same per-wave chain
+    const bool wide = blocks * 16 >= rows && rows / 32 >= 128 && d <= 768;
+    if (wide) blocks = (rows + 31) / 32;
     ProfScope prof(HS_PROF_LN_BWD, stream, 0, (double)rows * d * (4 + (dy_is_bf16 ? 2 : 4) + (resid ? 4 : 0) + (dx_in ? 4 : 0) + (dx ? 4 : 0) + (dx_bf16 ? 2 : 0)));
     const int nchunks = (d + 255) / 256;
 #define HS_LN_BWD(DYBF, NCH)                                                                                              \
-    hipLaunchKernelGGL((layernorm_bwd_kernel<DYBF, NCH>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, x, resid, gamma, \
-                       mean, rstd, dx_in, dx, (bf16_t*)dx_bf16, dgamma, dbeta, dxsum, rows, d)
+    do {                                                                                                                  \
+        if (wide && NCH <= 3)                                                                                             \
+            hipLaunchKernelGGL((layernorm_bwd_kernel<DYBF, (NCH <= 3 ? NCH : 1), 8>), dim3(blocks), dim3(512), 0, (hipStream_t)stream, dy, x, \
+                               resid, gamma, mean, rstd, dx_in, dx, (bf16_t*)dx_bf16, dgamma, dbeta, dxsum, rows, d);      \
+        else                                                                                                              \
+            hipLaunchKernelGGL((layernorm_bwd_kernel<DYBF, NCH>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, x, resid, gamma, \
+                               mean, rstd, dx_in, dx, (bf16_t*)dx_bf16, dgamma, dbeta, dxsum, rows, d);                    \
+    } while (0)
     if (dy_is_bf16) {
         if (nchunks == 1) HS_LN_BWD(true, 1); else if (nchunks == 2) HS_LN_BWD(true, 2); else if (nchunks == 3) HS_LN_BWD(true, 3); else HS_LN_BWD(true, 4);
     } else {
