@@ -277,8 +277,8 @@ def test_attn_bwd_full_length_vs_fp64(dev, N):
     assert max(errs) < 1.5e-2 and worst_head < 2e-2
 
 
-@pytest.mark.parametrize("rows,d", [(5, 768), (1030, 768), (64, 384), (7, 1024)])
-def test_layernorm(dev, rows, d):
+@pytest.mark.parametrize("rows,d", [(5, 768), (1030, 768), (64, 384), (7, 1024), (4097, 768), (8200, 384)])   # last two: the few-rows
+def test_layernorm(dev, rows, d):                                                                               # backward (8 waves, row pairs)
     from hsenet_amd import functional as Fn, _lib as L
     x, r = rnd((rows, d), 50, dev, 2.0) + 0.3, rnd((rows, d), 51, dev)
     g, b = 1 + 0.1 * rnd((d,), 52, dev), rnd((d,), 53, dev)
@@ -296,9 +296,10 @@ def test_layernorm(dev, rows, d):
     assert rel(g.grad, gg) < 1e-5 and rel(b.grad, gb) < 1e-5
 
 
-def test_layernorm_bwd_bf16_dy_and_colsum(dev):
+@pytest.mark.parametrize("rows", [777, 4097, 12290])          # 4 waves x 1 row / the few-rows variant (odd row count, ragged pairs)
+def test_layernorm_bwd_bf16_dy_and_colsum(dev, rows):
     from hsenet_amd import functional as Fn, _lib as L
-    rows, d = 777, 768
+    d = 768
     x, g, b = rnd((rows, d), 55, dev, 2.0), 1 + 0.1 * rnd((d,), 56, dev), rnd((d,), 57, dev)
     dyb, dx_in = rnd((rows, d), 58, dev).bfloat16(), rnd((rows, d), 59, dev)
     _, _, mean, rstd = Fn.layernorm_fwd(x, g, b)
