@@ -99,6 +99,7 @@ class ClipStage2Engine(_Engine):
         self.dall = torch.empty(n, d, **f32)
         self.acc = torch.zeros(4, **f32)                           # [CE loss, sum(dlogits*logits), relation MSE, -]
         self.global_step = 0
+        self._txt1 = self._txt2 = None
         self.side = torch.cuda.Stream(device=self.dev)
 
     # ------------------------------------------------------------------------------------------------------------------------
@@ -114,8 +115,9 @@ class ClipStage2Engine(_Engine):
 
     def forward_loss(self, images, images_2d, text_features_stage1, text_features) -> None:
         """everything up to dL/dlogits (kept in self.dlog); loss pieces accumulate in self.acc."""
-        Fn._need(text_features_stage1, text_features)
         s, d, B = Fn._s(), self.u2.d, self.B
+        for nm, t in (("text_features_stage1", text_features_stage1), ("text_features", text_features)):
+            Fn._need_as(t, nm, (B, d))              # hs_rows_copy reads B*d fp32 values through the raw pointer
         self._patchify(images, self.model.vision_encoder.patch_embedding, self.patches)
         # the frozen tower on a side stream: independent of the 2E3 forward until the logits
         self.side.wait_stream(torch.cuda.current_stream())
@@ -162,7 +164,9 @@ class ClipStage2Engine(_Engine):
         self.buckets.wait()
 
     def train_step(self, images, images_2d, text_features_stage1=None, text_features=None) -> None:
-        if text_features_stage1 is None:
+        if text_features_stage1 is None or text_features is None:
+            if self._txt1 is None:
+                raise L.HsError("train_step(images, images_2d) needs set_text_features() first (or pass both text feature tensors)")
             text_features_stage1, text_features = self._txt1, self._txt2
         self.forward_loss(images, images_2d, text_features_stage1, text_features)
         self.backward()
@@ -171,4 +175,12 @@ class ClipStage2Engine(_Engine):
 
     def set_text_features(self, text_features_stage1: torch.Tensor, text_features: torch.Tensor) -> None:
         """frozen text embeddings reused by every ``train_step(images, images_2d)`` call (bench.py)."""
-        self._txt1, self._txt2 = text_features_stage1.contiguous(), text_features.contiguous()
+        B, d = self.B, self.u2.d
+        txt = []
+        for nm, t in (("text_features_stage1", text_features_stage1), ("text_features", text_features)):
+            if not isinstance(t, torch.Tensor) or tuple(t.shape) != (B, d):
+                raise L.HsError(f"{nm} must be a [B={B}, {d}] tensor")
+            t = t.detach().to(device=self.dev, dtype=torch.float32).contiguous()      # an autocast text tower hands over bf16 / fp16
+            Fn._need_as(t, nm, (B, d))
+            txt.append(t)
+        self._txt1, self._txt2 = txt

@@ -1247,7 +1247,7 @@ extern "C" int hs_attn_fwd(const void* qkv, void* o, float* lse, int B, int N, i
             // optimistic kernel, then the guarded exact kernel over the blocks it flagged (normally none: one load + exit)
             dim3 grid2((unsigned)(((N + 255) / 256) * H * B));
             hipLaunchKernelGGL(attn_fwd_fast_kernel, grid2, dim3(256), 0, s, (const bf16_t*)qkv, (bf16_t*)o, lse, N, H, c2);
-            if (g_hs_dbg[0] != 2)
+            if (HS_DBG(g_hs_dbg[0]) != 2)         // (2 = timing-only: no fix-up pass; hook builds only)
                 hipLaunchKernelGGL(attn_fwd_bf16_kernel<true>, grid1, dim3(256), 0, s, (const bf16_t*)qkv, (bf16_t*)o, lse, N, H, c2);
         }
     } else if (prec == HS_PREC_F32) {

@@ -152,6 +152,13 @@ struct ProfScope {
 };
 
 extern int g_hs_dbg[8];   // diagnostic variant selectors (prof.hip: hs_debug_set)
+// Result-changing / timing-only kernel variants and the s_memtime stamps exist only in builds made with -DHS_DEBUG_HOOKS
+// (tools/build_variant.sh for tools/kbench); in the product library the selector is the constant 0 and the branches fold away.
+#ifdef HS_DEBUG_HOOKS
+#define HS_DBG(x) (x)
+#else
+#define HS_DBG(x) 0
+#endif
 
 #define HS_CHECK_LAUNCH()                                   \
     do {                                                    \

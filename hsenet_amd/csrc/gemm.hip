@@ -25,8 +25,9 @@ struct GemmP {
     int gm;                                // row tiles per group of the tile order (chosen by hs_gemm, see tile_order)
     // diagnostic (tools/kbench, HS_GEMM_DBG): 1 = skip the epilogue, 2 = one K-tile only, 3 = epilogue without its stores, 4 = s_memtime
     // phase sums (hs_debug_gemm_stamps), 5 = every K-tile re-reads the first (cache hits), 7 = 3 + 4, 22 = per-block timeline
-    // (hs_debug_gemm_trace).  0 in production.
-    int dbg;
+    // (hs_debug_gemm_trace).  Compiled in only under -DHS_DEBUG_HOOKS (tools/build_variant.sh): in the product build HS_DBG(x) is the
+    // constant 0, every variant branch folds away and the field is never read.
+    int dbg_;
 };
 
 template <bool F32AUX>
@@ -365,7 +366,7 @@ __device__ __forceinline__ void big_mainloop(f32x16 (&acc)[4][2], char* smem, in
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(fa[S][i]), as_frag(fb[S][j]), acc[i][j], 0, 0, 0);
     };
     auto dma = [&](int kt, unsigned so, int q0) {          // pieces q0 .. q0+3 of tile kt (0-3: A, 4-7: B)
-        if (dbg == 5) kt = kt0;                              // diagnostic: every tile re-reads the first one (cache hits)
+        if (HS_DBG(dbg) == 5) kt = kt0;                              // diagnostic: every tile re-reads the first one (cache hits)
         char* sa = smem + so;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -487,20 +488,20 @@ __device__ __forceinline__ void big_mainloop16(f32x4 (&acc)[8][4], char* smem, i
         rdA(I1{}, I1{}, I1{}, so);
         lds_wait8g<4>(fa[0][0], fa[0][1], fa[0][2], fa[0][3], fb[1][0], fb[1][1], fb[1][2], fb[1][3]);
         mma(I0{}, I1{}, I0{});
-        unsigned long long t0_ = dbg == 4 ? __builtin_amdgcn_s_memtime() : 0ull;
+        unsigned long long t0_ = HS_DBG(dbg) == 4 ? __builtin_amdgcn_s_memtime() : 0ull;
         lds_wait4<0>(fa[1][0], fa[1][1], fa[1][2], fa[1][3]);       // every read of this stage has landed
-        unsigned long long t1_ = dbg == 4 ? __builtin_amdgcn_s_memtime() : 0ull;
+        unsigned long long t1_ = HS_DBG(dbg) == 4 ? __builtin_amdgcn_s_memtime() : 0ull;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        unsigned long long t15_ = dbg == 4 ? __builtin_amdgcn_s_memtime() : 0ull;
+        unsigned long long t15_ = HS_DBG(dbg) == 4 ? __builtin_amdgcn_s_memtime() : 0ull;
         __builtin_amdgcn_s_barrier();
-        if (dbg == 4) { const unsigned long long t2_ = __builtin_amdgcn_s_memtime(); t_lds += t1_ - t0_; t_sync += t2_ - t15_; t_vm += t15_ - t1_; }
+        if (HS_DBG(dbg) == 4) { const unsigned long long t2_ = __builtin_amdgcn_s_memtime(); t_lds += t1_ - t0_; t_sync += t2_ - t15_; t_vm += t15_ - t1_; }
         // phase 3: (step 1, rows 64-127) || first fragments of the next tile
         if (has1) { rdA(I0{}, I0{}, I0{}, so1); rdB(I0{}, I0{}, so1); }
         mma(I1{}, I1{}, I1{});
         if (has2) dma(kt + 2, so, 0);
         so = so1;
     }
-    if (dbg == 4 && threadIdx.x == 0) { atomicAdd(&g_gemm_stamps[5], t_sync); atomicAdd(&g_gemm_stamps[6], t_lds); atomicAdd(&g_gemm_stamps[7], t_vm); }
+    if (HS_DBG(dbg) == 4 && threadIdx.x == 0) { atomicAdd(&g_gemm_stamps[5], t_sync); atomicAdd(&g_gemm_stamps[6], t_lds); atomicAdd(&g_gemm_stamps[7], t_vm); }
 }
 
 // diagnostic (dbg == 4): per-phase cycle sums of the epilogue, wave 0 lane 0 of every block (tools/kbench)
@@ -513,8 +514,8 @@ __device__ unsigned long long g_gemm_trace[4 * 4096];
 extern "C" void hs_debug_gemm_trace(unsigned long long* out, int nblocks) {
     (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gemm_trace), sizeof(unsigned long long) * 4 * (nblocks < 4096 ? nblocks : 4096));
 }
-#define TRACE(i) do { if (p.dbg == 22 && threadIdx.x == 0 && blockIdx.x < 4096) g_gemm_trace[blockIdx.x * 4 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
-#define STAMP(i) do { if (p.dbg == 4 || p.dbg == 7) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0) atomicAdd(&g_gemm_stamps[i], t_ - t_prev); t_prev = t_; } } while (0)
+#define TRACE(i) do { if (HS_DBG(p.dbg_) == 22 && threadIdx.x == 0 && blockIdx.x < 4096) g_gemm_trace[blockIdx.x * 4 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define STAMP(i) do { if (HS_DBG(p.dbg_) == 4 || HS_DBG(p.dbg_) == 7) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0) atomicAdd(&g_gemm_stamps[i], t_ - t_prev); t_prev = t_; } } while (0)
 
 // (asm with register constraints lives in __device__ helpers, never directly in a templated __global__ body: hipcc's
 // host pass then silently drops the kernel's launch stub)
@@ -622,7 +623,7 @@ static_assert(EF >= 0, "the 16x16x32 kernels are launched with compile-time epil
 #pragma unroll
         for (int ii = 0; ii < 2; ++ii) {
             const int i = 2 * g + ii, s0 = 2 * ii, s1 = 2 * ii + 1;
-            if (p.dbg == 3 || p.dbg == 7) { keep4(vlo[s0]); keep4(vhi[s0]); keep4(vlo[s1]); keep4(vhi[s1]); continue; }
+            if (HS_DBG(p.dbg_) == 3 || HS_DBG(p.dbg_) == 7) { keep4(vlo[s0]); keep4(vhi[s0]); keep4(vlo[s1]); keep4(vhi[s1]); continue; }
             if (p.out_f32) {   // fp32 rows are full lines already (8 columns x 4 B x 4 lanes)
 #pragma unroll
                 for (int st = s0; st <= s1; ++st)
@@ -704,8 +705,8 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmP& p, const int b_, con
         kt1 = min(kt_total, kt0 + per);
         if (kt0 >= kt1) return;
     }
-    if (p.dbg == 2) kt1 = kt0 + 1;
-    unsigned long long t_prev = (p.dbg == 4 || p.dbg == 7) ? __builtin_amdgcn_s_memtime() : 0ull;
+    if (HS_DBG(p.dbg_) == 2) kt1 = kt0 + 1;
+    unsigned long long t_prev = (HS_DBG(p.dbg_) == 4 || HS_DBG(p.dbg_) == 7) ? __builtin_amdgcn_s_memtime() : 0ull;
     f32x16 acc[C::MB][2];
 #pragma unroll
     for (int i = 0; i < C::MB; ++i)
@@ -744,12 +745,12 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmP& p, const int b_, con
     };
     STAMP(0);     // setup
     TRACE(0);
-    if (p.dbg == 22 && threadIdx.x == 0 && blockIdx.x < 4096)
+    if (HS_DBG(p.dbg_) == 22 && threadIdx.x == 0 && blockIdx.x < 4096)
         g_gemm_trace[blockIdx.x * 4 + 3] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
     if constexpr (M16) {
-        big_mainloop16(acc16, smem, row0, col0, wave, lane, rsA, rsB, va, vb, ka, kb, kt0, kt1, p.dbg == 7 ? 4 : p.dbg);
+        big_mainloop16(acc16, smem, row0, col0, wave, lane, rsA, rsB, va, vb, ka, kb, kt0, kt1, HS_DBG(p.dbg_) == 7 ? 4 : HS_DBG(p.dbg_));
     } else if constexpr (BIG) {
-        big_mainloop<BTR>(acc, smem, row0, col0, wave, lane, rsA, rsB, va, vb, ka, kb, kt0, kt1, p.dbg);
+        big_mainloop<BTR>(acc, smem, row0, col0, wave, lane, rsA, rsB, va, vb, ka, kb, kt0, kt1, HS_DBG(p.dbg_));
     } else {
     // ring: prefetch distance D = NSTAGE-1 tiles.  At step kt: wait until tile kt has landed (D-1 newer tiles may stay
     // in flight: counted vmcnt), barrier, then issue tile kt+D into the stage every wave finished reading before
@@ -789,7 +790,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmP& p, const int b_, con
     TRACE(1);
     __builtin_amdgcn_s_barrier();     // every wave is done reading the operand stages
     STAMP(2);     // post-loop barrier
-    if (p.dbg == 1) {
+    if (HS_DBG(p.dbg_) == 1) {
 #pragma unroll
         for (int i = 0; i < C::MB; ++i) { keep_alive(acc[i][0]); keep_alive(acc[i][1]); }
 #pragma unroll
@@ -873,7 +874,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmP& p, const int b_, con
                     }
 #pragma clang loop unroll(full)
                     for (int i = 0; i < GS; ++i)
-                        if (in[i] && (p.dbg == 3 || p.dbg == 7)) { keep4(vlo[i]); keep4(vhi[i]); }
+                        if (in[i] && (HS_DBG(p.dbg_) == 3 || HS_DBG(p.dbg_) == 7)) { keep4(vlo[i]); keep4(vhi[i]); }
                         else if (in[i]) {
                             u32x4 o;
                             o[0] = pack2bf(vlo[i][0], vlo[i][1]); o[1] = pack2bf(vlo[i][2], vlo[i][3]);
@@ -1138,7 +1139,7 @@ extern "C" int hs_gemm_group(const hs_gemm_args* args, int count, void* stream) 
         p.lda = a->lda; p.ldb = a->ldb; p.sA = 0; p.sB = 0; p.sC = 0; p.ldc = a->ldc;
         p.out_f32 = a->out_f32; p.out_bf16 = nullptr; p.bias = nullptr; p.resid = nullptr; p.aux = nullptr; p.aux_out = nullptr;
         p.colsum = nullptr; p.alpha = a->alpha; p.flags = a->flags; p.split_k = a->split_k;
-        p.scale_cols = 0; p.scale_alpha = 1.0f; p.nt = 0; p.dbg = 0;
+        p.scale_cols = 0; p.scale_alpha = 1.0f; p.nt = 0; p.dbg_ = 0;
         p.tiles_m = (a->M + 255) / 256;
         p.tiles_n = (a->N + 127) / 128;
         p.gm = kEnv.gm > 0 ? kEnv.gm : (p.tiles_n >= 8 ? 4 : 2);
@@ -1182,7 +1183,7 @@ extern "C" int hs_gemm(const hs_gemm_args* a, int prec, void* stream) {
     p.out_f32 = a->out_f32; p.out_bf16 = a->out_bf16; p.bias = a->bias; p.resid = a->resid; p.aux = a->aux;
     p.aux_out = a->aux_out; p.colsum = a->colsum_out; p.alpha = a->alpha; p.flags = a->flags; p.split_k = a->split_k;
     p.scale_cols = a->scale_cols; p.scale_alpha = a->scale_cols_alpha;
-    p.dbg = g_hs_dbg[3];
+    p.dbg_ = HS_DBG(g_hs_dbg[3]);
     p.gm = 0;
     // Output stores of a GEMM whose result cannot stay in the caches anyway are issued as streaming (nontemporal) stores:
     // ordinary stores park 128 KiB of dirty lines per tile in the XCD's 4-MiB L2 -- 32 tiles per round = the whole L2 --

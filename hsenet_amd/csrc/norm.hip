@@ -255,7 +255,9 @@ extern "C" int hs_layernorm_bwd(const void* dy, int dy_is_bf16, const float* x, 
     if (rows / 16 >= 256 && (rows + 15) / 16 < blocks) blocks = (rows + 15) / 16;
     // few rows (one or two volumes per GPU): the block's 3 x d float atomics onto the SAME 3 x d addresses from every block are the
     // serial part (257 blocks at 4097 rows) -- 8 waves x 4 rows per block halve the block count at the same per-wave chain
-    const bool wide = blocks * 16 >= rows && rows / 32 >= 128 && d <= 768;
+    bool wide = blocks * 16 >= rows && rows / 32 >= 128 && d <= 768;
+    if (HS_DBG(g_hs_dbg[5]) == 1) wide = false;                            // (hook builds: A/B of the two variants, tools/ln_bwd_ab.py)
+    if (HS_DBG(g_hs_dbg[5]) == 2) wide = rows / 32 >= 1 && d <= 768;
     if (wide) blocks = (rows + 31) / 32;
     ProfScope prof(HS_PROF_LN_BWD, stream, 0, (double)rows * d * (4 + (dy_is_bf16 ? 2 : 4) + (resid ? 4 : 0) + (dx_in ? 4 : 0) + (dx ? 4 : 0) + (dx_bf16 ? 2 : 0)));
     const int nchunks = (d + 255) / 256;

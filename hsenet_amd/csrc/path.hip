@@ -399,6 +399,9 @@ extern "C" int hs_packer_bwd(const hs_packer_desc* desc, const float* dout, cons
     const int Mt = c.B * T, Mc = c.B * cells;
     const int P = HS_PREC_BF16;
     const bool drop = c.drop_p > 0.f;
+    // dfeat is written as a DENSE [B][in_row_offset + T][d] tensor: a padded input stride would put every batch entry after the
+    // first at the wrong offset, so it is refused (before anything is launched) rather than scattered silently
+    if (dfeat && c.in_batch_stride != (int64_t)(c.in_row_offset + T) * d) return HS_ERR_SHAPE;
     const float *q = (const float*)(w + L.q), *kv = (const float*)(w + L.kv), *xl = (const float*)(w + L.xl), *st = (const float*)(w + L.stats);
     float *dsum = (float*)(w + L.dsum), *dxo = (float*)(w + L.dxo), *dq2 = (float*)(w + L.dq2), *dkv = (float*)(w + L.dkv);
     float *dlr = (float*)(w + L.dlr), *dhr = (float*)(w + L.dhr);

@@ -3,6 +3,7 @@
 // hs_prof_read() is the only entry point in the library that synchronises (hipEventSynchronize), and it is
 // never called from a launch path.
 #include "common.h"
+#include <cstdio>
 #include <vector>
 #include <mutex>
 
@@ -70,7 +71,22 @@ static const char* kNames[HS_PROF_COUNT] = {"gemm_nt", "gemm_nn", "gemm_tn", "at
                                             "attn_bwd_dq", "layernorm_fwd", "layernorm_bwd", "colsum", "cast", "patchify", "other"};
 extern "C" const char* hs_prof_name(int id) { return (id >= 0 && id < HS_PROF_COUNT) ? kNames[id] : ""; }
 
-// Diagnostic knob for kernel A/B work (tools/kbench.cpp): selects a kernel variant per class.  Not part of the public
-// header; every value defaults to 0 = the shipped kernel.
+// Diagnostic knob for kernel A/B work (tools/kbench.cpp): selects a kernel variant per class; every value defaults to 0 = the
+// shipped kernel.  The PRODUCT build accepts only the one selector whose variants compute the same result — key 0, value 1 = the
+// exact running-max attention forward alone (tests compare it with the optimistic kernel) — and refuses everything else with a
+// warning: the timing-only / truncating variants exist only in -DHS_DEBUG_HOOKS builds (tools/build_variant.sh).  Process-global,
+// not thread-safe: set it while no other thread is launching.
 int g_hs_dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-extern "C" void hs_debug_set(int key, int value) { if (key >= 0 && key < 8) g_hs_dbg[key] = value; }
+extern "C" void hs_debug_set(int key, int value) {
+#ifdef HS_DEBUG_HOOKS
+    if (key >= 0 && key < 8) g_hs_dbg[key] = value;
+#else
+    if (key == 0 && (value == 0 || value == 1)) { g_hs_dbg[0] = value; return; }
+    if (value == 0 && key >= 0 && key < 8) return;
+    static bool warned = false;
+    if (!warned) {
+        warned = true;
+        fprintf(stderr, "[hsenet_hip] hs_debug_set(%d, %d) ignored: diagnostic kernel variants are compiled only with -DHS_DEBUG_HOOKS\n", key, value);
+    }
+#endif
+}

@@ -25,6 +25,16 @@ class GradBuckets:
         for a, b in self.bounds:
             if not (0 <= a < b <= flat_grad.numel()):
                 raise ValueError(f"bucket ({a},{b}) outside the flat gradient of {flat_grad.numel()} elements")
+        # the buckets must PARTITION [0, total): an uncovered range would leave those gradients unsynchronised across ranks with no
+        # error, an overlap would sum a range twice
+        pos = 0
+        for a, b in sorted(self.bounds):
+            if a != pos:
+                raise ValueError(f"gradient buckets {'overlap' if a < pos else 'leave a gap'} at element {min(a, pos)}: "
+                                 f"they must partition [0, {flat_grad.numel()})")
+            pos = b
+        if pos != flat_grad.numel():
+            raise ValueError(f"gradient buckets end at {pos}, the flat gradient has {flat_grad.numel()} elements")
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.always = always and dist.is_available() and dist.is_initialized()

@@ -231,10 +231,10 @@ class EncoderUnit:
         if self.scorer:
             if image_2d is None:
                 raise L.HsError("ViT_stage2 needs image_2d (the 2D slice features)")
-            image_2d = image_2d.view(self.B, 32, -1)
-            Fn._need(image_2d)
-            if image_2d.dtype != torch.float32 or image_2d.shape[2] != self.d:
-                raise L.HsError("image_2d must be fp32 [B, 32, hidden]")
+            if not isinstance(image_2d, torch.Tensor) or image_2d.numel() != self.B * 32 * self.d:
+                raise L.HsError(f"image_2d must hold [B={self.B}, 32, hidden={self.d}] slice features")
+            Fn._need(image_2d)                                          # (vit.py:332 views it as (B, 32, -1))
+            Fn._need_as(image_2d.view(self.B, 32, -1), "image_2d", (self.B, 32, self.d))
             _seeds(self.edesc, self.model.training)
         ews, ewb = self._embed_ws()
         L.call("hs_embed_fwd", C.byref(self.edesc), patches.data_ptr(), Fn._p(image_2d) if self.scorer else None, self._ep,
@@ -249,6 +249,7 @@ class EncoderUnit:
         (and, for the last chunk, after the embedding backward) so the caller can launch that range's all-reduce."""
         if not self.trainable:
             raise L.HsError("this encoder unit was built frozen (forward-only)")
+        Fn._need_as(dy, "dy", self.y.shape)
         s = Fn._s()
         for i, (hi, lo) in enumerate(chunks):
             L.call("hs_vit_blocks_bwd", C.byref(self.desc), self.x0.data_ptr(), self._lp, self._np, dy.data_ptr(), self.dx0.data_ptr(),
@@ -386,7 +387,7 @@ class FlatEncoder(_Engine):
         return self.unit.forward(self.patches, image_2d)
 
     def backward(self, dy: torch.Tensor) -> None:
-        Fn._need(dy)
+        Fn._need_as(dy, "dy", self.y.shape)
         self.grad.zero_()
         self.unit.backward(self.patches, dy, self.layer_chunks, self.buckets.reduce)
         self.buckets.wait()
@@ -473,7 +474,7 @@ class DualEngine(_Engine):
         return self.out
 
     def backward(self, dout: torch.Tensor) -> None:
-        Fn._need(dout)
+        Fn._need_as(dout, "dout", self.out.shape)
         self.grad.zero_()
         n2 = len(self.chunks2)
         with self._fork():

@@ -47,6 +47,16 @@ def _need(*ts: Optional[torch.Tensor]) -> None:
             raise L.HsError("hsenet_amd kernels need contiguous tensors")
 
 
+def _need_as(t: torch.Tensor, what: str, shape, dtype=torch.float32) -> None:
+    """entry-point check of a tensor whose raw pointer goes to a kernel that reads prod(shape) elements of `dtype`: a wrong
+    dtype or shape would be an out-of-bounds device read (or silently wrong numbers), not an exception."""
+    if not isinstance(t, torch.Tensor):
+        raise L.HsError(f"{what} must be a tensor, got {type(t).__name__}")
+    _need(t)
+    if t.dtype != dtype or tuple(t.shape) != tuple(shape):
+        raise L.HsError(f"{what} must be {dtype} with shape {tuple(shape)}, got {t.dtype} {tuple(t.shape)}")
+
+
 def _f32(t: torch.Tensor) -> torch.Tensor:
     return t if t.dtype == torch.float32 else t.float()
 

@@ -70,7 +70,10 @@ class MRGStepEngine(_Engine):
         loss = llm_loss(emb)
         loss.backward()
         self.last_loss = loss.detach()
+        if feats.grad is None:
+            raise L.HsError("llm_loss(emb) must depend on the spliced image features (no gradient reached them)")
         dout = feats.grad.contiguous()
+        Fn._need_as(dout, "d(image features)", self.out.shape)
         self.grad.zero_()
         self.p2.backward(dout, None)                  # towers frozen: no gradient w.r.t. the encoder outputs
         self.buckets.reduce(0)

@@ -44,11 +44,12 @@ def _buckets(rank, world):
     gb.wait()
     assert torch.allclose(flat, sum(all_), atol=1e-6)
     assert torch.allclose(flat * gb.grad_scale, sum(all_) / world, atol=1e-6)
-    try:
-        GradBuckets(flat, [(0, 2000)])
-        raise AssertionError("out-of-range bucket accepted")
-    except ValueError:
-        pass
+    for bad in ([(0, 2000)], [(0, 400), (500, 1000)], [(0, 600), (500, 1000)], [(0, 900)]):
+        try:                         # out of range / gap / overlap / short: the buckets must partition the flat gradient
+            GradBuckets(flat, bad)
+            raise AssertionError(f"bad bucket plan accepted: {bad}")
+        except ValueError:
+            pass
 
 
 def _gather(rank, world):

@@ -252,3 +252,35 @@ def test_stage2_clip_engine_trains(dev):
         assert abs(eng._w - 0.1 * (1 - i / 5000)) < 1e-12
     assert np.isfinite(losses).all() and losses[-1] < losses[0], losses
     assert eng.global_step == 6 and float(m.logit_scale) != SCALE            # logit_scale is trained (AdamW on the flat buffer)
+
+
+def test_stage2_clip_engine_refuses_wrong_text_features(dev):
+    """the engine hands raw pointers to kernels that read B*d fp32 values: bf16 / fp16 text features (what an autocast BERT tower
+    produces) or a wrong shape must raise, not be read out of bounds; set_text_features converts; train_step without either raises."""
+    from hsenet_amd import _lib as L
+    from hsenet_amd.clip_step import ClipStage2Engine
+    from oracle import clip_cpu as RC, ref_cpu as R
+    B = 2
+    _, m, sd = _models(dev, 990)
+    eng = ClipStage2Engine(m, B)
+    x, s = R.synthetic_volume((B, 1, 8, 64, 64), 991).to(dev), R.synthetic_slices(B, 992).to(dev)
+    t1, t2 = RC.synthetic_text_features(B, 993).to(dev), RC.synthetic_text_features(B, 994).to(dev)
+    with pytest.raises(L.HsError):
+        eng.train_step(x, s)                                       # no text features yet
+    with pytest.raises(L.HsError):
+        eng.train_step(x, s, t1.bfloat16(), t2)                    # half-size elements: would be an out-of-bounds read
+    with pytest.raises(L.HsError):
+        eng.train_step(x, s, t1, t2[:, :512].contiguous())         # wrong width
+    with pytest.raises(L.HsError):
+        eng.train_step(x, s, t1[:1], t2[:1])                       # wrong batch
+    with pytest.raises(L.HsError):
+        eng.set_text_features(t1, t2[:1])
+    eng.train_step(x, s, t1, t2)
+    ref_loss = eng.loss_value()
+    _, m2, _ = _models(dev, 990)
+    eng2 = ClipStage2Engine(m2, B)
+    eng2.set_text_features(t1.to(torch.bfloat16).float().half(), t2.cpu())     # converted (dtype and device) once, here
+    assert eng2._txt1.dtype == torch.float32 and eng2._txt2.is_cuda
+    eng2.set_text_features(t1, t2)
+    eng2.train_step(x, s)
+    assert abs(eng2.loss_value() - ref_loss) < 1e-6 * max(1.0, abs(ref_loss))

@@ -221,3 +221,112 @@ def test_rccl_backend_world1_matches_no_process_group(dev, tmp_path):
     # same math; split-K float atomics sum in a different order run to run, and AdamW's first steps (update ~ lr * g / |g|) turn
     # last-bit gradient differences of near-zero gradients into visible ones
     assert moved > 0 and diff < 2e-2 * moved
+
+
+# ---- DualEngine (configs[2], bench.py's default workload) across ranks: bucket all-reduces launched from BOTH engine streams ----
+def _dual_parts(dev, layers=4):
+    from oracle import ref_cpu as R
+    from test_gpu_engine import _mine, _oracle
+    _, _, _, sds, x, s = _oracle(2, 950, layers)
+    return _mine(sds, dev, layers), x, s                     # eval(): the Dropout(0.1) sites would draw different masks per rank
+
+
+def _dual_worker(rank, world, port, out, two_streams, backend):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda", rank if backend == "nccl" else 0)
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from hsenet_amd.engine import DualEngine
+        (tower, p1, p2), x, s = _dual_parts(dev)
+        eng = DualEngine(tower, p1, p2, 1, lr=1e-3, weight_decay=0.1, n_buckets=2, two_streams=two_streams)
+        assert eng.buckets.world == 2 and len(eng.buckets.bounds) == 2 + 2 + 2
+        assert (eng.side is not None) == two_streams
+        xr, sr = x[rank:rank + 1].to(dev), s[rank:rank + 1].to(dev)
+        for _ in range(2):
+            eng.train_step(xr, sr)
+        torch.cuda.synchronize()
+        torch.save(eng.flat.cpu(), f"{out}.{rank}")
+    finally:
+        dist.destroy_process_group()
+
+
+def _dual_single(dev):
+    from hsenet_amd.engine import DualEngine
+    (tower, p1, p2), x, s = _dual_parts(dev)
+    eng = DualEngine(tower, p1, p2, 2, lr=1e-3, weight_decay=0.1, two_streams=False)
+    p0 = eng.flat.clone()
+    for _ in range(2):
+        eng.train_step(x.to(dev), s.to(dev))
+    torch.cuda.synchronize()
+    return eng.flat.cpu(), float((eng.flat - p0).norm())
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+@pytest.mark.parametrize("two_streams", [False, True])
+def test_dual_engine_two_ranks_match_single_rank(dev, tmp_path, two_streams):
+    """2 ranks x 1 volume == 1 rank x 2 volumes for the dual-encoder step, with the 2E3 chain (and ITS bucket all-reduces) on the
+    side stream and without; the two replicas must end bit-identical."""
+    out = str(tmp_path / f"dual2_{int(two_streams)}")
+    mp.spawn(_dual_worker, args=(2, _free_port(), out, two_streams, "gloo"), nprocs=2, join=True)
+    r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
+    assert torch.equal(r0, r1)
+    single, moved = _dual_single(dev)
+    diff = float((single - r0).norm())
+    print(f"dual step (two_streams={two_streams}): param movement {moved:.3e}, |dp2 - single| {diff:.3e}")
+    assert moved > 0 and diff < 3e-2 * moved
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL over xGMI)")
+@pytest.mark.parametrize("two_streams", [False, True])
+def test_dual_engine_two_gpus_rccl(dev, tmp_path, two_streams):
+    """the same equivalence with one process per GPU over RCCL (runs only where two GPUs are visible)."""
+    out = str(tmp_path / f"dual2n_{int(two_streams)}")
+    mp.spawn(_dual_worker, args=(2, _free_port(), out, two_streams, "nccl"), nprocs=2, join=True)
+    r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
+    assert torch.equal(r0, r1)
+    single, moved = _dual_single(dev)
+    assert moved > 0 and float((single - r0).norm()) < 3e-2 * moved
+
+
+def _dual_nccl1_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        from hsenet_amd.engine import DualEngine
+        (tower, p1, p2), x, s = _dual_parts(dev)
+        eng = DualEngine(tower, p1, p2, 2, lr=1e-3, weight_decay=0.1, n_buckets=2, two_streams=True)
+        eng.buckets.always = True               # identity all-reduces on RCCL, launched from the side stream AND the main stream
+        for _ in range(2):
+            eng.train_step(x.to(dev), s.to(dev))
+        torch.cuda.synchronize()
+        torch.save(eng.flat.cpu(), out)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dual_engine_rccl_world1_two_streams(dev, tmp_path):
+    """RCCL stream semantics of the two-stream engine on the one GPU there is: every bucket all-reduce is issued (asynchronously)
+    from the stream that produced the range — the 2E3 chain's from the side stream — and waited for on the main stream before
+    AdamW; the result must equal the run without a process group."""
+    out = str(tmp_path / "dual_nccl1.pt")
+    mp.spawn(_dual_nccl1_worker, args=(1, _free_port(), out), nprocs=1, join=True)
+    got = torch.load(out)
+    single, moved = _dual_single(dev)
+    diff = float((single - got).norm())
+    print(f"dual step on RCCL (world 1, two streams): param movement {moved:.3e}, difference {diff:.3e}")
+    assert moved > 0 and diff < 2e-2 * moved

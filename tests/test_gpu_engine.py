@@ -92,6 +92,9 @@ def test_dual_engine_vs_oracle(dev):
     worst = max(errs, key=errs.get)
     print(f"DualEngine backward worst grad err: {worst} {errs[worst]:.2e} over {len(errs)} tensors")
     assert errs[worst] < 5e-2, (worst, errs[worst])
+    for bad in (eng.dout.bfloat16(), eng.dout[:, :-1].contiguous(), eng.dout.transpose(1, 2)):
+        with pytest.raises(L.HsError):            # dout is read as B*256*hidden fp32 values through its raw pointer
+            eng.backward(bad)
 
     # ---- optimizer: same gradients into torch.optim.AdamW the way HF Trainer builds it
     ref_named = _named(tr, p1r, p2r)
@@ -209,6 +212,14 @@ def test_flat_encoder_stage2_vs_oracle(dev):
     assert errs[worst] < 5e-2, (worst, errs[worst])
     with pytest.raises(L.HsError):
         eng.forward(x.to(dev).transpose(3, 4), s.to(dev))          # non-contiguous volume: refused, not silently mis-read
+    # backward entry point: the raw pointer is read as B*N*d fp32 values
+    for bad in (eng.dy.bfloat16(), eng.dy[:, :-1].contiguous(), eng.dy.double(), eng.dy.cpu()):
+        with pytest.raises(L.HsError):
+            eng.backward(bad)
+    with pytest.raises(L.HsError):
+        eng.forward(x.to(dev), s.to(dev)[:, :16].contiguous())      # slice features of the wrong shape
+    with pytest.raises(L.HsError):
+        eng.forward(x.to(dev), s.to(dev).bfloat16())
 
 
 def test_mrg_step_engine_vs_oracle(dev):

@@ -315,6 +315,35 @@ def test_layernorm_bwd_bf16_dy_and_colsum(dev, rows):
     assert rel(dg, gg) < 1e-5 and rel(db, gb) < 1e-5 and rel(dsum, want.sum(0)) < 1e-5
 
 
+@pytest.mark.parametrize("rows", [16388, 32700])        # 4 and ~8 volumes' worth of rows: the few-rows (8-wave) variant is selected
+def test_layernorm_bwd_variants_agree_bitwise(dev, rows):
+    """the two LayerNorm-backward variants (hand-written one-row path, 4 waves; row pairs through the shared lambdas, 8 waves) must
+    not drift apart: the whole call (selects the 8-wave variant at these row counts) against the same rows fed in chunks of 4000
+    (< 4096 rows: always the 4-wave variant).  A row's dx depends on that row only -> bit-identical; the column sums differ only
+    by the order of their float atomics."""
+    from hsenet_amd import functional as Fn, _lib as L
+    d, s = 768, torch.cuda.current_stream().cuda_stream
+    x, g, b = rnd((rows, d), 65, dev, 2.0), 1 + 0.1 * rnd((d,), 66, dev), rnd((d,), 67, dev)
+    dyb, dx_in = rnd((rows, d), 68, dev).bfloat16(), rnd((rows, d), 69, dev)
+    _, _, mean, rstd = Fn.layernorm_fwd(x, g, b)
+
+    def run(r0, r1, dx, dxb, sums):
+        L.call("hs_layernorm_bwd", dyb[r0:r1].data_ptr(), 1, x[r0:r1].data_ptr(), None, g.data_ptr(), mean[r0:r1].data_ptr(),
+               rstd[r0:r1].data_ptr(), dx_in[r0:r1].data_ptr(), dx[r0:r1].data_ptr(), dxb[r0:r1].data_ptr(), sums[0].data_ptr(),
+               sums[1].data_ptr(), sums[2].data_ptr(), r1 - r0, d, s)
+    outs = []
+    for chunk in (rows, 4000):
+        dx, dxb = torch.empty_like(x), torch.empty(rows, d, dtype=torch.bfloat16, device=dev)
+        sums = [torch.zeros(d, device=dev) for _ in range(3)]
+        for r0 in range(0, rows, chunk):
+            run(r0, min(rows, r0 + chunk), dx, dxb, sums)
+        outs.append((dx, dxb, sums))
+    (dx_w, dxb_w, s_w), (dx_n, dxb_n, s_n) = outs
+    assert torch.equal(dx_w, dx_n) and torch.equal(dxb_w, dxb_n)
+    for a, c in zip(s_w, s_n):
+        assert rel(a, c) < 1e-5
+
+
 @pytest.mark.parametrize("geom", [((2, 1, 8, 32, 32), (4, 16, 16)), ((1, 1, 32, 64, 48), (16, 16, 16)), ((1, 2, 4, 6, 10), (2, 3, 5))])
 @pytest.mark.parametrize("prec", ["bf16", "f32"])
 def test_patchify(dev, geom, prec):
