@@ -3,6 +3,8 @@
 #include "common.h"
 
 int hs_cast_bf16_multi(const float* const* src, void* const* dst, const int64_t* n, int count, void* stream);   // small.hip
+// fp32 [R][C] -> bf16 [C][R] for up to `count` matrices in one launch per 64 (R, C multiples of 64)               // small.hip
+int hs_cast_bf16_transpose_multi(const float* const* src, void* const* dst, const int* R, const int* C, int count, void* stream);
 
 namespace hsdrv {
 

@@ -585,7 +585,24 @@ static_assert(EF >= 0, "the 16x16x32 kernels are launched with compile-time epil
             rhi[G & 1][st] = *(const f32x4*)(p.resid + ix + 4);
         }
     };
+    // the saved gelu'(z) tile of a GELU' epilogue (dgrad of fc2 against the transposed weight copy): loaded like the residual, 16 B
+    // (8 bf16 columns) per step, one group ahead, unconditionally; its column sums (the bias gradient of fc1) accumulate per lane
+    // over the wave's 128 rows and are reduced across the 16 lanes of a row group at the end
+    constexpr bool want_aux_in = (flags & HS_EPI_GELU_BWD) != 0;
+    u32x4 zin[2][4];
+    auto load_aux = [&](auto g_tag) {
+        constexpr int G = decltype(g_tag)::value;
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            const int i = 2 * G + (st >> 1), jp = st & 1;
+            const int m = mw + 16 * i + l15;
+            const long ix = (m < p.M && n_in[jp]) ? cz + (long)m * p.ldc + ncol[jp] : 0l;
+            zin[G & 1][st] = *(const u32x4*)((const bf16_t*)p.aux + ix);
+        }
+    };
+    f32x4 cs_lo[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}, cs_hi[2] = {cs_lo[0], cs_lo[0]};
     if (want_res) load_res(std::integral_constant<int, 0>{});
+    if (want_aux_in) load_aux(std::integral_constant<int, 0>{});
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         f32x4 vlo[4], vhi[4];
@@ -596,6 +613,11 @@ static_assert(EF >= 0, "the 16x16x32 kernels are launched with compile-time epil
             if (g == 0) load_res(std::integral_constant<int, 1>{});
             if (g == 1) load_res(std::integral_constant<int, 2>{});
             if (g == 2) load_res(std::integral_constant<int, 3>{});
+        }
+        if (want_aux_in) {
+            if (g == 0) load_aux(std::integral_constant<int, 1>{});
+            if (g == 1) load_aux(std::integral_constant<int, 2>{});
+            if (g == 2) load_aux(std::integral_constant<int, 3>{});
         }
 #pragma unroll
         for (int st = 0; st < 4; ++st) {
@@ -610,10 +632,15 @@ static_assert(EF >= 0, "the 16x16x32 kernels are launched with compile-time epil
 #pragma unroll
         for (int st = 0; st < 4; ++st) {
             const int i = 2 * g + (st >> 1), jp = st & 1;
-            u32x2 k0 = {0u, 0u}, k1 = {0u, 0u};
-            vlo[st] = epi_math(p, flags, 0, acc16[i][J0 + 2 * jp], vlo[st], u32x2{0u, 0u}, bias_lo[jp], alpha_n[jp], &k0);
-            vhi[st] = epi_math(p, flags, 0, acc16[i][J0 + 2 * jp + 1], vhi[st], u32x2{0u, 0u}, bias_hi[jp], alpha_n[jp], &k1);
+            u32x2 k0 = {0u, 0u}, k1 = {0u, 0u}, zl = {0u, 0u}, zh = {0u, 0u};
+            if (want_aux_in) { zl = u32x2{zin[g & 1][st][0], zin[g & 1][st][1]}; zh = u32x2{zin[g & 1][st][2], zin[g & 1][st][3]}; }
+            vlo[st] = epi_math(p, flags, 0, acc16[i][J0 + 2 * jp], vlo[st], zl, bias_lo[jp], alpha_n[jp], &k0);
+            vhi[st] = epi_math(p, flags, 0, acc16[i][J0 + 2 * jp + 1], vhi[st], zh, bias_hi[jp], alpha_n[jp], &k1);
             zb[st] = u32x4{k0[0], k0[1], k1[0], k1[1]};
+            if (want_aux_in) {
+                const float keep = in[st] ? 1.0f : 0.0f;       // rows / columns outside the matrix contribute nothing
+                cs_lo[jp] += vlo[st] * keep; cs_hi[jp] += vhi[st] * keep;
+            }
         }
         // bf16 outputs: a lane's two 16-B pieces of row l15 (column halves jp = 0, 1) are HALF lines, 16 rows x 64 B per store
         // instruction -- streamed to memory that way they ran at half the rate of full lines (tools/micro/store_ctx: 118 vs 81 us
@@ -663,6 +690,23 @@ static_assert(EF >= 0, "the 16x16x32 kernels are launched with compile-time epil
                         if (inB) *(u32x4*)((bf16_t*)p.aux_out + idxB) = z1;
                     }
                 }
+            }
+        }
+    }
+    if (want_aux_in && p.colsum) {   // fused bias gradient: column sums of this wave's 128 x 64 piece, one atomic per column
+#pragma unroll
+        for (int jp = 0; jp < 2; ++jp) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                for (int sh = 1; sh < 16; sh <<= 1) {       // the 16 lanes of a row group hold the same columns, different rows
+                    cs_lo[jp][e] += __shfl_xor(cs_lo[jp][e], sh, 64);
+                    cs_hi[jp][e] += __shfl_xor(cs_hi[jp][e], sh, 64);
+                }
+            }
+            if (l15 == 0 && n_in[jp]) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { atomicAdd(p.colsum + ncol[jp] + e, cs_lo[jp][e]); atomicAdd(p.colsum + ncol[jp] + 4 + e, cs_hi[jp][e]); }
             }
         }
     }
@@ -1222,13 +1266,15 @@ extern "C" int hs_gemm(const hs_gemm_args* a, int prec, void* stream) {
         if (big) hipLaunchKernelGGL((gemm_bf16_kernel<ATR, BTR, true, EF>), grid, dim3(512), 0, s, p);                \
         else hipLaunchKernelGGL((gemm_bf16_kernel<ATR, BTR, false, EF>), grid, dim3(512), 0, s, p);                   \
     } while (0)
-        const bool m16 = big && a->layout == HS_GEMM_NT && !a->colsum_out && !kEnv.no_m16;
+        const bool m16 = big && a->layout == HS_GEMM_NT && (!a->colsum_out || a->flags == (HS_EPI_GELU_BWD | HS_EPI_SAVE_DGELU)) && !kEnv.no_m16;
 #define HS_LAUNCH_M16(EF) hipLaunchKernelGGL((gemm_bf16_kernel<false, false, true, EF, true>), grid, dim3(512), 0, s, p)
         p.nblocks = (int)grid.x;
-        const bool m16_ok = m16 && col8 && (f == 0 || f == (HS_EPI_BIAS | HS_EPI_RESID) || f == (HS_EPI_BIAS | HS_EPI_GELU | HS_EPI_SAVE_DGELU));
+        const bool m16_ok = m16 && col8 && (f == 0 || f == (HS_EPI_BIAS | HS_EPI_RESID) || f == (HS_EPI_BIAS | HS_EPI_GELU | HS_EPI_SAVE_DGELU) ||
+                                            (f == (HS_EPI_GELU_BWD | HS_EPI_SAVE_DGELU) && !(((uintptr_t)a->aux) & 15)));
         if (m16_ok) {
             if (f == 0) HS_LAUNCH_M16(0);
             else if (f == (HS_EPI_BIAS | HS_EPI_RESID)) HS_LAUNCH_M16(HS_EPI_BIAS | HS_EPI_RESID);
+            else if (f == (HS_EPI_GELU_BWD | HS_EPI_SAVE_DGELU)) HS_LAUNCH_M16(HS_EPI_GELU_BWD | HS_EPI_SAVE_DGELU);
             else HS_LAUNCH_M16(HS_EPI_BIAS | HS_EPI_GELU | HS_EPI_SAVE_DGELU);
         } else if (a->layout == HS_GEMM_NT) {
             if (col8 && f == 0) HS_LAUNCH_E(false, false, 0);

@@ -70,6 +70,25 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
     }
 }
 
+// The per-element arithmetic of the LayerNorm backward, ONE definition for both row loops of the kernel below (the hand-written
+// one-row path and the row-pair lambdas): contraction is spelled out (explicit fma, pragma off for the rest) so that the two paths
+// cannot drift apart by the compiler fusing differently in each -- tests/test_gpu_kernels.py compares their dx bit for bit.
+__device__ __forceinline__ void ln_bwd_accum(float xv, float dv, float gam, float mu, float rs, float& xh, float& gy, float& s1,
+                                             float& s2, float& dg, float& db) {
+#pragma clang fp contract(off)
+    xh = (xv - mu) * rs;
+    gy = dv * gam;
+    s1 += gy;
+    s2 = __builtin_fmaf(gy, xh, s2);
+    dg = __builtin_fmaf(dv, xh, dg);
+    db += dv;
+}
+__device__ __forceinline__ float ln_bwd_out(float gy, float xh, float c1, float c2, float rs, float di) {
+#pragma clang fp contract(off)
+    const float t = __builtin_fmaf(-xh, c2, gy - c1);
+    return __builtin_fmaf(rs, t, di);
+}
+
 // Each wave walks rows (grid-stride), keeps its dgamma/dbeta partials in registers, then the block reduces
 // through LDS and issues one float atomic per column.
 // NCH = 256-column chunks per row actually used (d <= NCH*256): sizes the register arrays and the LDS reduction
@@ -117,13 +136,10 @@ __global__ __launch_bounds__(WPB * 64, 16 / WPB) void layernorm_bwd_kernel(const
                     dv = *(const f32x4*)((const float*)dy_ + (long)row * d + ch * 4);
                 }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    R.xh[i][e] = (xv[e] - mu) * R.rs;
-                    R.gy[i][e] = dv[e] * g[i][e];
-                    R.s1 += R.gy[i][e];
-                    R.s2 += R.gy[i][e] * R.xh[i][e];
-                    dg[i][e] += dv[e] * R.xh[i][e];
-                    db[i][e] += dv[e];
+                for (int e = 0; e < 4; ++e) {         // (vector elements cannot bind to references: through locals)
+                    float xh_, gy_, dg_ = dg[i][e], db_ = db[i][e];
+                    ln_bwd_accum(xv[e], dv[e], g[i][e], mu, R.rs, xh_, gy_, R.s1, R.s2, dg_, db_);
+                    R.xh[i][e] = xh_; R.gy[i][e] = gy_; dg[i][e] = dg_; db[i][e] = db_;
                 }
             }
         }
@@ -136,8 +152,7 @@ __global__ __launch_bounds__(WPB * 64, 16 / WPB) void layernorm_bwd_kernel(const
             if (ch < nch) {
                 f32x4 o;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = R.rs * (R.gy[i][e] - c1 - R.xh[i][e] * c2);
-                o += R.di[i];
+                for (int e = 0; e < 4; ++e) o[e] = ln_bwd_out(R.gy[i][e], R.xh[i][e], c1, c2, R.rs, R.di[i][e]);
                 ds[i] += o;
                 if (dx) *(f32x4*)(dx + (long)row * d + ch * 4) = o;
                 if (dxb) {
@@ -181,12 +196,9 @@ __global__ __launch_bounds__(WPB * 64, 16 / WPB) void layernorm_bwd_kernel(const
                     }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        xh[i][e] = (xv[e] - mu) * rs;
-                        gy[i][e] = dv[e] * g[i][e];
-                        s1 += gy[i][e];
-                        s2 += gy[i][e] * xh[i][e];
-                        dg[i][e] += dv[e] * xh[i][e];
-                        db[i][e] += dv[e];
+                        float xh_, gy_, dg_ = dg[i][e], db_ = db[i][e];
+                        ln_bwd_accum(xv[e], dv[e], g[i][e], mu, rs, xh_, gy_, s1, s2, dg_, db_);
+                        xh[i][e] = xh_; gy[i][e] = gy_; dg[i][e] = dg_; db[i][e] = db_;
                     }
                 }
             }
@@ -197,8 +209,7 @@ __global__ __launch_bounds__(WPB * 64, 16 / WPB) void layernorm_bwd_kernel(const
                 if (ch < nch) {
                     f32x4 o;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = rs * (gy[i][e] - c1 - xh[i][e] * c2);
-                    o += di[i];
+                    for (int e = 0; e < 4; ++e) o[e] = ln_bwd_out(gy[i][e], xh[i][e], c1, c2, rs, di[i][e]);
                     ds[i] += o;
                     if (dx) *(f32x4*)(dx + (long)row * d + ch * 4) = o;
                     if (dxb) {
@@ -253,9 +264,11 @@ extern "C" int hs_layernorm_bwd(const void* dy, int dy_is_bf16, const float* x, 
     int blocks = (rows + 3) / 4;
     if (blocks > 2048) blocks = 2048;
     if (rows / 16 >= 256 && (rows + 15) / 16 < blocks) blocks = (rows + 15) / 16;
-    // few rows (one or two volumes per GPU): the block's 3 x d float atomics onto the SAME 3 x d addresses from every block are the
+    // few rows (up to ~10 volumes per GPU): the block's 3 x d float atomics onto the SAME 3 x d addresses from every block are the
     // serial part (257 blocks at 4097 rows) -- 8 waves x 4 rows per block halve the block count at the same per-wave chain
-    bool wide = blocks * 16 >= rows && rows / 32 >= 128 && d <= 768;
+    // Measured (tools/ln_bwd_ab.py on a hook build, d = 768, bf16 dy; wide / narrow time): 4097 rows 0.77, 8194 0.97, 12291 0.80, 16388 0.81,
+    // 20485 0.77, 24582 0.84, 28679 0.91, 32776 0.86, 49164 0.96, 81940 1.05 -> the 8-wave variant up to 10 volumes' worth of rows.
+    bool wide = rows / 32 >= 128 && rows <= 10 * 4100 && d <= 768;
     if (HS_DBG(g_hs_dbg[5]) == 1) wide = false;                            // (hook builds: A/B of the two variants, tools/ln_bwd_ab.py)
     if (HS_DBG(g_hs_dbg[5]) == 2) wide = rows / 32 >= 1 && d <= 768;
     if (wide) blocks = (rows + 31) / 32;

@@ -696,6 +696,54 @@ int hs_cast_bf16_multi(const float* const* src, void* const* dst, const int64_t*
     }
     return HS_OK;
 }
+// fp32 [R][C] -> bf16 [C][R]: the TRANSPOSED bf16 weight copies the backward pass multiplies the output gradients with.  A dgrad
+// dX = dY W reads W [out][in] with the reduction index (out) as the memory row -- the NN layout, transposed LDS reads, the slower
+// GEMM kernel; against W^T [in][out] the same product is an NT GEMM and runs on the forward's kernel.  Up to 64 matrices per
+// launch, 64 x 64 tiles through LDS, R and C multiples of 64.  Internal to the library (vit.hip); rounding = hs_cast_bf16's.
+struct CastTSegs { const float* src[64]; bf16_t* dst[64]; int R[64], C[64]; int first[65]; };
+__global__ __launch_bounds__(256) void cast_bf16_transpose_multi_kernel(CastTSegs g) {
+    __shared__ __attribute__((aligned(16))) bf16_t t[64][64 + 8];          // 144-B rows: 16-B aligned reads
+    int b = blockIdx.x, sgm = 0;
+    while (b >= g.first[sgm + 1]) ++sgm;                                    // (block-uniform; <= 64 segments)
+    b -= g.first[sgm];
+    const int R = g.R[sgm], C = g.C[sgm], tc = C >> 6;
+    const int r0 = (b / tc) << 6, c0 = (b % tc) << 6;
+    const float* __restrict__ x = g.src[sgm];
+    bf16_t* __restrict__ y = g.dst[sgm];
+    const int tr = threadIdx.x >> 2, tb = (threadIdx.x & 3) << 4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const f32x4 v = *(const f32x4*)(x + (long)(r0 + tr) * C + c0 + tb + 4 * k);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t[tb + 4 * k + e][tr] = f2bf(v[e]);
+    }
+    __syncthreads();
+    const u32x4 lo = *(const u32x4*)&t[tr][tb], hi = *(const u32x4*)&t[tr][tb + 8];
+    *(u32x4*)(y + (long)(c0 + tr) * R + r0 + tb) = lo;
+    *(u32x4*)(y + (long)(c0 + tr) * R + r0 + tb + 8) = hi;
+}
+int hs_cast_bf16_transpose_multi(const float* const* src, void* const* dst, const int* R, const int* C, int count, void* stream) {
+    if (!src || !dst || !R || !C || count < 1) return HS_ERR_ARG;
+    for (int c0 = 0; c0 < count; c0 += 64) {
+        CastTSegs g;
+        const int cnt = count - c0 < 64 ? count - c0 : 64;
+        double bytes = 0;
+        g.first[0] = 0;
+        for (int i = 0; i < cnt; ++i) {
+            const int r = R[c0 + i], c = C[c0 + i];
+            if (!src[c0 + i] || !dst[c0 + i] || r < 64 || c < 64 || (r & 63) || (c & 63)) return HS_ERR_SHAPE;
+            if (((uintptr_t)src[c0 + i] | (uintptr_t)dst[c0 + i]) & 15) return HS_ERR_SHAPE;
+            g.src[i] = src[c0 + i]; g.dst[i] = (bf16_t*)dst[c0 + i]; g.R[i] = r; g.C[i] = c;
+            g.first[i + 1] = g.first[i] + (r >> 6) * (c >> 6);
+            bytes += (double)r * c * 6;
+        }
+        for (int i = cnt; i < 64; ++i) { g.src[i] = nullptr; g.dst[i] = nullptr; g.R[i] = 0; g.C[i] = 0; g.first[i + 1] = g.first[cnt]; }
+        ProfScope prof(HS_PROF_CAST, stream, 0, bytes);
+        hipLaunchKernelGGL(cast_bf16_transpose_multi_kernel, dim3((unsigned)g.first[cnt]), dim3(256), 0, (hipStream_t)stream, g);
+        HS_CHECK_LAUNCH();
+    }
+    return HS_OK;
+}
 extern "C" int hs_cast_f32(const void* x, float* y, int64_t n, void* stream) {
     if (!x || !y) return HS_ERR_ARG;
     if (n < 1 || (((uintptr_t)x | (uintptr_t)y) & 15)) return HS_ERR_SHAPE;

@@ -12,6 +12,7 @@
 //   x' = xm + a W2^T + b2                                gemm NT, epilogue bias+residual -> fp32 (= hidden[l])
 // The residual stream (x, xm) is fp32 throughout, as under the reference's autocast policy.
 #include "driver.h"
+#include <cstdlib>
 #include <vector>
 
 using namespace hsdrv;
@@ -19,9 +20,18 @@ using namespace hsdrv;
 namespace {
 
 struct Layout {
-    size_t wbf, xmid, h1, h2, qkv, o, lse, z, a, stats, fstats, dx, dh, dxb, dob, dz, dqkv, delta, qb, total;
+    size_t wbf, wbft, xmid, h1, h2, qkv, o, lse, z, a, stats, fstats, dx, dh, dxb, dob, dz, dqkv, delta, qb, total;
     size_t per_w;  // bf16 weight elements per layer
 };
+
+// The dgrads dX = dY W read W [out][in] with the reduction index as the memory row (NN layout: transposed LDS reads, the slower
+// kernel).  Against a transposed bf16 copy W^T [in][out] -- re-made once per backward call, 14 MB per layer -- the same product is
+// an NT GEMM on the forward's kernel (256x256 tile, 16x16x32 MFMA, accumulators straight to memory).  Needs 64-multiples.
+// (HS_DGRAD_NN=1, read once: A/B runs against the NN kernels)
+inline bool dgrad_nt(const hs_vit_desc& c) {
+    static const bool off = getenv("HS_DGRAD_NN") != nullptr;
+    return !off && !(c.d & 63) && !(c.mlp & 63);
+}
 
 Layout make_layout(const hs_vit_desc& c) {
     Layout L;
@@ -32,6 +42,8 @@ Layout make_layout(const hs_vit_desc& c) {
     auto take = [&](size_t bytes) { size_t o = off; off += al256(bytes); return o; };
     L.per_w = 3 * d * d + d * d + mlp * d + d * mlp;
     L.wbf = take(c.prec == HS_PREC_BF16 ? (size_t)c.L * L.per_w * 2 : 0);
+    // TRANSPOSED bf16 weight copies for the backward pass' dgrads (see dgrad_nt below): same per-layer order [Wqkv^T | Wo^T | W1^T | W2^T]
+    L.wbft = take(c.prec == HS_PREC_BF16 && c.save_for_bwd && dgrad_nt(c) ? (size_t)c.L * L.per_w * 2 : 0);
     L.xmid = take(Ls * M * d * 4);
     L.h1 = take(Ls * M * d * es);
     L.h2 = take(Ls * M * d * es);
@@ -185,6 +197,21 @@ extern "C" int hs_vit_blocks_bwd(const hs_vit_desc* desc, const float* x0, const
     char* dqkv = w + L.dqkv;
     float* delta = (float*)(w + L.delta);
 
+    const bool nt = bf && dgrad_nt(c);
+    if (nt) {   // W^T copies of this call's layers: one multi-segment launch
+        std::vector<const float*> src;
+        std::vector<void*> dst;
+        std::vector<int> R, Cc;
+        for (int l = l_lo; l < l_hi; ++l) {
+            bf16_t* wl = (bf16_t*)(w + L.wbft) + (size_t)l * L.per_w;
+            const float* const* p = lp + (size_t)l * P_COUNT;
+            src.push_back(p[P_WQKV]); dst.push_back(wl); R.push_back(3 * d); Cc.push_back(d);
+            src.push_back(p[P_WO]); dst.push_back(wl + 3 * d * d); R.push_back(d); Cc.push_back(d);
+            src.push_back(p[P_W1]); dst.push_back(wl + 4 * d * d); R.push_back(mlp); Cc.push_back(d);
+            src.push_back(p[P_W2]); dst.push_back(wl + 4 * d * d + (size_t)mlp * d); R.push_back(d); Cc.push_back(mlp);
+        }
+        RC(hs_cast_bf16_transpose_multi(src.data(), dst.data(), R.data(), Cc.data(), (int)src.size(), stream));
+    }
     if (l_hi == c.L) {
         const float* fs = (const float*)(w + L.fstats);
         // (each LN backward also emits the column sums of the dx it produces = the bias gradient of the Linear below it)
@@ -214,20 +241,27 @@ extern "C" int hs_vit_blocks_bwd(const hs_vit_desc* desc, const float* x0, const
 
         if (bf) {
             // bf16: dgrad chain first, the four weight gradients as one grouped launch at the end of the layer
+            const bf16_t* wlt = (const bf16_t*)(w + L.wbft) + (size_t)l * L.per_w;        // (valid when nt)
+            const bf16_t *wqkvt = wlt, *wot = wlt + 3 * d * d, *w1t = wlt + 4 * d * d, *w2t = wlt + 4 * d * d + (size_t)mlp * d;
             const int j = 2 * (c.L - 1 - l);
             const size_t dxs = al256(Md * 2);
             const bf16_t* dx_in = (const bf16_t*)(w + L.dxb + (size_t)(j % 3) * dxs);
             bf16_t* dx_mid = (bf16_t*)(w + L.dxb + (size_t)((j + 1) % 3) * dxs);
             bf16_t* dx_out = (bf16_t*)(w + L.dxb + (size_t)((j + 2) % 3) * dxs);
             // ---- MLP branch: x' = xm + W2 gelu(W1 h2 + b1) + b2        (db2 came with the dx that entered this layer)
-            RC(gemm(P, HS_GEMM_NN, dx_in, w2, M, mlp, d, d, mlp, nullptr, dz, mlp, nullptr, nullptr, z, nullptr,
-                    HS_EPI_GELU_BWD | HS_EPI_SAVE_DGELU, 1, stream, g[P_B1]));               // db1 = colsum(dz), fused in the epilogue
-            RC(gemm(P, HS_GEMM_NN, dz, w1, M, d, mlp, mlp, d, nullptr, dh, d, nullptr, nullptr, nullptr, nullptr, 0, 1, stream));
+            if (nt) RC(gemm(P, HS_GEMM_NT, dx_in, w2t, M, mlp, d, d, d, nullptr, dz, mlp, nullptr, nullptr, z, nullptr,
+                            HS_EPI_GELU_BWD | HS_EPI_SAVE_DGELU, 1, stream, g[P_B1]));       // db1 = colsum(dz), fused in the epilogue
+            else RC(gemm(P, HS_GEMM_NN, dx_in, w2, M, mlp, d, d, mlp, nullptr, dz, mlp, nullptr, nullptr, z, nullptr,
+                         HS_EPI_GELU_BWD | HS_EPI_SAVE_DGELU, 1, stream, g[P_B1]));
+            if (nt) RC(gemm(P, HS_GEMM_NT, dz, w1t, M, d, mlp, mlp, mlp, nullptr, dh, d, nullptr, nullptr, nullptr, nullptr, 0, 1, stream));
+            else RC(gemm(P, HS_GEMM_NN, dz, w1, M, d, mlp, mlp, d, nullptr, dh, d, nullptr, nullptr, nullptr, nullptr, 0, 1, stream));
             RC(hs_layernorm_bwd(dh, 1, xmid, nullptr, p[P_N2W], st + 2 * M, st + 3 * M, dx, dx, dx_mid, g[P_N2W], g[P_N2B], g[P_BO], M, d, stream));
             // ---- attention branch: xm = x + Wo attn(LN1 x) + bo         (dbo came from the LN2 backward just above)
-            RC(gemm(P, HS_GEMM_NN, dx_mid, wo, M, d, d, d, d, nullptr, dob, d, nullptr, nullptr, nullptr, nullptr, 0, 1, stream));
+            if (nt) RC(gemm(P, HS_GEMM_NT, dx_mid, wot, M, d, d, d, d, nullptr, dob, d, nullptr, nullptr, nullptr, nullptr, 0, 1, stream));
+            else RC(gemm(P, HS_GEMM_NN, dx_mid, wo, M, d, d, d, d, nullptr, dob, d, nullptr, nullptr, nullptr, nullptr, 0, 1, stream));
             RC(hs_attn_bwd(qkv, o, dob, lse, dqkv, delta, c.B, c.N, c.H, 64, HS_ATTN_Q_PRESCALED, stream));
-            RC(gemm(P, HS_GEMM_NN, dqkv, wqkv, M, d, 3 * d, 3 * d, d, nullptr, dh, d, nullptr, nullptr, nullptr, nullptr, 0, 1, stream));
+            if (nt) RC(gemm(P, HS_GEMM_NT, dqkv, wqkvt, M, d, 3 * d, 3 * d, 3 * d, nullptr, dh, d, nullptr, nullptr, nullptr, nullptr, 0, 1, stream));
+            else RC(gemm(P, HS_GEMM_NN, dqkv, wqkv, M, d, 3 * d, 3 * d, d, nullptr, dh, d, nullptr, nullptr, nullptr, nullptr, 0, 1, stream));
             float* dxo = (l == 0) ? dx0 : dx;
             float* b2_below = (l == 0) ? nullptr : lg[(size_t)(l - 1) * P_COUNT + P_B2];
             RC(hs_layernorm_bwd(dh, 1, xin, nullptr, p[P_N1W], st, st + M, dx, dxo, l == 0 ? nullptr : dx_out, g[P_N1W], g[P_N1B], b2_below, M, d, stream));

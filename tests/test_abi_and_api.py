@@ -153,8 +153,12 @@ def test_fused_driver_descriptors_validate_without_a_gpu():
         assert lib.hs_packer_workspace_bytes(C.byref(bad)) == 0
         assert lib.hs_packer_fwd(C.byref(bad), 1, 1, 1, 1, 0, None) < 0
     assert lib.hs_packer_fwd(C.byref(k), None, None, None, None, 0, None) == L.HS_ERR_ARG
-    v = L.VitDesc(1, 4097, 768, 12, 3072, 12, L.PREC_BF16, 1, 0.0, None)
-    per_volume = lib.hs_vit_workspace_bytes(C.byref(v))
-    assert 1.0e9 < per_volume < 1.6e9                               # ~1.2 GB of saved activations per 256^3 volume
+    ws1 = lib.hs_vit_workspace_bytes(C.byref(L.VitDesc(1, 4097, 768, 12, 3072, 12, L.PREC_BF16, 1, 0.0, None)))
+    ws2 = lib.hs_vit_workspace_bytes(C.byref(L.VitDesc(2, 4097, 768, 12, 3072, 12, L.PREC_BF16, 1, 0.0, None)))
+    assert 1.0e9 < ws2 - ws1 < 1.4e9                                # ~1.2 GB of saved activations per 256^3 volume
+    fixed = 2 * ws1 - ws2                                           # batch-independent part: the bf16 weight copies (W and W^T), 2 x 170 MB
+    assert 3.3e8 < fixed < 3.6e8
+    fwd_only = lib.hs_vit_workspace_bytes(C.byref(L.VitDesc(1, 4097, 768, 12, 3072, 12, L.PREC_BF16, 0, 0.0, None)))
+    assert fwd_only < 0.45e9                                        # forward-only: one layer's activations + the W copies, no W^T
     assert lib.hs_vit_workspace_bytes(C.byref(L.VitDesc(1, 4097, 768, 11, 3072, 12, L.PREC_BF16, 1, 0.0, None))) == 0   # head dim != 64
     assert lib.hs_sumsq(None, None, None, 8, None) == L.HS_ERR_ARG and lib.hs_rows_copy(None, 0, None, None, 0, 1, 1, 4, None) == L.HS_ERR_ARG

@@ -261,9 +261,9 @@ def test_stage2_clip_engine_refuses_wrong_text_features(dev):
     from hsenet_amd.clip_step import ClipStage2Engine
     from oracle import clip_cpu as RC, ref_cpu as R
     B = 2
-    _, m, sd = _models(dev, 990)
+    _, m = _models(dev, 990)
     eng = ClipStage2Engine(m, B)
-    x, s = R.synthetic_volume((B, 1, 8, 64, 64), 991).to(dev), R.synthetic_slices(B, 992).to(dev)
+    x, s = R.synthetic_volume((B, 1) + IMG, 991).to(dev), R.synthetic_slices(B, 992).to(dev)
     t1, t2 = RC.synthetic_text_features(B, 993).to(dev), RC.synthetic_text_features(B, 994).to(dev)
     with pytest.raises(L.HsError):
         eng.train_step(x, s)                                       # no text features yet
@@ -277,7 +277,7 @@ def test_stage2_clip_engine_refuses_wrong_text_features(dev):
         eng.set_text_features(t1, t2[:1])
     eng.train_step(x, s, t1, t2)
     ref_loss = eng.loss_value()
-    _, m2, _ = _models(dev, 990)
+    _, m2 = _models(dev, 990)
     eng2 = ClipStage2Engine(m2, B)
     eng2.set_text_features(t1.to(torch.bfloat16).float().half(), t2.cpu())     # converted (dtype and device) once, here
     assert eng2._txt1.dtype == torch.float32 and eng2._txt2.is_cuda

@@ -688,3 +688,15 @@ def test_gemm_big_tile_paths(dev):
     assert rel(o32, acc2) < 1e-6
     Fn.gemm(dy, w2, L.GEMM_NN, prec=L.PREC_BF16, out_bf16=o16, aux=g16, flags=L.EPI_GELU_BWD | L.EPI_SAVE_DGELU)
     assert rel(o16.float(), acc2 * g16.double()) < 3e-3
+    # the same dgrad against the TRANSPOSED weight copy = an NT GEMM on the 16x16x32 kernel, x gelu'(z), fused column sums
+    # (what hs_vit_blocks_bwd launches for fc2's dgrad); must agree with the NN kernel's result and the fp64 statement
+    w2t = w2.t().contiguous()                                             # [N][K=256]
+    o16t = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev)
+    cs, cs_nn = torch.zeros(N, device=dev), torch.zeros(N, device=dev)
+    Fn.gemm(dy, w2t, L.GEMM_NT, prec=L.PREC_BF16, out_bf16=o16t, aux=g16, flags=L.EPI_GELU_BWD | L.EPI_SAVE_DGELU, colsum_out=cs)
+    Fn.gemm(dy, w2, L.GEMM_NN, prec=L.PREC_BF16, out_bf16=o16, aux=g16, flags=L.EPI_GELU_BWD | L.EPI_SAVE_DGELU, colsum_out=cs_nn)
+    want2 = acc2 * g16.double()
+    assert rel(o16t.float(), want2) < 3e-3 and (o16t != o16).float().mean().item() < 1e-3
+    assert rel(cs, want2.sum(0)) < 1e-5 and rel(cs_nn, want2.sum(0)) < 1e-5
+    Fn.gemm(dy, w2t, L.GEMM_NT, prec=L.PREC_BF16, out_bf16=o16t, aux=g16, flags=L.EPI_GELU_BWD | L.EPI_SAVE_DGELU)        # no column sums
+    assert rel(o16t.float(), want2) < 3e-3

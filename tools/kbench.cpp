@@ -191,11 +191,13 @@ int main(int argc, char** argv) {
             {"qkv NT", HS_GEMM_NT, M, 2304, 768, 0}, {"proj NT", HS_GEMM_NT, M, 768, 768, 0}, {"fc1 NT", HS_GEMM_NT, M, 3072, 768, 0},
             {"fc2 NT", HS_GEMM_NT, M, 768, 3072, 0}, {"dgrad fc2 NN", HS_GEMM_NN, M, 3072, 768, 0}, {"dgrad fc1 NN", HS_GEMM_NN, M, 768, 3072, 0},
             {"dgrad qkv NN", HS_GEMM_NN, M, 768, 2304, 0}, {"dgrad proj NN", HS_GEMM_NN, M, 768, 768, 0},
+            {"dgrad qkv as NT", HS_GEMM_NT, M, 768, 2304, 0},   // (the dgrads against a transposed weight copy: fc1 = "fc2 NT", proj = "proj NT", fc2 = "fc1 NT")
             {"wgrad fc1 TN", HS_GEMM_TN, 3072, 768, M, 0}, {"wgrad fc2 TN", HS_GEMM_TN, 768, 3072, M, 0}, {"wgrad qkv TN", HS_GEMM_TN, 2304, 768, M, 0},
             {"wgrad proj TN", HS_GEMM_TN, 768, 768, M, 0}, {"sq NT 4096", HS_GEMM_NT, 4096, 4096, 4096, 0}, {"sq NT 8192", HS_GEMM_NT, 8192, 8192, 8192, 0},
             // the fused epilogues of the encoder layer, as vit.hip launches them
             {"fc1+gelu NT epi", HS_GEMM_NT, M, 3072, 768, HS_EPI_BIAS | HS_EPI_GELU | HS_EPI_SAVE_DGELU}, {"fc2+resid NT epi", HS_GEMM_NT, M, 768, 3072, HS_EPI_BIAS | HS_EPI_RESID},
-            {"proj+resid NT epi", HS_GEMM_NT, M, 768, 768, HS_EPI_BIAS | HS_EPI_RESID}, {"dgrad fc2 gelu' NN epi", HS_GEMM_NN, M, 3072, 768, HS_EPI_GELU_BWD | HS_EPI_SAVE_DGELU}};
+            {"proj+resid NT epi", HS_GEMM_NT, M, 768, 768, HS_EPI_BIAS | HS_EPI_RESID}, {"dgrad fc2 gelu' NN epi", HS_GEMM_NN, M, 3072, 768, HS_EPI_GELU_BWD | HS_EPI_SAVE_DGELU},
+            {"dgrad fc2 gelu' as NT epi", HS_GEMM_NT, M, 3072, 768, HS_EPI_GELU_BWD | HS_EPI_SAVE_DGELU}};
         for (const Sh& s : shapes) {
             if (*filt && !strstr(s.name, filt)) continue;
             const bool tn = s.lay == HS_GEMM_TN;
