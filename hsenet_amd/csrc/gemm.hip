@@ -1195,7 +1195,7 @@ extern "C" int hs_gemm_group(const hs_gemm_args* args, int count, void* stream) 
     }
     g.first[count] = nblocks;
     g.count = count;
-    ProfScope prof(HS_PROF_GEMM_NT + HS_GEMM_TN, stream, flops, bytes);
+    ProfScope prof(HS_PROF_GEMM_TN_GROUP, stream, flops, bytes);
     hipLaunchKernelGGL((gemm_bf16_group_kernel<true, true, false, HS_EPI_ATOMIC>), dim3(nblocks), dim3(512), 0, (hipStream_t)stream, g);
     HS_CHECK_LAUNCH();
     return HS_OK;
@@ -1240,8 +1240,7 @@ extern "C" int hs_gemm(const hs_gemm_args* a, int prec, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     const int zdim = a->split_k > 1 ? a->split_k : a->batch;
     const double mnk = (double)a->M * a->N * a->K * a->batch;
-    ProfScope prof(HS_PROF_GEMM_NT + a->layout, stream, 2.0 * mnk,
-                   ((double)a->M * a->K + (double)a->N * a->K) * a->batch * esz + (double)a->M * a->N * a->batch * (a->out_f32 ? 4 : 2));
+    const double prof_bytes = ((double)a->M * a->K + (double)a->N * a->K) * a->batch * esz + (double)a->M * a->N * a->batch * (a->out_f32 ? 4 : 2);
     if (prec == HS_PREC_BF16) {
         // tile choice: the 256x256 tile does twice the MFMA work per barrier / DMA piece / LDS read.  Measured on the layer's shapes
         // at 1-4 volumes (4097-16388 rows): it wins by 4-28 % as soon as the 256x128 tile would need a second round of the chip's CUs
@@ -1271,6 +1270,12 @@ extern "C" int hs_gemm(const hs_gemm_args* a, int prec, void* stream) {
         p.nblocks = (int)grid.x;
         const bool m16_ok = m16 && col8 && (f == 0 || f == (HS_EPI_BIAS | HS_EPI_RESID) || f == (HS_EPI_BIAS | HS_EPI_GELU | HS_EPI_SAVE_DGELU) ||
                                             (f == (HS_EPI_GELU_BWD | HS_EPI_SAVE_DGELU) && !(((uintptr_t)a->aux) & 15)));
+        // profiling class = the kernel function: the four 16x16x32 instantiations are the encoder layer's hot GEMMs
+        const int pclass = !m16_ok ? HS_PROF_GEMM_NT + a->layout
+                         : f == 0 ? HS_PROF_GEMM_NT16_PLAIN
+                         : f == (HS_EPI_BIAS | HS_EPI_RESID) ? HS_PROF_GEMM_NT16_RESID
+                         : f == (HS_EPI_GELU_BWD | HS_EPI_SAVE_DGELU) ? HS_PROF_GEMM_NT16_DGELU : HS_PROF_GEMM_NT16_GELU;
+        ProfScope prof(pclass, stream, 2.0 * mnk, prof_bytes);
         if (m16_ok) {
             if (f == 0) HS_LAUNCH_M16(0);
             else if (f == (HS_EPI_BIAS | HS_EPI_RESID)) HS_LAUNCH_M16(HS_EPI_BIAS | HS_EPI_RESID);
@@ -1292,6 +1297,7 @@ extern "C" int hs_gemm(const hs_gemm_args* a, int prec, void* stream) {
 #undef HS_LAUNCH_E
 #undef HS_LAUNCH_M16
     } else {
+        ProfScope prof(HS_PROF_GEMM_NT + a->layout, stream, 2.0 * mnk, prof_bytes);
         p.tiles_m = (a->M + 63) / 64;
         dim3 grid(p.tiles_m * ((a->N + 63) / 64), 1, zdim);
         if (a->layout == HS_GEMM_NT) hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(256), 0, s, p);

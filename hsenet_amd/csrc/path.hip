@@ -554,7 +554,7 @@ extern "C" int hs_adamw_masked(float* p, const float* g, float* m, float* v, con
     if (grad_sumsq && !(max_grad_norm > 0.f)) return HS_ERR_ARG;
     const float bc1 = 1.0f - powf(beta1, (float)step);
     const float bc2s = sqrtf(1.0f - powf(beta2, (float)step));
-    ProfScope prof(HS_PROF_OTHER, stream, 0, (double)n * 28);
+    ProfScope prof(HS_PROF_ADAMW, stream, 0, (double)n * 28);
     hipLaunchKernelGGL(adamw_masked_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, decay_mask,
                        (long)n, lr, beta1, beta2, eps, weight_decay, grad_scale, grad_sumsq, max_grad_norm, bc1, bc2s);
     HS_CHECK_LAUNCH();

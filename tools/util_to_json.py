@@ -19,10 +19,13 @@ import sys
 out, batch = sys.argv[1], int(sys.argv[2])
 workload = sys.argv[3] if len(sys.argv) > 3 else "dual256"
 tag = sys.argv[4] if len(sys.argv) > 4 else "r03"
-CLASS = {"attn_fwd_fast_kernel": "attn_fwd", "attn_bwd_dkdv16_w4_kernel": "attn_bwd_dkdv", "attn_bwd_dq2_kernel": "attn_bwd_dq",
-         "gemm_bf16_kernel<false, false": "gemm_nt", "gemm_bf16_kernel<false, true": "gemm_nn", "gemm_bf16_kernel<true, true": "gemm_tn",
-         "gemm_bf16_group_kernel<true, true": "gemm_tn_group", "layernorm_bwd_kernel": "layernorm_bwd",
-         "layernorm_fwd_kernel": "layernorm_fwd", "adamw_masked_kernel": "adamw", "patchify_kernel": "patchify"}
+# kernel-name substring -> class (= hs_prof_name() of the library's per-kernel timers); first match wins
+CLASS = [("attn_fwd_fast_kernel", "attn_fwd"), ("attn_bwd_dkdv16_w4_kernel", "attn_bwd_dkdv"), ("attn_bwd_dq2_kernel", "attn_bwd_dq"),
+         ("gemm_bf16_kernel<false, false, true, 0, true>", "gemm_nt16_plain"), ("gemm_bf16_kernel<false, false, true, 9, true>", "gemm_nt16_bias_resid"),
+         ("gemm_bf16_kernel<false, false, true, 67, true>", "gemm_nt16_bias_gelu"), ("gemm_bf16_kernel<false, false, true, 68, true>", "gemm_nt16_dgelu"),
+         ("gemm_bf16_group_kernel<true, true", "gemm_tn_group"), ("gemm_bf16_kernel<false, false", "gemm_nt"), ("gemm_bf16_kernel<false, true", "gemm_nn"),
+         ("gemm_bf16_kernel<true, true", "gemm_tn"), ("layernorm_bwd_kernel", "layernorm_bwd"), ("layernorm_fwd_kernel", "layernorm_fwd"),
+         ("adamw_masked_kernel", "adamw"), ("patchify_kernel", "patchify")]
 
 
 def mfma_flops(name):
@@ -34,7 +37,7 @@ def mfma_flops(name):
 
 
 def klass(name):
-    for k, c in CLASS.items():
+    for k, c in CLASS:
         if k in name:
             return c
     return None
