@@ -335,9 +335,14 @@ int hs_relation_mse(const float* l_ref, const float* l, float* dl, float* loss, 
 int hs_ce_rows(const float* logits, float* dlogits, float* loss, int rows, int cols, int label0, float weight, int accumulate,
                void* stream);
 
-/* diagnostic: selects a kernel variant per class for tools/kbench A/B runs (every key defaults to 0 = the shipped kernel) */
+/* diagnostic: selects a kernel variant per class for tools/kbench A/B runs (every key defaults to 0 = the shipped kernel).
+ * The PRODUCT library honours only the selector whose variants compute the same result (key 0: 1 = the exact running-max
+ * attention forward alone instead of the optimistic kernel + fix-up pass); every other (key, value != 0) is refused with a
+ * one-time warning on stderr: the timing-only / truncating variants and the s_memtime stamps below are compiled only into
+ * -DHS_DEBUG_HOOKS builds (tools/build_variant.sh).  Process-global, not thread-safe. */
 void hs_debug_set(int key, int value);
-/* diagnostic (hs_debug_set(3, 4 | 7) / (3, 22), tools/kbench only): s_memtime phase sums of the bf16 GEMM's blocks (8 counters;
+/* diagnostic (-DHS_DEBUG_HOOKS builds: hs_debug_set(3, 4 | 7) / (3, 22), tools/kbench only; all zeros in the product library):
+ * s_memtime phase sums of the bf16 GEMM's blocks (8 counters;
  * reset != 0 clears them) / the per-block timeline {tile start, main loop end, epilogue end, HW_ID | XCC_ID << 32} of the first
  * min(nblocks, 4096) blocks of the last launch */
 void hs_debug_gemm_stamps(unsigned long long* out, int reset);
