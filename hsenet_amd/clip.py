@@ -17,7 +17,6 @@ All arithmetic runs in libhsenet_hip.so (exact-f32 MFMA GEMMs: the matrices are 
 from __future__ import annotations
 
 import math
-from typing import Optional
 
 import torch
 import torch.distributed as dist

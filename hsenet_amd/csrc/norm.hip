@@ -91,12 +91,13 @@ __device__ __forceinline__ float ln_bwd_out(float gy, float xh, float c1, float 
 
 // Each wave walks rows (grid-stride), keeps its dgamma/dbeta partials in registers, then the block reduces
 // through LDS and issues one float atomic per column.
+// (launch bounds: 4 blocks of 4 waves per CU, 3 for the d = 1024 instantiation whose row arrays need ~150 registers)
 // NCH = 256-column chunks per row actually used (d <= NCH*256): sizes the register arrays and the LDS reduction
 // buffer, which set the occupancy of this HBM-bound kernel (NCH=4 for every d cost 200 VGPRs / 48 KiB: 2 waves/SIMD).
 // WPB = waves per block: 4, or 8 for small row counts (one volume per GPU: 4097 rows) where a wave's rows are a serial chain of
 // load latencies -- 16 rows per block then take 2 steps per wave instead of 4 while the block's 3 x d reduction atomics stay the same.
 template <bool DYBF, int NCH, int WPB = 4>
-__global__ __launch_bounds__(WPB * 64, 16 / WPB) void layernorm_bwd_kernel(const void* __restrict__ dy_, const float* __restrict__ x,
+__global__ __launch_bounds__(WPB * 64, (NCH >= 4 && WPB == 4) ? 3 : 16 / WPB) void layernorm_bwd_kernel(const void* __restrict__ dy_, const float* __restrict__ x,
                                                             const float* __restrict__ resid, const float* __restrict__ gamma,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ dx_in, float* __restrict__ dx,

@@ -19,7 +19,7 @@ std::mutex g_mu;
 hipEvent_t get_event() {
     if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
     hipEvent_t e;
-    hipEventCreate(&e);
+    (void)hipEventCreate(&e);
     return e;
 }
 }  // namespace
@@ -29,7 +29,7 @@ int hs_prof_begin(int id, void* stream, double flops, double bytes) {
     std::lock_guard<std::mutex> lk(g_mu);
     Rec r;
     r.id = id; r.a = get_event(); r.b = get_event();
-    hipEventRecord(r.a, (hipStream_t)stream);
+    (void)hipEventRecord(r.a, (hipStream_t)stream);
     g_recs.push_back(r);
     g_flops[id] += flops;
     g_bytes[id] += bytes;
@@ -38,7 +38,7 @@ int hs_prof_begin(int id, void* stream, double flops, double bytes) {
 void hs_prof_end(int token, void* stream) {
     if (token < 0) return;
     std::lock_guard<std::mutex> lk(g_mu);
-    hipEventRecord(g_recs[token].b, (hipStream_t)stream);
+    (void)hipEventRecord(g_recs[token].b, (hipStream_t)stream);
 }
 
 extern "C" int hs_prof_enable(int on) {

@@ -10,7 +10,7 @@ bound per link, so buckets are kept large (a quarter of the encoder, ~85 MB fp32
 """
 from __future__ import annotations
 
-from typing import List, Optional, Sequence, Tuple
+from typing import List, Sequence, Tuple
 
 import torch
 import torch.distributed as dist

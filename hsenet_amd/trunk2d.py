@@ -16,8 +16,6 @@ instead (on the CPU restatement, in the CPU test suite) against HuggingFace's Vi
 ``hs_vit_desc.ln_eps = 1e-6`` and ``hs_vit_desc.qkv_bias``."""
 from __future__ import annotations
 
-import ctypes as C
-
 import torch
 from torch import nn
 

@@ -180,7 +180,7 @@ def _nccl_worker(rank, world, port, out):
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)            # RCCL, as bench.py initialises it
     try:
         from hsenet_amd.engine import FlatEncoder
-        from hsenet_amd.dp import gather_features, _AllGatherCat
+        from hsenet_amd.dp import _AllGatherCat
         eng = FlatEncoder(_model(dev), 2, lr=1e-3, weight_decay=0.1, n_buckets=2)
         eng.buckets.always = True                                                      # run the collectives at world size 1
         x = _vols().to(dev)
