@@ -264,3 +264,40 @@ def test_mrg_step_engine_vs_oracle(dev):
     for n, p in _named(tower, p1, p2):
         moved = float((p.detach() - before[n]).abs().max())
         assert (moved > 0) == n.startswith("mm_projector"), (n, moved)           # towers frozen, packers trained
+
+
+def test_forward_backward_capture_into_a_hip_graph(dev):
+    """the C ABI never allocates, frees or synchronises, so a sequence of calls can be captured in a hipGraph.  The
+    fused forward + backward of an encoder (hs_embed_* + hs_vit_blocks_* + the loss gradient: ~150 launches) is captured once and
+    replayed on NEW input written into the captured buffer; outputs and gradients must equal the eager run on that input."""
+    import hsenet_amd as H
+    from hsenet_amd import _lib as L, functional as Fn
+    from hsenet_amd.engine import FlatEncoder
+    from oracle import ref_cpu as R
+    kw = dict(in_channels=1, img_size=IMG, patch_size=PATCH, num_layers=2, pos_embed="perceptron", classification=True)
+    ref = R.ViT_stage1(**kw)
+    m = H.ViT_stage1(**kw).eval()
+    m.load_state_dict(R.seeded_state_dict(ref, 970))
+    eng = FlatEncoder(m.to(dev), 2)
+    xa, xb = R.synthetic_volume((2, 1) + IMG, 971).to(dev), R.synthetic_volume((2, 1) + IMG, 972).to(dev)
+
+    def fwd_bwd(x):
+        y = eng.forward(x)
+        L.call("hs_mse_grad", y.data_ptr(), eng.dy.data_ptr(), None, y.numel(), Fn._s())
+        eng.backward(eng.dy)
+        return y
+
+    y_b = fwd_bwd(xb).clone()                                      # eager reference on input B (also warms every lazy allocation up)
+    g_b = eng.grad.clone()
+    x = xa.clone()
+    fwd_bwd(x)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        y = fwd_bwd(x)
+    x.copy_(xb)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(y, y_b)
+    # weight gradients are float-atomic sums (split-K): equal up to the order of the adds
+    assert rel(eng.grad, g_b) < 1e-5
