@@ -5,7 +5,7 @@
 # then  python tools/traffic_to_json.py <outdir> <batch>  writes profiles/r02_traffic.json.
 # FETCH_SIZE is doubled when converting (MI355X_MICROARCH.md "HBM": gfx950 tallies 128-B requests at 64 B).
 set -e
-B=${1:-10}; OUT=${2:-gpurun_out/traffic}
+B=${1:-53}; OUT=${2:-gpurun_out/traffic}
 ROOT=$(pwd)
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp

@@ -4,7 +4,7 @@
 #     bash tools/collect_util.sh <batch> <outdir>
 # then  python tools/util_to_json.py <outdir> <batch> [workload] [round tag]  merges both into profiles/<tag>_pmc.json
 set -e
-B=${1:-20}; OUT=${2:-gpurun_out/traffic}
+B=${1:-53}; OUT=${2:-gpurun_out/traffic}
 ROOT=$(pwd)
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
