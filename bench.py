@@ -313,8 +313,16 @@ def main():
         torch.cuda.synchronize()
 
     def inputs(batch):
+        """two sets of `batch` synthetic volumes U[0,1) + slice features N(0,1), resident in HBM (default_rng(1234 + rank)).
+        Drawn and uploaded one volume (64 MiB) at a time: the same values as one (batch, 1, D, H, W) draw, without a multi-GB host array per
+        rank (53 volumes x 2 sets x 8 ranks would be 57 GB of host memory)."""
         rng = np.random.default_rng(1234 + rank)
-        vols = [torch.from_numpy(rng.random((batch, 1) + img, dtype=np.float32)).to(dev) for _ in range(2)]
+        vols = []
+        for _ in range(2):
+            v = torch.empty((batch, 1) + img, dtype=torch.float32, device=dev)
+            for i in range(batch):
+                v[i, 0].copy_(torch.from_numpy(rng.random(img, dtype=np.float32)))
+            vols.append(v)
         slices = [torch.from_numpy(rng.standard_normal((batch, 32, 768), dtype=np.float32)).to(dev) for _ in range(2)]
         return vols, slices
 
