@@ -275,6 +275,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-batch1", action="store_true")
     a = ap.parse_args()
+    batch_defaulted = a.batch is None
     if a.batch is None:
         a.batch = 1 if a.workload in ("clip_c4a", "mrg_c5") else DEFAULT_BATCH
 
@@ -326,8 +327,38 @@ def main():
         slices = [torch.from_numpy(rng.standard_normal((batch, 32, 768), dtype=np.float32)).to(dev) for _ in range(2)]
         return vols, slices
 
-    eng, pe, needs_2d = build_engine(a.workload, geom, a.batch, dev)
-    vols, slices = inputs(a.batch)
+    # The default batch takes ~200 GB of HBM.  If it does not fit (a GPU that is not empty), every rank falls back TOGETHER to the next
+    # smaller candidate -- the batch that ran is in config.batch_per_gpu; an explicit --batch is never changed.
+    reserve_gb = float(os.environ.get("HS_BENCH_RESERVE_GB", "0"))       # (test hook: occupy part of the HBM to exercise the fallback)
+    reserved = torch.empty(int(reserve_gb * 1e9), dtype=torch.uint8, device=dev) if reserve_gb > 0 else None
+    candidates = [a.batch] + ([b for b in (31, 20, 8) if b < a.batch] if batch_defaulted else [])
+    for cand in candidates:
+        eng = vols = slices = None
+        ok = 1
+        try:
+            eng, pe, needs_2d = build_engine(a.workload, geom, cand, dev)
+            vols, slices = inputs(cand)
+            if needs_2d:                                        # one untimed step: the engines size some workspaces on first use
+                eng.train_step(vols[0], slices[0])
+            else:
+                eng.train_step(vols[0])
+            torch.cuda.synchronize()
+        except torch.cuda.OutOfMemoryError:
+            ok = 0
+        if world > 1:
+            flag = torch.tensor([ok], device=dev, dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = int(flag.item())
+        if ok:
+            a.batch = cand
+            break
+        if rank == 0:
+            print(f"[bench] {cand} volumes per GPU do not fit in HBM here; trying a smaller batch", file=sys.stderr, flush=True)
+        del eng, vols, slices
+        torch.cuda.empty_cache()
+        torch.cuda.reset_peak_memory_stats(dev)
+    else:
+        sys.exit("bench.py: no candidate batch fits in HBM")
     dt, step = timed_run(eng, needs_2d, vols, slices, a.steps, a.warmup, sync)
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -397,7 +428,7 @@ def main():
         "model_tflops": round(vols_per_s * fb / 1e12, 2),
         "mfma_roofline_frac_end_to_end": round(vols_per_s * fb / 1e12 / (PEAK_BF16_TFLOPS * world), 4),
         "outputs_finite": finite,
-        "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 1e9, 2),
+        "peak_hbm_gb": round((torch.cuda.max_memory_allocated(dev) - (reserved.numel() if reserved is not None else 0)) / 1e9, 2),
     }
     if roof:
         out["roofline"] = roof
