@@ -1,0 +1,54 @@
+"""bench.py's host logic (no GPU): the algorithmic FLOP constants are SURVEY.md section 8(d)'s, the committed PMC summary is found for
+the default workload, and the last committed bench line of the default run keeps the driver's JSON contract."""
+import glob
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def test_algorithmic_flops_are_the_survey_numbers():
+    import bench
+    Np, Pd = 4096, 4096                                      # 256^3 volume, patch 16^3
+    enc = 2.0 * Np * Pd * 768 + 12 * (24.0 * 4097 * 768 * 768 + 4.0 * 4097 * 4097 * 768)
+    assert abs(enc - 1.3405e12) < 2e8                       # encoder forward at 256^3
+    assert abs(bench.flops_per_volume("vit256", Np, Pd) - 4.0215e12) < 1e9          # configs[1]: forward + backward = 3 x forward
+    dual = bench.flops_per_volume("dual256", Np, Pd)
+    assert abs(dual / 3.0 - 2.717e12) < 1e9 and abs(dual - 8.15e12) < 5e9           # configs[2]: C3 forward 2.717e12
+    assert abs(bench.flops_per_volume("clip_c4a", Np, Pd) - 5.39e12) < 2e10         # configs[3], the reference-faithful C4-A step
+    # the native geometry (32x256x256, patch 4x16x16): ViT-B forward 5.061e11
+    assert abs(bench.flops_per_volume("vit256", 2048, 1024) / 3.0 - 5.061e11) < 1e8
+
+
+def test_default_batch_and_pmc_summary_are_consistent():
+    import bench
+    assert bench.DEFAULT_BATCH == 53
+    blocks = bench.DEFAULT_BATCH * 33 * 12                   # attention-backward grid: 33 blocks of 128 keys/queries x 12 heads per volume
+    assert abs(blocks / 512.0 - round(blocks / 512.0)) < 0.02 and blocks / 512.0 < round(blocks / 512.0)      # just under a whole number of rounds
+    pmc = bench.measured_pmc("attn_bwd_dkdv", bench.DEFAULT_BATCH, "dual256")
+    assert pmc and pmc["source"].startswith("profiles/") and pmc["hbm_bytes_per_launch"] > 1e9 and 0.4 < pmc["mfma_busy_frac"] < 0.8
+    assert bench.measured_pmc("attn_bwd_dkdv", 7, "dual256") == {}                  # nothing committed for that batch: traffic = null
+
+
+def test_committed_bench_line_keeps_the_contract():
+    lines = sorted(glob.glob(os.path.join(ROOT, "profiles", "r03_*_bench_dual_batch53.json")))
+    assert lines, "the bench line of the default run is committed with the profiles"
+    d = json.load(open(lines[-1]))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "CT-volumes/sec" and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["config"]["workload"].startswith("BASELINE configs[2]") and d["config"]["batch_per_gpu"] == 53 and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["kernel"] == "attn_bwd_dkdv" and r["traffic"] > 0
+    # achieved = algorithmic FLOPs per launch / average launch time (6 N^2 d per (batch, head): dV, dP, dK of SURVEY 8(d)'s 8 N^2 d backward)
+    assert abs(r["flops_per_launch"] - 6.0 * 4097 ** 2 * 64 * 12 * 53) < 1e6
+    assert abs(r["achieved"] - r["flops_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e12) < 1.0
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    # the step is the sum of its kernels: per-class totals of the instrumented pass (3 steps) against ms_per_step
+    total = sum(k["total_ms"] for k in d["kernels"]) / 3.0
+    assert abs(total - d["ms_per_step"]) < 0.03 * d["ms_per_step"], (total, d["ms_per_step"])
