@@ -749,40 +749,11 @@ __global__ __launch_bounds__(256) void attn_bwd_f32_kernel(const float* __restri
 // backward, bf16
 // ------------------------------------------------------------------------------------------------------
 // ------------------------------------------------------------------------------------------------------
-// backward v2.  attn_stats_kernel leaves, per (b, head, query): ws[0] = -delta = -sum_d dO*O and ws[1] = -lse*log2(e), the
+// backward v2.  Per (b, head, query): ws[0] = -delta = -sum_d dO*O and ws[1] = -lse*log2(e) (written by the dQ sweep, which runs first), the
 // two row constants both sweeps preload into their MFMA accumulators (S' = q'.k - lse*log2e, dP' = dO.v - delta), so
 // that P = exp2(S') and dS = P * dP' need no subtraction (cdna guide, attention backward, "row constants as the initial
 // accumulator").  P = exp2(S' ) <= 1 always: unlike the forward fast path nothing here is optimistic.
 // ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_stats_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ d_o,
-                                                         const float* __restrict__ lse, float* __restrict__ ws, int B, int N, int H) {
-    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
-    const long total = (long)B * N * H * 8;
-    float acc = 0.f;
-    const bool ok = gid < total;
-    if (ok) {
-        const u32x4 a = *(const u32x4*)(o + gid * 8);
-        const u32x4 g = *(const u32x4*)(d_o + gid * 8);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            acc += __uint_as_float(a[i] << 16) * __uint_as_float(g[i] << 16);
-            acc += __uint_as_float(a[i] & 0xffff0000u) * __uint_as_float(g[i] & 0xffff0000u);
-        }
-    }
-    acc += __shfl_xor(acc, 1, 64);
-    acc += __shfl_xor(acc, 2, 64);
-    acc += __shfl_xor(acc, 4, 64);
-    if (ok && (threadIdx.x & 7) == 0) {
-        const long row = gid >> 3;  // (b*N + n)*H + head
-        const int head = (int)(row % H);
-        const long bn = row / H;
-        const int n = (int)(bn % N), b = (int)(bn / N);
-        const long i = ((long)b * H + head) * N + n;
-        ws[i] = -acc;
-        ws[(long)B * H * N + i] = -lse[i] * 1.44269504088896341f;
-    }
-}
-
 __device__ __forceinline__ void lds_settle4(u32x4& a, u32x4& b, u32x4& c, u32x4& d) {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)::"memory");
 }
@@ -806,9 +777,14 @@ __device__ __forceinline__ int offR16(int r, int c) { return r * 128 + ((c ^ swz
 // dS^T = exp2(S'^T) * dP'^T -> bf16 -> dQ^T[d][q] += K^T dS^T (K read transposed from the same image).
 // NW = 4 with two blocks per CU: the two waves of a SIMD then belong to different blocks and drift out of phase, so one
 // wave's exp/convert stretch runs under the other's MFMAs (two waves of ONE block are phase-locked by the tile barrier).
+// The dQ sweep runs FIRST and also produces the two row constants (round 3; there used to be a separate statistics kernel that read
+// O and dO once more): a wave holds the dO rows of its 32 queries as MFMA operands anyway, so it loads the matching O rows (16 B per
+// lane and k-step), forms delta = sum_d dO*O in registers (8 products per k-step and lane, the two lanes of a row combined by one
+// shuffle), takes lse from the forward, and writes ws[0] = -delta, ws[1] = -lse*log2(e) for the dK/dV sweep launched after it.
 template <int NW>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void attn_bwd_dq2_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
-                                                           const float* __restrict__ ws, bf16_t* __restrict__ dqkv, int B,
+                                                           const bf16_t* __restrict__ o, const float* __restrict__ lse,
+                                                           float* __restrict__ ws, bf16_t* __restrict__ dqkv, int B,
                                                            int N, int H, float qmul, float out_mul) {
     __shared__ __attribute__((aligned(16))) char smem[3 * 16384];
     constexpr int QB = NW * 32, NP = 8 / NW;                 // queries per block; K (and V) DMA pieces per wave per tile
@@ -846,13 +822,28 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void attn_bwd_dq2_kernel(
 
     const int qrow = min(q0 + c, N - 1);
     bf16x8 qf[4], dof[4];
+    const __amdgpu_buffer_rsrc_t rso = make_rsrc(o + (long)b * N * Dm, (size_t)N * Dm * 2);
+    float dsum = 0.f;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
         qf[ks] = scale_frag(buf_load16(rs, (unsigned)(((long)qrow * D3 + head * 64 + ks * 16 + 8 * h) * 2)), qmul);
-        dof[ks] = __builtin_bit_cast(bf16x8, buf_load16(rsd, (unsigned)(((long)qrow * Dm + head * 64 + ks * 16 + 8 * h) * 2)));
+        const unsigned off = (unsigned)(((long)qrow * Dm + head * 64 + ks * 16 + 8 * h) * 2);
+        const u32x4 g = buf_load16(rsd, off), a = buf_load16(rso, off);
+        dof[ks] = __builtin_bit_cast(bf16x8, g);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            dsum += __uint_as_float(a[i] << 16) * __uint_as_float(g[i] << 16);
+            dsum += __uint_as_float(a[i] & 0xffff0000u) * __uint_as_float(g[i] & 0xffff0000u);
+        }
     }
+    dsum += __shfl_xor(dsum, 32, 64);                        // lanes c and c + 32 hold the two halves of every 16-wide k-step of row qrow
     const long srow = ((long)b * H + head) * N + qrow;
-    f32x16 cd = splat16(ws[srow]), cl = splat16(ws[(long)B * H * N + srow]);
+    const float nd = -dsum, nl = -lse[srow] * 1.44269504088896341f;
+    if (h == 0 && q0 + c < N) {                              // one writer per query row (rows past N are clamped duplicates)
+        ws[srow] = nd;
+        ws[(long)B * H * N + srow] = nl;
+    }
+    f32x16 cd = splat16(nd), cl = splat16(nl);
     asm volatile("" : "+v"(cd), "+v"(cl));          // opaque: keep the 2 x 16 registers instead of re-splatting per use
     unsigned rb0[4];                                         // row-fragment bases: row c, chunk 2ks+h (image R swizzle)
 #pragma unroll
@@ -1286,28 +1277,22 @@ extern "C" int hs_attn_bwd(const void* qkv, const void* o, const void* d_o, cons
     const float c2 = pre ? 1.0f : scale * LOG2E;
     const float dk_mul = pre ? 1.0f / LOG2E : scale;        // dK = dh^-0.5 dS^T q = dS^T q' / log2(e)
     hipStream_t s = (hipStream_t)stream;
-    const long total = (long)B * N * H * 8;
     // FLOP credit follows SURVEY.md 8(d): the backward's ALGORITHMIC work is 2.0 x the forward's 4*nn (dV, dP, dQ, dK: four
     // products); the recomputation of S (both kernels) and of dP (dQ kernel) is executed but NOT counted.  dK/dV kernel: dV, dP, dK
     // = 6*nn (executes 8*nn); dQ kernel: dQ = 2*nn (executes 6*nn).
     const double nn = (double)B * H * N * N * 64;
     const double io = (double)B * N * H * 64 * 2;
     float* nstat = delta_ws;                                  // [0] = -delta, [1] = -lse*log2e   (2 x [B][H][N])
-    {
-        ProfScope prof(HS_PROF_ATTN_DELTA, stream, 0, 2 * io);
-        hipLaunchKernelGGL(attn_stats_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const bf16_t*)o,
-                           (const bf16_t*)d_o, lse, nstat, B, N, H);
-    }
     dim3 grid((unsigned)(((N + 127) / 128) * H * B));
+    {   // the dQ sweep first: it also writes the row constants the dK/dV sweep preloads (no separate statistics pass)
+        ProfScope prof(HS_PROF_ATTN_DQ, stream, 2.0 * nn, 6 * io);
+        hipLaunchKernelGGL(attn_bwd_dq2_kernel<4>, grid, dim3(256), 0, s, (const bf16_t*)qkv, (const bf16_t*)d_o, (const bf16_t*)o, lse,
+                           nstat, (bf16_t*)dqkv, B, N, H, c2, scale);
+    }
     {
         ProfScope prof(HS_PROF_ATTN_DKDV, stream, 6.0 * nn, 6 * io);
         hipLaunchKernelGGL(attn_bwd_dkdv16_w4_kernel, grid, dim3(256), 0, s, (const bf16_t*)qkv, (const bf16_t*)d_o, nstat,
                            (bf16_t*)dqkv, B, N, H, c2, dk_mul);
-    }
-    {
-        ProfScope prof(HS_PROF_ATTN_DQ, stream, 2.0 * nn, 5 * io);
-        hipLaunchKernelGGL(attn_bwd_dq2_kernel<4>, grid, dim3(256), 0, s, (const bf16_t*)qkv, (const bf16_t*)d_o, nstat,
-                           (bf16_t*)dqkv, B, N, H, c2, scale);
     }
     HS_CHECK_LAUNCH();
     return HS_OK;
