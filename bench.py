@@ -338,10 +338,11 @@ def main():
         try:
             eng, pe, needs_2d = build_engine(a.workload, geom, cand, dev)
             vols, slices = inputs(cand)
-            if needs_2d:                                        # one untimed step: the engines size some workspaces on first use
-                eng.train_step(vols[0], slices[0])
-            else:
-                eng.train_step(vols[0])
+            if world == 1:                                      # one untimed step: the engines size some workspaces on first use
+                if needs_2d:                                    # (not with several ranks: a step contains collectives, and a rank that ran
+                    eng.train_step(vols[0], slices[0])          # out of memory inside it would leave the others waiting)
+                else:
+                    eng.train_step(vols[0])
             torch.cuda.synchronize()
         except torch.cuda.OutOfMemoryError:
             ok = 0
