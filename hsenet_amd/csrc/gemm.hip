@@ -417,28 +417,36 @@ template <int CNT>
 __device__ __forceinline__ void lds_wait8g(u32x4& a, u32x4& b, u32x4& c, u32x4& d, u32x4& e, u32x4& f, u32x4& g, u32x4& i) {
     asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(i) : "i"(CNT) : "memory");
 }
+// Stages (round 3): THREE for A, two for B.  With two 64-KiB stages (rounds 1-2) this loop ran at ~73 % of the MFMA rate, held by the
+// LATENCY of L2 misses, not by bandwidth: nearly every K-tile has a piece that comes from beyond the L2 (the A
+// panel is streamed from HBM once: compulsory), a K-tile is complete when its slowest piece has landed, and two stages gave A one
+// K-tile of prefetch distance (B 0.75).  This kernel's epilogue does not stage through LDS, so the whole 160 KiB are free for
+// operands: 3 x 32 KiB of A + 2 x 32 KiB of B (qkv 899 -> 830 us, fc2 1013 -> 931, 8192^3 1127 -> 1252 TFLOP/s; in the engine the four
+// instantiations gained 8-18 %, the step 3.1 %).  A(t+2) is issued in phase 0
+// of tile t (1.75 K-tiles before the barrier that needs it), B(t+2) in phase 3 of tile t (1.0 K-tile); the issue ORDER B(t+1) < A(t+2)
+// makes "everything but the newest 4 pieces" exactly the pieces barrier(t) needs (A(t+1), B(t+1)), so the wait is a counted vmcnt(4).
+//   LDS: A stages at 0 / 32 K / 64 K, B stages at 96 K / 128 K.
 __device__ __forceinline__ void big_mainloop16(f32x4 (&acc)[8][4], char* smem, int row0, int col0, int wave, int lane,
-                                               __amdgpu_buffer_rsrc_t rsA, __amdgpu_buffer_rsrc_t rsB, const unsigned (&va)[4],
-                                               const unsigned (&vb)[4], unsigned ka, unsigned kb, int kt0, int kt1, int dbg) {
-    constexpr int STAGE = GCfg<true>::STAGE;
-    unsigned long long t_sync = 0, t_lds = 0, t_vm = 0;
+                                                  __amdgpu_buffer_rsrc_t rsA, __amdgpu_buffer_rsrc_t rsB, const unsigned (&va)[4],
+                                                  const unsigned (&vb)[4], unsigned ka, unsigned kb, int kt0, int kt1) {
+    constexpr unsigned AST = 32768u, BBASE = 98304u;
     const int r = lane & 15, q = lane >> 4, f = swzR16(r);
     unsigned ab0[2], bb0[2];
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
         ab0[st] = lds_off(smem) + (row0 + r) * 128 + (((4 * st + q) ^ f) << 4);
-        bb0[st] = lds_off(smem) + 32768 + (col0 + r) * 128 + (((4 * st + q) ^ f) << 4);
+        bb0[st] = lds_off(smem) + BBASE + (col0 + r) * 128 + (((4 * st + q) ^ f) << 4);
     }
     u32x4 fa[2][4], fb[2][4];
-    auto rdA = [&](auto set_tag, auto st_tag, auto hf_tag, unsigned so) {
+    auto rdA = [&](auto set_tag, auto st_tag, auto hf_tag, unsigned sa) {
         constexpr int S = decltype(set_tag)::value, ST = decltype(st_tag)::value, HF = decltype(hf_tag)::value;
-        const unsigned a = ab0[ST] + so;
+        const unsigned a = ab0[ST] + sa;
         ldsr128<(HF * 4 + 0) * 2048>(fa[S][0], a); ldsr128<(HF * 4 + 1) * 2048>(fa[S][1], a);
         ldsr128<(HF * 4 + 2) * 2048>(fa[S][2], a); ldsr128<(HF * 4 + 3) * 2048>(fa[S][3], a);
     };
-    auto rdB = [&](auto set_tag, auto st_tag, unsigned so) {
+    auto rdB = [&](auto set_tag, auto st_tag, unsigned sb) {
         constexpr int S = decltype(set_tag)::value, ST = decltype(st_tag)::value;
-        const unsigned b = bb0[ST] + so;
+        const unsigned b = bb0[ST] + sb;
         ldsr128<0>(fb[S][0], b); ldsr128<2048>(fb[S][1], b); ldsr128<4096>(fb[S][2], b); ldsr128<6144>(fb[S][3], b);
     };
     auto mma = [&](auto aset_tag, auto bset_tag, auto hf_tag) {
@@ -449,59 +457,57 @@ __device__ __forceinline__ void big_mainloop16(f32x4 (&acc)[8][4], char* smem, i
             for (int j = 0; j < 4; ++j)
                 acc[HF * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(fb[SB][j]), as_frag(fa[SA][i]), acc[HF * 4 + i][j], 0, 0, 0);
     };
-    auto dma = [&](int kt, unsigned so, int q0) {
-        char* sa = smem + so;
+    auto dmaA = [&](int kt, unsigned sa) {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            if (q0 == 0) dma_piece(rsA, sa, p, wave, va[p], (unsigned)kt * ka);
-            else dma_piece(rsB, sa + 32768, p, wave, vb[p], (unsigned)kt * kb);
-        }
+        for (int p = 0; p < 4; ++p) dma_piece(rsA, smem + sa, p, wave, va[p], (unsigned)kt * ka);
+    };
+    auto dmaB = [&](int kt, unsigned sb) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) dma_piece(rsB, smem + BBASE + sb, p, wave, vb[p], (unsigned)kt * kb);
     };
     typedef std::integral_constant<int, 0> I0;
     typedef std::integral_constant<int, 1> I1;
-    dma(kt0, 0, 0);
-    dma(kt0, 0, 4);
+    // prologue, in the order the counted waits rely on: A(0), B(0), A(1), B(1)
+    dmaA(kt0, 0u);
+    dmaB(kt0, 0u);
     if (kt0 + 1 < kt1) {
-        dma(kt0 + 1, STAGE, 0);
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        dmaA(kt0 + 1, AST);
+        dmaB(kt0 + 1, AST);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
     rdA(I0{}, I0{}, I0{}, 0u);
     rdB(I0{}, I0{}, 0u);
-    unsigned so = 0;
+    unsigned sa = 0, sb = 0;                                   // stages of tile kt: A (kt - kt0) % 3, B (kt - kt0) % 2
     for (int kt = kt0; kt < kt1; ++kt) {
         const bool has1 = kt + 1 < kt1, has2 = kt + 2 < kt1;
-        const unsigned so1 = so ^ (unsigned)STAGE;
+        const unsigned sa1 = sa == 2 * AST ? 0u : sa + AST, sa2 = sa1 == 2 * AST ? 0u : sa1 + AST, sb1 = sb ^ AST;
         // phase 0: (step 0, rows 0-63)
-        rdA(I1{}, I0{}, I1{}, so);
+        rdA(I1{}, I0{}, I1{}, sa);
         lds_wait8g<4>(fa[0][0], fa[0][1], fa[0][2], fa[0][3], fb[0][0], fb[0][1], fb[0][2], fb[0][3]);
         mma(I0{}, I0{}, I0{});
-        if (has1) dma(kt + 1, so1, 4);
+        if (has2) dmaA(kt + 2, sa2);                            // the stage tile kt-1 was read from (every wave passed barrier(kt-1) since)
         // phase 1: (step 0, rows 64-127)
-        rdA(I0{}, I1{}, I0{}, so);
-        rdB(I1{}, I1{}, so);
+        rdA(I0{}, I1{}, I0{}, sa);
+        rdB(I1{}, I1{}, sb);
         lds_wait4<8>(fa[1][0], fa[1][1], fa[1][2], fa[1][3]);
         mma(I1{}, I0{}, I1{});
         // phase 2: (step 1, rows 0-63)
-        rdA(I1{}, I1{}, I1{}, so);
+        rdA(I1{}, I1{}, I1{}, sa);
         lds_wait8g<4>(fa[0][0], fa[0][1], fa[0][2], fa[0][3], fb[1][0], fb[1][1], fb[1][2], fb[1][3]);
         mma(I0{}, I1{}, I0{});
-        unsigned long long t0_ = HS_DBG(dbg) == 4 ? __builtin_amdgcn_s_memtime() : 0ull;
-        lds_wait4<0>(fa[1][0], fa[1][1], fa[1][2], fa[1][3]);       // every read of this stage has landed
-        unsigned long long t1_ = HS_DBG(dbg) == 4 ? __builtin_amdgcn_s_memtime() : 0ull;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        unsigned long long t15_ = HS_DBG(dbg) == 4 ? __builtin_amdgcn_s_memtime() : 0ull;
+        lds_wait4<0>(fa[1][0], fa[1][1], fa[1][2], fa[1][3]);       // every read of this tile's stages has landed
+        if (has2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // A(kt+1), B(kt+1) landed; A(kt+2) stays in flight
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (HS_DBG(dbg) == 4) { const unsigned long long t2_ = __builtin_amdgcn_s_memtime(); t_lds += t1_ - t0_; t_sync += t2_ - t15_; t_vm += t15_ - t1_; }
         // phase 3: (step 1, rows 64-127) || first fragments of the next tile
-        if (has1) { rdA(I0{}, I0{}, I0{}, so1); rdB(I0{}, I0{}, so1); }
+        if (has1) { rdA(I0{}, I0{}, I0{}, sa1); rdB(I0{}, I0{}, sb1); }
         mma(I1{}, I1{}, I1{});
-        if (has2) dma(kt + 2, so, 0);
-        so = so1;
+        if (has2) dmaB(kt + 2, sb);                             // this tile's B stage: free since the barrier
+        sa = sa1; sb = sb1;
     }
-    if (HS_DBG(dbg) == 4 && threadIdx.x == 0) { atomicAdd(&g_gemm_stamps[5], t_sync); atomicAdd(&g_gemm_stamps[6], t_lds); atomicAdd(&g_gemm_stamps[7], t_vm); }
 }
 
 // diagnostic (dbg == 4): per-phase cycle sums of the epilogue, wave 0 lane 0 of every block (tools/kbench)
@@ -720,7 +726,7 @@ template <bool ATR, bool BTR, bool BIG, int EF, bool M16 = false>
 __device__ __forceinline__ void gemm_bf16_body(const GemmP& p, const int b_, const int nb_) {
     static_assert(!M16 || (BIG && !ATR && !BTR), "the 16x16x32 main loop exists for the 256x256 NT tile");
     typedef GCfg<BIG> C;
-    __shared__ __attribute__((aligned(16))) char smem[C::SMEM];
+    __shared__ __attribute__((aligned(16))) char smem[M16 ? 163840 : C::SMEM];     // (16x16x32 kernels: 3 A + 2 B stages, no epilogue staging)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = BIG ? wave >> 2 : wave >> 1, wn = BIG ? wave & 3 : wave & 1;
@@ -792,7 +798,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmP& p, const int b_, con
     if (HS_DBG(p.dbg_) == 22 && threadIdx.x == 0 && blockIdx.x < 4096)
         g_gemm_trace[blockIdx.x * 4 + 3] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
     if constexpr (M16) {
-        big_mainloop16(acc16, smem, row0, col0, wave, lane, rsA, rsB, va, vb, ka, kb, kt0, kt1, HS_DBG(p.dbg_) == 7 ? 4 : HS_DBG(p.dbg_));
+        big_mainloop16(acc16, smem, row0, col0, wave, lane, rsA, rsB, va, vb, ka, kb, kt0, kt1);
     } else if constexpr (BIG) {
         big_mainloop<BTR>(acc, smem, row0, col0, wave, lane, rsA, rsB, va, vb, ka, kb, kt0, kt1, HS_DBG(p.dbg_));
     } else {
