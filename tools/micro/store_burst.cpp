@@ -54,11 +54,12 @@ int main() {
     unsigned short* out; CK(hipMalloc(&out, (size_t)4096 * 256 * 256 * 2));
     unsigned long long *ti, *td; CK(hipMalloc(&ti, maxb * 8)); CK(hipMalloc(&td, maxb * 8));
     std::vector<unsigned long long> hi(maxb), hd(maxb);
-    struct Cfg { long ld; int tiles_n, wide, nt, dirty, spin, rd_kb; } cfgs[] = {{2304, 9, 0, 0, 0, 1500, 0}, {2304, 9, 0, 0, 0, 3000, 0}, {2304, 9, 0, 0, 0, 0, 384}, {2304, 9, 0, 0, 0, 1500, 384}, {2304, 9, 0, 1, 0, 1500, 384}};
+    struct Cfg { long ld; int tiles_n, wide, nt, dirty, spin, rd_kb; } cfgs[] = {{2304, 9, 0, 0, 0, 1500, 0}, {2304, 9, 1, 0, 0, 1500, 0}, {2304, 9, 0, 1, 0, 1500, 0},
+                                                                                 {2304, 9, 1, 1, 0, 1500, 0}, {2304, 9, 0, 1, 0, 1500, 384}, {2304, 9, 1, 1, 0, 1500, 384}};
     for (const Cfg& c : cfgs) {
         const long ld = c.ld; const int spin = c.spin;
         printf("ld %ld tiles_n %d wide %d nontemporal %d caches pre-filled with dirty lines %d\n", c.ld, c.tiles_n, c.wide, c.nt, c.dirty); printf("  spin %d, reads %d KiB per operand per block\n", c.spin, c.rd_kb);
-        for (int nb : {256, 2880}) {
+        for (int nb : {32, 256, 2880}) {
             for (int rep = 0; rep < 3; ++rep) {
                 hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
                 if (c.dirty) hipLaunchKernelGGL(dirty_fill, dim3(2048), dim3(256), 0, 0, scratch, nscr);
