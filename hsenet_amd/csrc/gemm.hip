@@ -1274,16 +1274,18 @@ extern "C" int hs_gemm(const hs_gemm_args* a, int prec, void* stream) {
         const bool m16 = big && a->layout == HS_GEMM_NT && (!a->colsum_out || a->flags == (HS_EPI_GELU_BWD | HS_EPI_SAVE_DGELU)) && !kEnv.no_m16;
 #define HS_LAUNCH_M16(EF) hipLaunchKernelGGL((gemm_bf16_kernel<false, false, true, EF, true>), grid, dim3(512), 0, s, p)
         p.nblocks = (int)grid.x;
-        const bool m16_ok = m16 && col8 && (f == 0 || f == (HS_EPI_BIAS | HS_EPI_RESID) || f == (HS_EPI_BIAS | HS_EPI_GELU | HS_EPI_SAVE_DGELU) ||
+        const bool m16_ok = m16 && col8 && (f == 0 || f == HS_EPI_BIAS || f == (HS_EPI_BIAS | HS_EPI_RESID) || f == (HS_EPI_BIAS | HS_EPI_GELU | HS_EPI_SAVE_DGELU) ||
                                             (f == (HS_EPI_GELU_BWD | HS_EPI_SAVE_DGELU) && !(((uintptr_t)a->aux) & 15)));
         // profiling class = the kernel function: the four 16x16x32 instantiations are the encoder layer's hot GEMMs
         const int pclass = !m16_ok ? HS_PROF_GEMM_NT + a->layout
                          : f == 0 ? HS_PROF_GEMM_NT16_PLAIN
+                         : f == HS_EPI_BIAS ? HS_PROF_GEMM_NT16_BIAS
                          : f == (HS_EPI_BIAS | HS_EPI_RESID) ? HS_PROF_GEMM_NT16_RESID
                          : f == (HS_EPI_GELU_BWD | HS_EPI_SAVE_DGELU) ? HS_PROF_GEMM_NT16_DGELU : HS_PROF_GEMM_NT16_GELU;
         ProfScope prof(pclass, stream, 2.0 * mnk, prof_bytes);
         if (m16_ok) {
             if (f == 0) HS_LAUNCH_M16(0);
+            else if (f == HS_EPI_BIAS) HS_LAUNCH_M16(HS_EPI_BIAS);        // patch embedding, scorer / packer projections (fp32 out)
             else if (f == (HS_EPI_BIAS | HS_EPI_RESID)) HS_LAUNCH_M16(HS_EPI_BIAS | HS_EPI_RESID);
             else if (f == (HS_EPI_GELU_BWD | HS_EPI_SAVE_DGELU)) HS_LAUNCH_M16(HS_EPI_GELU_BWD | HS_EPI_SAVE_DGELU);
             else HS_LAUNCH_M16(HS_EPI_BIAS | HS_EPI_GELU | HS_EPI_SAVE_DGELU);

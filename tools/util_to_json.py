@@ -22,6 +22,7 @@ tag = sys.argv[4] if len(sys.argv) > 4 else "r03"
 # kernel-name substring -> class (= hs_prof_name() of the library's per-kernel timers); first match wins
 CLASS = [("attn_fwd_fast_kernel", "attn_fwd"), ("attn_bwd_dkdv16_w4_kernel", "attn_bwd_dkdv"), ("attn_bwd_dq2_kernel", "attn_bwd_dq"),
          ("gemm_bf16_kernel<false, false, true, 0, true>", "gemm_nt16_plain"), ("gemm_bf16_kernel<false, false, true, 9, true>", "gemm_nt16_bias_resid"),
+         ("gemm_bf16_kernel<false, false, true, 1, true>", "gemm_nt16_bias"),
          ("gemm_bf16_kernel<false, false, true, 67, true>", "gemm_nt16_bias_gelu"), ("gemm_bf16_kernel<false, false, true, 68, true>", "gemm_nt16_dgelu"),
          ("gemm_bf16_group_kernel<true, true", "gemm_tn_group"), ("gemm_bf16_kernel<false, false", "gemm_nt"), ("gemm_bf16_kernel<false, true", "gemm_nn"),
          ("gemm_bf16_kernel<true, true", "gemm_tn"), ("layernorm_bwd_kernel", "layernorm_bwd"), ("layernorm_fwd_kernel", "layernorm_fwd"),
