@@ -69,6 +69,9 @@ SIGNATURES = {
     "hs_layernorm_bwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "hs_attn_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "hs_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "hs_attn_bwd_ws_bytes": [_i, _i, _i, _i],
+    "hs_attn_bwd2": [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _vp],
+    "hs_attn_bwd_ws_error": [_vp, _i, _i, _i, _vp],
     "hs_cross_attn_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _u64, _u64, _vp],
     "hs_cross_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _u64, _u64, _vp],
     "hs_dropout": [_vp, _vp, _i64, _f, _u64, _u64, _vp],
@@ -120,7 +123,7 @@ SIGNATURES = {
     "hs_debug_gemm_stamps": [_vp, _i],
     "hs_debug_gemm_trace": [_vp, _i],
 }
-_RESTYPE = {"hs_vit_workspace_bytes": _sz, "hs_embed_workspace_bytes": _sz, "hs_packer_workspace_bytes": _sz,
+_RESTYPE = {"hs_vit_workspace_bytes": _sz, "hs_attn_bwd_ws_bytes": _sz, "hs_embed_workspace_bytes": _sz, "hs_packer_workspace_bytes": _sz,
             "hs_prof_name": C.c_char_p, "hs_debug_set": None, "hs_debug_gemm_stamps": None,
             "hs_debug_gemm_trace": None}
 

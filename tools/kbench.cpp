@@ -21,6 +21,7 @@
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
 
 static void* g_lib;
+static int g_variant = 0;
 template <typename T> static T sym(const char* n) {
     void* p = dlsym(g_lib, n);
     if (!p) { fprintf(stderr, "missing symbol %s\n", n); exit(2); }
@@ -84,6 +85,9 @@ template <typename F> static double time_us(F&& f, int reps) {
 
 typedef int (*attn_fwd_t)(const void*, void*, float*, int, int, int, int, int, int, void*);
 typedef int (*attn_bwd_t)(const void*, const void*, const void*, const float*, void*, float*, int, int, int, int, int, void*);
+typedef int (*attn_bwd2_t)(const void*, const void*, const void*, const float*, void*, void*, size_t, int, int, int, int, int, void*);
+typedef size_t (*attn_ws_t)(int, int, int, int);
+typedef int (*attn_err_t)(const void*, int, int, int, void*);
 typedef int (*gemm_t)(const hs_gemm_args*, int, void*);
 typedef void (*dbg_t)(int, int);
 
@@ -155,14 +159,40 @@ int main(int argc, char** argv) {
                     printf("  round %d variant %d: %9.1f us  %7.1f TFLOP/s\n", round, var[i], us, fl_f / us / 1e6);
                 }
         } else {
-            auto bwd = sym<attn_bwd_t>("hs_attn_bwd");
+            auto bwd1 = sym<attn_bwd_t>("hs_attn_bwd");
+            auto bwd2 = sym<attn_bwd2_t>("hs_attn_bwd2");
+            auto wsb = sym<attn_ws_t>("hs_attn_bwd_ws_bytes");
+            auto wserr = sym<attn_err_t>("hs_attn_bwd_ws_error");
+            const size_t ws_bytes = wsb(B, N, H, aflags);
+            void* ws2 = dev_zero(ws_bytes);
+            printf("attn bwd workspace: %.1f MB (two-sweep scratch %.1f MB)\n", ws_bytes / 1e6, (double)B * H * N * 8 / 1e6);
+            // variant >= 100: hs_attn_bwd2 (the one-sweep kernel when the library selects it: HS_ATTN_FUSED); else hs_attn_bwd
+            auto bwd = [&](const void* q_, const void* o_, const void* g_, const float* l_, void* out_, float* dl_, int B_, int N_, int H_, int dh_, int fl_, void* st_) -> int {
+                if (g_variant >= 100) return bwd2(q_, o_, g_, l_, out_, ws2, ws_bytes, B_, N_, H_, dh_, fl_, st_);
+                return bwd1(q_, o_, g_, l_, out_, dl_, B_, N_, H_, dh_, fl_, st_);
+            };
             dbg(0, 0);
             fwd(qkv, o[0], lse[0], B, N, H, 64, HS_PREC_BF16, aflags, 0);
             void* d_o = dev_bf16_gauss(no, 1.0f);
             void* dqkv[2] = {dev_zero(nq * 2), dev_zero(nq * 2)};
             float* delta = (float*)dev_zero(nl * 4 * 2 + (size_t)B * N * Dm * 4);
-            for (int i = 0; i < 2; ++i) { dbg(1, var[i] % 10); dbg(2, var[i] / 10); int rc = bwd(qkv, o[0], d_o, lse[0], dqkv[i], delta, B, N, H, 64, aflags, 0); if (rc) { printf("variant %d rc=%d\n", var[i], rc); return 3; } }
+            for (int i = 0; i < 2; ++i) { g_variant = var[i]; dbg(1, var[i] % 10); dbg(2, (var[i] / 10) % 10); int rc = bwd(qkv, o[0], d_o, lse[0], dqkv[i], delta, B, N, H, 64, aflags, 0); if (rc) { printf("variant %d rc=%d\n", var[i], rc); return 3; } }
             CK(hipDeviceSynchronize());
+            if (vA >= 100 || vB >= 100) printf("one-sweep error word: %d\n", wserr(ws2, B, N, H, 0));
+            if (void* stp = dlsym(g_lib, "hs_debug_attn_stamps")) {        // hook builds: phase stamps of the one-sweep kernel
+                unsigned long long* dbuf = (unsigned long long*)dev_zero(96 * 8);
+                ((void (*)(unsigned long long*))stp)(dbuf);
+                g_variant = 100; bwd(qkv, o[0], d_o, lse[0], dqkv[1], delta, B, N, H, 64, aflags, 0); CK(hipDeviceSynchronize());
+                unsigned long long hs[96]; CK(hipMemcpy(hs, dbuf, sizeof hs, hipMemcpyDeviceToHost));
+                ((void (*)(unsigned long long*))stp)(nullptr);
+                printf("one-sweep stamps, cycles: wait | barrier | C+V0 | A0+V1 | A1 | W+tr issue | lds wait | 8 MFMA | 8 MFMA | hand-off | P+lgkm | total\n");
+                for (int it = 0; it < 8; ++it) {
+                    const unsigned long long* t = hs + it * 12;
+                    printf("   iter %d:", 40 + it);
+                    for (int k = 1; k < 12; ++k) printf(" %5lld", (long long)(t[k] - t[k - 1]));
+                    printf(" | %6lld\n", (long long)(t[11] - t[0]));
+                }
+            }
             Cmp c = cmp_bf16(dqkv[0], dqkv[1], nq);
             printf("attn bwd B=%d N=%d: variant %d vs %d: dqkv rel %.3e maxabs %.3e\n", B, N, vA, vB, c.rel, c.maxabs);
             {   // per section (dq | dk | dv)
@@ -174,7 +204,7 @@ int main(int argc, char** argv) {
             }
             for (int round = 0; round < 3; ++round)
                 for (int i = 0; i < 2; ++i) {
-                    dbg(1, var[i] % 10); dbg(2, var[i] / 10);      // variant = 10 * (dK/dV kernel) + (dQ kernel)
+                    g_variant = var[i]; dbg(1, var[i] % 10); dbg(2, (var[i] / 10) % 10);      // variant = 10 * (dK/dV kernel) + (dQ kernel); >= 100: hs_attn_bwd2
                     const double us = time_us([&] { bwd(qkv, o[0], d_o, lse[0], dqkv[i], delta, B, N, H, 64, aflags, 0); }, reps);
                     printf("  round %d variant %d: %9.1f us  %7.1f TFLOP/s (algorithmic 10 N^2 d)\n", round, var[i], us, 2.5 * fl_f / us / 1e6);
                 }
