@@ -16,7 +16,7 @@ HS_OK, HS_ERR_SHAPE, HS_ERR_ARCH, HS_ERR_LAUNCH, HS_ERR_ARG = 0, -1, -2, -3, -4
 PREC_BF16, PREC_F32 = 0, 1
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 EPI_BIAS, EPI_GELU, EPI_GELU_BWD, EPI_RESID, EPI_ATOMIC, EPI_BIAS_M, EPI_SAVE_DGELU = 1, 2, 4, 8, 16, 32, 64
-ATTN_Q_PRESCALED, ATTN_F32 = 1, 2
+ATTN_Q_PRESCALED, ATTN_F32, ATTN_ONE_SWEEP, ATTN_ONE_SWEEP_TILES = 1, 2, 4, 8
 Q_PRESCALE = 0.125 * 1.44269504088896341   # dh^-0.5 * log2(e) for dh = 64 (hs_gemm scale_cols_alpha for the q third)
 
 _ERR = {HS_ERR_SHAPE: "unsupported shape/alignment", HS_ERR_ARCH: "no gfx950 device", HS_ERR_LAUNCH: "HIP launch error",
@@ -71,7 +71,7 @@ SIGNATURES = {
     "hs_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "hs_attn_bwd_ws_bytes": [_i, _i, _i, _i],
     "hs_attn_bwd2": [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _vp],
-    "hs_attn_bwd_ws_error": [_vp, _i, _i, _i, _vp],
+    "hs_attn_bwd_ws_error": [_vp, _i, _i, _i, _i, _vp],
     "hs_cross_attn_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _u64, _u64, _vp],
     "hs_cross_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _u64, _u64, _vp],
     "hs_dropout": [_vp, _vp, _i64, _f, _u64, _u64, _vp],

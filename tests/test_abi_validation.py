@@ -36,7 +36,7 @@ def _zeros(name):
 def test_null_arguments_are_refused(name):
     """every compute entry point: all pointers NULL, all sizes 0 -> negative status (or 0 bytes for the workspace queries)."""
     rc = getattr(L.load(), name)(*_zeros(name))
-    if name.endswith("_workspace_bytes"):
+    if name.endswith("_workspace_bytes") or name.endswith("_ws_bytes"):
         assert rc == 0
     else:
         assert rc in (L.HS_ERR_ARG, L.HS_ERR_SHAPE), (name, rc)
@@ -92,6 +92,19 @@ def test_kernel_shape_checks():
     assert lib.hs_attn_fwd(P, P, P, 1, 128, 12, 64, L.PREC_BF16, 64, None) == L.HS_ERR_ARG
     assert lib.hs_attn_fwd(P, P, None, 1, 128, 12, 64, L.PREC_BF16, 0, None) == L.HS_ERR_ARG              # bf16 needs the lse output
     assert lib.hs_attn_bwd(P, P, P, P, P, P, 1, 128, 12, 48, 0, None) == S
+    # hs_attn_bwd2: workspace sizes, unknown flags, alignment; the one-sweep kernel needs its own (larger) workspace
+    two = 2 * 4 * 12 * 513 * 4
+    assert lib.hs_attn_bwd_ws_bytes(4, 513, 12, 0) == two
+    one = lib.hs_attn_bwd_ws_bytes(4, 513, 12, L.ATTN_ONE_SWEEP)
+    assert one > two and lib.hs_attn_bwd_ws_bytes(4, 513, 12, L.ATTN_ONE_SWEEP | L.ATTN_ONE_SWEEP_TILES) > one
+    assert lib.hs_attn_bwd_ws_bytes(4, 500, 12, L.ATTN_ONE_SWEEP) == 2 * 4 * 12 * 500 * 4        # shape does not fit: the two-sweep scratch
+    assert lib.hs_attn_bwd_ws_bytes(4, 513, 12, L.ATTN_ONE_SWEEP | L.ATTN_F32) == two
+    assert lib.hs_attn_bwd_ws_bytes(0, 513, 12, 0) == 0
+    assert lib.hs_attn_bwd2(P, P, P, P, P, P, two - 1, 4, 513, 12, 64, 0, None) == S              # workspace too small
+    assert lib.hs_attn_bwd2(P, P, P, P, P, P + 8, one, 4, 513, 12, 64, L.ATTN_ONE_SWEEP, None) == S  # misaligned workspace
+    assert lib.hs_attn_bwd2(P, P, P, P, P, P, one, 4, 513, 12, 64, 64, None) == L.HS_ERR_ARG      # unknown flag
+    assert lib.hs_attn_bwd2(P, P, P, P, P, None, one, 4, 513, 12, 64, 0, None) == L.HS_ERR_ARG
+    assert lib.hs_attn_bwd2(P, P, P, P, P, P, one, 4, 513, 12, 32, 0, None) == S
 
 
 @no_gpu_only

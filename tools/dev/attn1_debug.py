@@ -1,6 +1,6 @@
 """Development probe for the one-sweep attention backward (hs_attn_bwd2): fp32 torch reference on the same bf16 inputs,
 errors broken down by section (dq | dk | dv), key half / d half / key block, so a wrong operand map shows its shape.
-   python tools/dev/attn1_debug.py [B] [N] [H]          (HS_ATTN_FUSED=2 or 12 to force the one-sweep kernel)"""
+   python tools/dev/attn1_debug.py [B] [N] [H]          (HS_TILES=1: per-key-block dQ tiles + a second kernel instead of the ordered hand-off)"""
 import ctypes as C, os, sys
 import torch
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
@@ -24,12 +24,13 @@ o = torch.empty(B, N, Dm, device=dev, dtype=torch.bfloat16)
 lse = torch.empty(B, H, N, device=dev, dtype=torch.float32)
 st = torch.cuda.current_stream().cuda_stream
 _lib.call("hs_attn_fwd", qkv.data_ptr(), o.data_ptr(), lse.data_ptr(), B, N, H, 64, _lib.PREC_BF16, 0, st)
-wsb = lib.hs_attn_bwd_ws_bytes(B, N, H, 0)
+fl = _lib.ATTN_ONE_SWEEP | (_lib.ATTN_ONE_SWEEP_TILES if os.environ.get('HS_TILES') else 0)
+wsb = lib.hs_attn_bwd_ws_bytes(B, N, H, fl)
 ws = torch.zeros(wsb, device=dev, dtype=torch.uint8)
 dqkv = torch.zeros(B, N, 3, H, 64, device=dev, dtype=torch.bfloat16)
-_lib.call("hs_attn_bwd2", qkv.data_ptr(), o.data_ptr(), d_o.data_ptr(), lse.data_ptr(), dqkv.data_ptr(), ws.data_ptr(), wsb, B, N, H, 64, 0, st)
+_lib.call("hs_attn_bwd2", qkv.data_ptr(), o.data_ptr(), d_o.data_ptr(), lse.data_ptr(), dqkv.data_ptr(), ws.data_ptr(), wsb, B, N, H, 64, fl, st)
 torch.cuda.synchronize()
-print("ws bytes", wsb, "error word", lib.hs_attn_bwd_ws_error(ws.data_ptr(), B, N, H, st))
+print("ws bytes", wsb, "error word", lib.hs_attn_bwd_ws_error(ws.data_ptr(), B, N, H, fl, st))
 # fp32 reference on the same bf16 inputs
 q = qkv[:, :, 0].float().permute(0, 2, 1, 3).requires_grad_(True)
 k = qkv[:, :, 1].float().permute(0, 2, 1, 3).requires_grad_(True)

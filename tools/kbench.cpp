@@ -87,7 +87,7 @@ typedef int (*attn_fwd_t)(const void*, void*, float*, int, int, int, int, int, i
 typedef int (*attn_bwd_t)(const void*, const void*, const void*, const float*, void*, float*, int, int, int, int, int, void*);
 typedef int (*attn_bwd2_t)(const void*, const void*, const void*, const float*, void*, void*, size_t, int, int, int, int, int, void*);
 typedef size_t (*attn_ws_t)(int, int, int, int);
-typedef int (*attn_err_t)(const void*, int, int, int, void*);
+typedef int (*attn_err_t)(const void*, int, int, int, int, void*);
 typedef int (*gemm_t)(const hs_gemm_args*, int, void*);
 typedef void (*dbg_t)(int, int);
 
@@ -100,6 +100,7 @@ int main(int argc, char** argv) {
     g_lib = dlopen(libp.c_str(), RTLD_NOW);
     if (!g_lib) { fprintf(stderr, "dlopen %s: %s\n", libp.c_str(), dlerror()); return 2; }
     auto dbg = sym<dbg_t>("hs_debug_set");
+    if (getenv("HS_DBG4")) dbg(4, atoi(getenv("HS_DBG4")));
     const std::string mode = argv[1];
     const int B = argc > 2 ? atoi(argv[2]) : 4, reps = argc > 3 ? atoi(argv[3]) : 10;
     const int N = getenv("HS_N") ? atoi(getenv("HS_N")) : 4097, H = 12, Dm = 768;
@@ -163,12 +164,13 @@ int main(int argc, char** argv) {
             auto bwd2 = sym<attn_bwd2_t>("hs_attn_bwd2");
             auto wsb = sym<attn_ws_t>("hs_attn_bwd_ws_bytes");
             auto wserr = sym<attn_err_t>("hs_attn_bwd_ws_error");
-            const size_t ws_bytes = wsb(B, N, H, aflags);
+            const int oflags = aflags | HS_ATTN_ONE_SWEEP | (getenv("HS_TILES") ? HS_ATTN_ONE_SWEEP_TILES : 0);
+            const size_t ws_bytes = wsb(B, N, H, oflags);
             void* ws2 = dev_zero(ws_bytes);
             printf("attn bwd workspace: %.1f MB (two-sweep scratch %.1f MB)\n", ws_bytes / 1e6, (double)B * H * N * 8 / 1e6);
-            // variant >= 100: hs_attn_bwd2 (the one-sweep kernel when the library selects it: HS_ATTN_FUSED); else hs_attn_bwd
+            // variant >= 100: hs_attn_bwd2 with HS_ATTN_ONE_SWEEP (HS_TILES=1 in the environment: the per-key-block tile form); else hs_attn_bwd
             auto bwd = [&](const void* q_, const void* o_, const void* g_, const float* l_, void* out_, float* dl_, int B_, int N_, int H_, int dh_, int fl_, void* st_) -> int {
-                if (g_variant >= 100) return bwd2(q_, o_, g_, l_, out_, ws2, ws_bytes, B_, N_, H_, dh_, fl_, st_);
+                if (g_variant >= 100) return bwd2(q_, o_, g_, l_, out_, ws2, ws_bytes, B_, N_, H_, dh_, oflags, st_);
                 return bwd1(q_, o_, g_, l_, out_, dl_, B_, N_, H_, dh_, fl_, st_);
             };
             dbg(0, 0);
@@ -178,14 +180,15 @@ int main(int argc, char** argv) {
             float* delta = (float*)dev_zero(nl * 4 * 2 + (size_t)B * N * Dm * 4);
             for (int i = 0; i < 2; ++i) { g_variant = var[i]; dbg(1, var[i] % 10); dbg(2, (var[i] / 10) % 10); int rc = bwd(qkv, o[0], d_o, lse[0], dqkv[i], delta, B, N, H, 64, aflags, 0); if (rc) { printf("variant %d rc=%d\n", var[i], rc); return 3; } }
             CK(hipDeviceSynchronize());
-            if (vA >= 100 || vB >= 100) printf("one-sweep error word: %d\n", wserr(ws2, B, N, H, 0));
+            if (vA >= 100 || vB >= 100) printf("one-sweep error word: %d\n", wserr(ws2, B, N, H, oflags, 0));
             if (void* stp = dlsym(g_lib, "hs_debug_attn_stamps")) {        // hook builds: phase stamps of the one-sweep kernel
-                unsigned long long* dbuf = (unsigned long long*)dev_zero(96 * 8);
+                unsigned long long* dbuf = (unsigned long long*)dev_zero(100 * 8);
                 ((void (*)(unsigned long long*))stp)(dbuf);
                 g_variant = 100; bwd(qkv, o[0], d_o, lse[0], dqkv[1], delta, B, N, H, 64, aflags, 0); CK(hipDeviceSynchronize());
-                unsigned long long hs[96]; CK(hipMemcpy(hs, dbuf, sizeof hs, hipMemcpyDeviceToHost));
+                unsigned long long hs[100]; CK(hipMemcpy(hs, dbuf, sizeof hs, hipMemcpyDeviceToHost));
+                printf("hand-offs %llu, of which %llu re-read their granules (%llu re-reads)\n", hs[97], hs[96], hs[98]);
                 ((void (*)(unsigned long long*))stp)(nullptr);
-                printf("one-sweep stamps, cycles: wait | barrier | C+V0 | A0+V1 | A1 | W+tr issue | lds wait | 8 MFMA | 8 MFMA | hand-off | P+lgkm | total\n");
+                printf("one-sweep stamps, cycles: wait | barrier | C + 3 DMA | A0+V1 | A1 + hand-off | B reads | 8 MFMA | 8 MFMA + W | lgkm0 | - | - | total\n");
                 for (int it = 0; it < 8; ++it) {
                     const unsigned long long* t = hs + it * 12;
                     printf("   iter %d:", 40 + it);
