@@ -16,7 +16,14 @@ Other workloads: --workload vit256 (configs[1]: the 3D-ViT alone), clip_c4a (con
 mrg_c5 (configs[4]: frozen towers + trainable packers spliced into a random-init HF Phi-4-mini-shaped decoder; reported, not
 roofline-scored: the LLM is outside the HIP path), native_dual (configs[2] at the reference's own 32x256x256 / 4x16x16 geometry).
 
-Prints ONE JSON line (rank 0).  Extra objects: `roofline` (dominant kernel class, measured with HIP events on the launch
+Flags: --scaling strong (fixed GLOBAL batch --global-batch, per-GPU batch = global / world; default weak = fixed per-GPU batch);
+--attn-logit-std S (scale the q rows of every qkv weight so that the scaled attention logits have standard deviation S: random-init
+attention is nearly uniform, trained attention is peaky and the attention kernels are data-dependent at the power cap).
+
+Prints ONE JSON line (rank 0).  Beside the contract keys: `attention` (credited TFLOP/s and fraction of peak over attention forward +
+both backward sweeps: the north-star's own number), `optimizer_excluded` (the rate of forward + backward + all-reduce alone),
+`peaky_attention` (the same step and attention figures at logit std 1.5), `f32_mode` (volumes/s of the <= 1e-3 parity mode through
+the module API).  Extra objects: `roofline` (dominant kernel class, measured with HIP events on the launch
 stream in a second, instrumented pass over the same steps), `cpu_baseline` (the CPU oracle — a plain-PyTorch fp32 port of the
 reference — timed on this host for the SAME workload, rank 0, N=1 only) and `batch1` (the same step at 1 volume per GPU, the
 per-GPU load of configs[3]/[4]).
@@ -94,6 +101,91 @@ def measured_pmc(kernel, batch, workload):
         except Exception:
             pass
     return {}
+
+
+def attention_aggregate(classes):
+    """credited TFLOP/s over attention forward + backward (forward 4 N^2 d, backward 8 N^2 d per (batch, head, layer))."""
+    att = [c for c in classes if c["name"].startswith("attn_") and c["flops"]]
+    if not att:
+        return None
+    fl, ms = sum(c["flops"] for c in att), sum(c["total_ms"] for c in classes if c["name"].startswith("attn_"))
+    tf = fl / (ms * 1e-3) / 1e12
+    return {"credited_tflops": round(tf, 2), "frac": round(tf / PEAK_BF16_TFLOPS, 4), "ms_per_step_share": None,
+            "kernels": sorted(c["name"] for c in classes if c["name"].startswith("attn_")), "total_ms": round(ms, 3)}
+
+
+def encoders_of(eng):
+    """the ViT modules an engine trains (for --attn-logit-std)."""
+    ms = []
+    for nm in ("u1", "u2", "unit"):
+        u = getattr(eng, nm, None)
+        if u is not None and hasattr(u, "model"):
+            ms.append(u.model)
+    return ms
+
+
+def set_attn_logit_std(models, std):
+    """scale the q rows of every block's qkv weight so that the scaled logits q.k / 8 have standard deviation `std` for unit-variance
+    LayerNorm outputs: std(logit) = sigma_q * sigma_k with sigma^2 = mean squared row norm of Wq / Wk (64-dim heads, 1/8 scaling).
+    Returns the factor applied to the first block (random init: sigma_q sigma_k = 0.31, i.e. near-uniform attention)."""
+    first = None
+    with torch.no_grad():
+        for m in models:
+            for blk in m.blocks:
+                w = blk.attn.qkv.weight
+                d = w.shape[1]
+                sq = float(w[:d].float().pow(2).sum(1).mean().sqrt())
+                sk = float(w[d:2 * d].float().pow(2).sum(1).mean().sqrt())
+                f = std / max(sq * sk, 1e-12)
+                w[:d].mul_(f)
+                first = f if first is None else first
+    return first
+
+
+def f32_mode_rate(workload, geom, dev, steps=2):
+    """volumes/s of the exact-f32 parity mode (hsenet_amd.set_precision("f32"): v_mfma_f32_32x32x2_f32 GEMMs and attention, the mode that
+    meets the north-star's <= 1e-3) for the same modules, forward + backward of one volume through the module API (autograd)."""
+    import hsenet_amd as H
+    img, patch = geom["img"], geom["patch"]
+    torch.manual_seed(1234)
+    rng = np.random.default_rng(99)
+    vol = torch.from_numpy(rng.random((1, 1) + img, dtype=np.float32)).to(dev)
+    s2d = torch.from_numpy(rng.standard_normal((1, 32, 768), dtype=np.float32)).to(dev)
+    if workload in ("dual256", "native_dual"):
+        tower = H.build_vision_tower(TowerCfg(img, patch)).to(dev)
+        pk = dict(grid=geom["grid"], kernel_size=geom["kernel"])
+        p1 = H.VisualPacker_3d_phi_v3(img, patch, 768, OUT_DIM, "mlp", 2, **pk).to(dev)
+        p2 = H.VisualPacker_3d_phi_v3(img, patch, 768, OUT_DIM, "mlp", 2, **pk).to(dev)
+        mods = [tower, p1, p2]
+
+        def step():
+            out = H.encode_images(tower, p1, p2, vol, s2d)
+            (out * out).mean().backward()
+    elif workload == "vit256":
+        m = H.ViT_stage1(in_channels=1, img_size=img, patch_size=patch, pos_embed="perceptron", classification=True).to(dev)
+        mods = [m]
+
+        def step():
+            y, _ = m(vol)
+            (y * y).mean().backward()
+    else:
+        return None
+    H.set_precision("f32")
+    try:
+        step()                                              # warm-up
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            for m in mods:
+                m.zero_grad(set_to_none=True)
+            step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+    finally:
+        H.set_precision("bf16")
+    return {"value": round(1.0 / dt, 3), "unit": "CT-volumes/sec", "ms_per_step": round(1e3 * dt, 2), "batch_per_gpu": 1, "steps": steps,
+            "what": "forward + backward, module API (autograd), exact-f32 MFMA everywhere (the mode whose outputs are within 1e-3 of the "
+                    "reference: tests/test_gpu_parity.py); no optimizer step"}
 
 
 def cpu_model():
@@ -184,6 +276,8 @@ def build_engine(workload, geom, batch, dev, group=None):
     import hsenet_amd as H
     from hsenet_amd.engine import DualEngine, FlatEncoder
     img, patch = geom["img"], geom["patch"]
+    # gradient exchange (hsenet_amd/dp.py): wire fp32 | bf16, algorithm allreduce | rs_ag | auto; default = the reference's DDP setting
+    dp = dict(grad_wire=os.environ.get("HS_GRAD_WIRE", "fp32"), grad_algo=os.environ.get("HS_GRAD_ALGO", "allreduce"))
     torch.manual_seed(1234)
     if workload in ("dual256", "native_dual"):
         tower = H.build_vision_tower(TowerCfg(img, patch)).to(dev)
@@ -191,13 +285,13 @@ def build_engine(workload, geom, batch, dev, group=None):
         p1 = H.VisualPacker_3d_phi_v3(img, patch, 768, OUT_DIM, "mlp", 2, **pk).to(dev)
         p2 = H.VisualPacker_3d_phi_v3(img, patch, 768, OUT_DIM, "mlp", 2, **pk).to(dev)
         ts = os.environ.get("HS_DUAL_STREAMS")                     # (env: A/B runs only; default = the engine's batch rule)
-        eng = DualEngine(tower, p1, p2, batch, lr=1e-4, weight_decay=0.1, group=group, two_streams=None if ts is None else ts != "0")
+        eng = DualEngine(tower, p1, p2, batch, lr=1e-4, weight_decay=0.1, group=group, two_streams=None if ts is None else ts != "0", **dp)
         pe = tower.vision_tower_stage1.patch_embedding
         return eng, pe, True
     if workload == "clip_c4a":
         from hsenet_amd.clip_step import ClipStage2Engine, make_clip_stage2
         model = make_clip_stage2(img, patch).to(dev)
-        eng = ClipStage2Engine(model, batch, lr=1e-4, weight_decay=0.1, group=group)
+        eng = ClipStage2Engine(model, batch, lr=1e-4, weight_decay=0.1, group=group, **dp)
         rng = np.random.default_rng(4321 + int(os.environ.get("RANK", "0")))
         txt = [torch.nn.functional.normalize(torch.from_numpy(rng.standard_normal((batch, 768), dtype=np.float32)), dim=-1).to(dev)
                for _ in range(2)]                                   # frozen text embeddings: normalize(N(0,1))
@@ -206,7 +300,7 @@ def build_engine(workload, geom, batch, dev, group=None):
     if workload == "mrg_c5":
         return build_mrg(geom, batch, dev, group)
     model = H.ViT_stage1(in_channels=1, img_size=img, patch_size=patch, pos_embed="perceptron", classification=True).to(dev)
-    eng = FlatEncoder(model, batch, lr=1e-4, weight_decay=0.1, group=group)
+    eng = FlatEncoder(model, batch, lr=1e-4, weight_decay=0.1, group=group, **dp)
     return eng, model.patch_embedding, False
 
 
@@ -248,12 +342,14 @@ def build_mrg(geom, batch, dev, group):
     return _Step(), tower.vision_tower_stage1.patch_embedding, True
 
 
-def timed_run(eng, needs_2d, vols, slices, steps, warmup, sync):
+def timed_run(eng, needs_2d, vols, slices, steps, warmup, sync, optimizer=True):
+    kw = {} if optimizer else {"optimizer": False}
+
     def step(i):
         if needs_2d:
-            eng.train_step(vols[i % 2], slices[i % 2])
+            eng.train_step(vols[i % 2], slices[i % 2], **kw)
         else:
-            eng.train_step(vols[i % 2])
+            eng.train_step(vols[i % 2], **kw)
     for i in range(warmup):
         step(i)
     sync()
@@ -274,10 +370,32 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-batch1", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the optimizer_excluded / peaky_attention / f32_mode legs")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --batch volumes on EVERY GPU; strong: --global-batch volumes in total, split over the GPUs")
+    ap.add_argument("--global-batch", type=int, default=None, help="--scaling strong: total volumes per step (default 56 = 7 per GPU at 8 GPUs; "
+                    "clip_c4a / clip_c4b / mrg_c5: 8, BASELINE configs[3]/[4])")
+    ap.add_argument("--grad-wire", default=None, choices=["fp32", "bf16"], help="gradient exchange wire format (default fp32; also HS_GRAD_WIRE)")
+    ap.add_argument("--grad-algo", default=None, choices=["allreduce", "rs_ag", "auto"], help="gradient exchange algorithm (default allreduce; also HS_GRAD_ALGO)")
+    ap.add_argument("--attn-logit-std", type=float, default=None, help="scale the q rows of the qkv weights so that the scaled attention "
+                    "logits have this standard deviation (random init: 0.31)")
     a = ap.parse_args()
+    if a.grad_wire:
+        os.environ["HS_GRAD_WIRE"] = a.grad_wire
+    if a.grad_algo:
+        os.environ["HS_GRAD_ALGO"] = a.grad_algo
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    small = a.workload in ("clip_c4a", "clip_c4b", "mrg_c5")
+    if a.scaling == "strong":
+        if a.batch is not None:
+            sys.exit("--scaling strong takes --global-batch, not --batch")
+        g = a.global_batch if a.global_batch is not None else (8 if small else 56)
+        if g % world_env:
+            sys.exit(f"--global-batch {g} is not divisible by the {world_env} ranks")
+        a.batch = g // world_env
     batch_defaulted = a.batch is None
     if a.batch is None:
-        a.batch = 1 if a.workload in ("clip_c4a", "mrg_c5") else DEFAULT_BATCH
+        a.batch = 1 if small else DEFAULT_BATCH
 
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -338,11 +456,10 @@ def main():
         try:
             eng, pe, needs_2d = build_engine(a.workload, geom, cand, dev)
             vols, slices = inputs(cand)
-            if world == 1:                                      # one untimed step: the engines size some workspaces on first use
-                if needs_2d:                                    # (not with several ranks: a step contains collectives, and a rank that ran
-                    eng.train_step(vols[0], slices[0])          # out of memory inside it would leave the others waiting)
-                else:
-                    eng.train_step(vols[0])
+            # one untimed forward + backward WITHOUT collectives: the engines size some workspaces on first use, and a rank that runs
+            # out of memory must find out before the vote below, not inside a step whose all-reduces the other ranks are waiting in
+            if hasattr(eng, "probe_step"):
+                eng.probe_step(*((vols[0], slices[0]) if needs_2d else (vols[0],)))
             torch.cuda.synchronize()
         except torch.cuda.OutOfMemoryError:
             ok = 0
@@ -360,6 +477,7 @@ def main():
         torch.cuda.reset_peak_memory_stats(dev)
     else:
         sys.exit("bench.py: no candidate batch fits in HBM")
+    logit_factor = set_attn_logit_std(encoders_of(eng), a.attn_logit_std) if a.attn_logit_std else None
     dt, step = timed_run(eng, needs_2d, vols, slices, a.steps, a.warmup, sync)
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -369,41 +487,71 @@ def main():
 
     # ---- instrumented pass: per-kernel-class HIP-event timing on the launch stream, same steps --------------
     # EVERY rank runs these steps (they contain the gradient all-reduces); only rank 0 records and reads the timers.
-    roof, classes = None, []
-    if not a.no_roofline:
+    def instrumented(step_fn, n):
+        """-> (classes, roofline) of n more steps with the library's per-kernel-class timers on (rank 0; others ([], None))."""
         # per-kernel durations are only meaningful for kernels that run ALONE: an engine that forks its two encoder chains onto
         # two streams (DualEngine below 16 volumes per GPU) runs this pass on one stream
         forked = getattr(eng, "two_streams", False) and getattr(eng, "side", None) is not None
         if forked:
             side, eng.side = eng.side, None
+        classes_, roof_ = [], None
         if rank == 0:
             L.call("hs_prof_enable", 1)
-        for i in range(max(1, min(a.steps, 3))):
-            step(i)
+        for i in range(n):
+            step_fn(i)
         torch.cuda.synchronize()
         if rank == 0:
-            classes = profile_classes()
+            classes_ = profile_classes()
             L.call("hs_prof_enable", 0)
-            for c in classes:
+            for c in classes_:
                 c["avg_us"] = 1e3 * c["total_ms"] / c["launches"]
                 c["tflops"] = c["flops"] / (c["total_ms"] * 1e-3) / 1e12 if c["flops"] else 0.0
                 c["gbs"] = c["bytes"] / (c["total_ms"] * 1e-3) / 1e9
-            mf = [c for c in classes if c["flops"]]
+            mf = [c for c in classes_ if c["flops"]]
             dom = max(mf, key=lambda c: c["total_ms"])
             pmc = measured_pmc(dom["name"], a.batch, a.workload)
-            roof = dict(kernel=dom["name"], bound="mfma", achieved=round(dom["tflops"], 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
-                        frac=round(dom["tflops"] / PEAK_BF16_TFLOPS, 4), traffic=pmc.get("hbm_bytes_per_launch"),
-                        avg_launch_us=round(dom["avg_us"], 2), flops_per_launch=dom["flops"] / dom["launches"])
+            roof_ = dict(kernel=dom["name"], bound="mfma", achieved=round(dom["tflops"], 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
+                         frac=round(dom["tflops"] / PEAK_BF16_TFLOPS, 4), traffic=pmc.get("hbm_bytes_per_launch"),
+                         avg_launch_us=round(dom["avg_us"], 2), flops_per_launch=dom["flops"] / dom["launches"])
             if pmc:
-                roof["traffic_source"] = pmc["source"]
+                roof_["traffic_source"] = pmc["source"]
                 if pmc.get("mfma_busy_frac") is not None:
-                    roof["mfma_busy_frac_pmc"] = round(pmc["mfma_busy_frac"], 4)
+                    roof_["mfma_busy_frac_pmc"] = round(pmc["mfma_busy_frac"], 4)
             if forked:
-                roof["note"] = "instrumented pass on one stream (the timed pass forks the two encoder chains onto two streams)"
+                roof_["note"] = "instrumented pass on one stream (the timed pass forks the two encoder chains onto two streams)"
         if forked:
             eng.side = side
-    if world > 1:
-        dist.barrier()
+        if world > 1:
+            dist.barrier()
+        return classes_, roof_
+
+    n_inst = max(1, min(a.steps, 3))
+    roof, classes = None, []
+    if not a.no_roofline:
+        classes, roof = instrumented(step, n_inst)
+
+    # ---- the north-star's side figures: optimizer excluded, peaky attention ------------------------------------------------
+    extras = {}
+    if not a.no_extras and a.workload != "mrg_c5":
+        k = max(2, min(a.steps, 5))
+        dtn, _ = timed_run(eng, needs_2d, vols, slices, k, 1, sync, optimizer=False)       # every rank: the all-reduces are inside
+        if world > 1:
+            t = torch.tensor([dtn], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dtn = float(t.item())
+        extras["optimizer_excluded"] = {"value": round(world * a.batch * k / dtn, 3), "unit": "CT-volumes/sec", "ms_per_step": round(1e3 * dtn / k, 3),
+                                        "steps": k, "what": "forward + backward + gradient all-reduce, no AdamW / clip pass"}
+        if world == 1 and a.attn_logit_std is None and encoders_of(eng) and not a.no_roofline:
+            f = set_attn_logit_std(encoders_of(eng), 1.5)
+            dtp, stepp = timed_run(eng, needs_2d, vols, slices, k, 1, sync)
+            cls_p, roof_p = instrumented(stepp, n_inst)
+            extras["peaky_attention"] = {"attn_logit_std": 1.5, "q_weight_factor": round(f, 3), "value": round(a.batch * k / dtp, 3),
+                                         "unit": "CT-volumes/sec", "ms_per_step": round(1e3 * dtp / k, 3), "steps": k,
+                                         "attention": attention_aggregate(cls_p),
+                                         "roofline": {kk: roof_p[kk] for kk in ("kernel", "achieved", "frac", "avg_launch_us")} if roof_p else None,
+                                         "what": "the same step after scaling the q rows of every qkv weight so that the scaled logits have std "
+                                                 "1.5 (random init: 0.31, near-uniform attention; trained attention is peaky and the attention "
+                                                 "kernels draw more power on such data)"}
 
     Np, Pd = pe.n_patches, pe.patch_dim
     fb = flops_per_volume(a.workload, Np, Pd)
@@ -423,18 +571,30 @@ def main():
     out = {
         "metric": METRIC, "value": round(vols_per_s, 3), "unit": "CT-volumes/sec",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"BASELINE {geom['cfg']}: {img[0]}x{img[1]}x{img[2]} volume, {desc}, random-init weights",
-                   "batch_per_gpu": a.batch, "global_batch": a.batch * world, "parallelism": f"dp{world}"},
+                   "batch_per_gpu": a.batch, "global_batch": a.batch * world, "parallelism": f"dp{world}",
+                   "grad_exchange": f"{os.environ.get('HS_GRAD_WIRE', 'fp32')}/{os.environ.get('HS_GRAD_ALGO', 'allreduce')}"},
         "model_tflops": round(vols_per_s * fb / 1e12, 2),
         "mfma_roofline_frac_end_to_end": round(vols_per_s * fb / 1e12 / (PEAK_BF16_TFLOPS * world), 4),
         "outputs_finite": finite,
         "peak_hbm_gb": round((torch.cuda.max_memory_allocated(dev) - (reserved.numel() if reserved is not None else 0)) / 1e9, 2),
     }
+    if batch_defaulted and a.workload == "dual256" and a.batch == DEFAULT_BATCH:
+        out["config"]["batch_changed_from"] = 20          # rounds 1-2 quoted this metric at 20 volumes per GPU (same code: --batch 20)
+    if a.attn_logit_std:
+        out["config"]["attn_logit_std"] = a.attn_logit_std
+        out["config"]["q_weight_factor"] = round(logit_factor, 3) if logit_factor else None
     if roof:
         out["roofline"] = roof
+        att = attention_aggregate(classes)
+        if att:
+            att["ms_per_step_share"] = round(att["total_ms"] / n_inst / (1e3 * dt / a.steps), 4)
+            out["attention"] = att
         out["kernels"] = [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in c.items() if k != "bytes" and k != "flops"}
                           for c in sorted(classes, key=lambda c: -c["total_ms"])]
+
+    out.update(extras)
 
     # ---- the same step at ONE volume per GPU (the per-GPU load of configs[3]/[4]: batch 8 over 8 GPUs) ----------
     if not a.no_batch1 and a.batch != 1 and world == 1:
@@ -447,6 +607,15 @@ def main():
         out["batch1"] = {"value": round(n1 / dt1, 3), "unit": "CT-volumes/sec", "ms_per_step": round(1e3 * dt1 / n1, 3), "steps": n1,
                          "mfma_roofline_frac_end_to_end": round(n1 / dt1 * fb / 1e12 / PEAK_BF16_TFLOPS, 4)}
         del eng1
+    if rank == 0 and world == 1 and not a.no_extras:
+        try:
+            del eng, vols, slices
+        except NameError:
+            pass
+        torch.cuda.empty_cache()
+        f32 = f32_mode_rate(a.workload, geom, dev)
+        if f32:
+            out["f32_mode"] = f32
     if rank == 0 and world == 1 and not a.no_cpu_baseline and a.workload != "mrg_c5":      # (the LLM-dominated step has no CPU leg)
         out["cpu_baseline"] = cpu_baseline(a.workload, geom)
     if rank == 0:

@@ -60,7 +60,7 @@ class ClipStage2Engine(_Engine):
     text_features)``; text features: L2-normalised [B_local, d] (frozen)."""
 
     def __init__(self, model: M3DCLIPVision_stage2, batch: int, *, lr=1e-4, weight_decay=0.1, max_grad_norm: Optional[float] = 1.0,
-                 n_buckets=4, group=None):
+                 n_buckets=4, group=None, grad_wire="fp32", grad_algo="allreduce"):
         if model.local_loss or not model.gather_loss:
             raise L.HsError("ClipStage2Engine drives the shipped configuration: gather_loss=True, local_loss=False")
         self.model, self.B, self.group = model, batch, group
@@ -82,7 +82,8 @@ class ClipStage2Engine(_Engine):
             offs.append(off)
             off += _al(p.numel())
         self.chunks, bounds = _encoder_bounds(self.u2, names, offs, "vision_encoder.", 0, off, n_buckets)
-        self._finish(entries, bounds, lr=lr, weight_decay=weight_decay, max_grad_norm=max_grad_norm, group=group)
+        self._finish(entries, bounds, lr=lr, weight_decay=weight_decay, max_grad_norm=max_grad_norm, group=group,
+                     grad_wire=grad_wire, grad_algo=grad_algo)
         self.u1.bind()
         self.u2.bind()
         self.h1 = _Head(self.u1, model.stage1_pretrained_CLIP.mm_vision_proj, False)
@@ -163,15 +164,19 @@ class ClipStage2Engine(_Engine):
         self.u2.backward(self.patches, self.u2.dy, self.chunks, self.buckets.reduce)
         self.buckets.wait()
 
-    def train_step(self, images, images_2d, text_features_stage1=None, text_features=None) -> None:
-        if text_features_stage1 is None or text_features is None:
+    def train_step(self, images, images_2d, text_features_stage1=None, text_features=None, optimizer: bool = True) -> None:
+        if (text_features_stage1 is None) != (text_features is None):
+            raise L.HsError("train_step: pass BOTH text feature tensors or neither (the cached pair of set_text_features would silently "
+                            "replace the one that was given)")
+        if text_features_stage1 is None:
             if self._txt1 is None:
                 raise L.HsError("train_step(images, images_2d) needs set_text_features() first (or pass both text feature tensors)")
             text_features_stage1, text_features = self._txt1, self._txt2
         self.forward_loss(images, images_2d, text_features_stage1, text_features)
         self.backward()
-        self.optimizer_step()
-        self.global_step += 1
+        if optimizer:
+            self.optimizer_step()
+            self.global_step += 1
 
     def set_text_features(self, text_features_stage1: torch.Tensor, text_features: torch.Tensor) -> None:
         """frozen text embeddings reused by every ``train_step(images, images_2d)`` call (bench.py)."""

@@ -320,10 +320,10 @@ class PackerUnit:
 class _Engine:
     """shared: flat buffers, gradient buckets, optimizer."""
 
-    def _finish(self, entries, bounds, *, lr, weight_decay, max_grad_norm, group):
+    def _finish(self, entries, bounds, *, lr, weight_decay, max_grad_norm, group, grad_wire="fp32", grad_algo="allreduce"):
         self.params = FlatParams(entries, self.dev)
         self.flat, self.grad = self.params.flat, self.params.grad
-        self.buckets = GradBuckets(self.grad, bounds, group)
+        self.buckets = GradBuckets(self.grad, bounds, group, wire=grad_wire, algo=grad_algo)
         self.lr, self.wd, self.max_grad_norm = lr, weight_decay, max_grad_norm
         self.loss = torch.zeros(1, dtype=torch.float32, device=self.dev)
 
@@ -333,6 +333,15 @@ class _Engine:
 
     def optimizer_step(self) -> None:
         self.params.step(lr=self.lr, weight_decay=self.wd, grad_scale=self.buckets.grad_scale, max_grad_norm=self.max_grad_norm)
+
+    def probe_step(self, *inputs) -> None:
+        """one forward + backward WITHOUT collectives and without the optimizer: sizes every lazily allocated workspace and surfaces an
+        out-of-memory condition on THIS rank before any rank has entered a collective (bench.py's per-rank fit vote)."""
+        self.buckets.muted = True
+        try:
+            self.train_step(*inputs, optimizer=False)
+        finally:
+            self.buckets.muted = False
 
     def _patchify(self, vol: torch.Tensor, pe, patches: torch.Tensor) -> None:
         Fn._need(vol)
@@ -366,7 +375,8 @@ def _encoder_bounds(unit: EncoderUnit, params_names, params_offsets, prefix: str
 class FlatEncoder(_Engine):
     """One encoder with flat parameter / gradient / moment buffers and an explicit fused train step (BASELINE configs[1])."""
 
-    def __init__(self, model, batch: int, *, lr=1e-4, weight_decay=0.1, max_grad_norm: Optional[float] = 1.0, n_buckets=4, group=None):
+    def __init__(self, model, batch: int, *, lr=1e-4, weight_decay=0.1, max_grad_norm: Optional[float] = 1.0, n_buckets=4, group=None,
+                 grad_wire="fp32", grad_algo="allreduce"):
         self.unit = EncoderUnit(model, batch, trainable=True)
         self.model, self.dev, self.B = model, self.unit.dev, batch
         entries = _encoder_entries(self.unit, "")
@@ -376,7 +386,8 @@ class FlatEncoder(_Engine):
             offs.append(off)
             off += _al(p.numel())
         self.layer_chunks, bounds = _encoder_bounds(self.unit, probe_names, offs, "", 0, off, n_buckets)
-        self._finish(entries, bounds, lr=lr, weight_decay=weight_decay, max_grad_norm=max_grad_norm, group=group)
+        self._finish(entries, bounds, lr=lr, weight_decay=weight_decay, max_grad_norm=max_grad_norm, group=group,
+                     grad_wire=grad_wire, grad_algo=grad_algo)
         self.unit.bind()
         u = self.unit
         self.patches = torch.empty(batch * u.Np, u.Pd, dtype=torch.bfloat16, device=self.dev)
@@ -392,12 +403,13 @@ class FlatEncoder(_Engine):
         self.unit.backward(self.patches, dy, self.layer_chunks, self.buckets.reduce)
         self.buckets.wait()
 
-    def train_step(self, vol: torch.Tensor, image_2d: Optional[torch.Tensor] = None) -> None:
-        """one step of L = mean(y^2): fwd, dL/dy = 2 y / numel, bwd (+ bucketed all-reduce), clipped AdamW."""
+    def train_step(self, vol: torch.Tensor, image_2d: Optional[torch.Tensor] = None, optimizer: bool = True) -> None:
+        """one step of L = mean(y^2): fwd, dL/dy = 2 y / numel, bwd (+ bucketed all-reduce), clipped AdamW (optimizer=False: without it)."""
         y = self.forward(vol, image_2d)
         L.call("hs_mse_grad", y.data_ptr(), self.dy.data_ptr(), None, y.numel(), Fn._s())
         self.backward(self.dy)
-        self.optimizer_step()
+        if optimizer:
+            self.optimizer_step()
 
 
 class DualEngine(_Engine):
@@ -410,7 +422,7 @@ class DualEngine(_Engine):
 
     def __init__(self, tower: ViT3DTower_dual_encoders, packer1: VisualPacker_3d_phi_v3, packer2: VisualPacker_3d_phi_v3, batch: int, *,
                  lr=1e-4, weight_decay=0.1, max_grad_norm: Optional[float] = 1.0, n_buckets=4, group=None,
-                 two_streams: Optional[bool] = None):
+                 two_streams: Optional[bool] = None, grad_wire="fp32", grad_algo="allreduce"):
         if tower.select_feature != "patch" or tower.remain_2d3d_ViT_type != "dual_vits":
             raise L.HsError("DualEngine drives the shipped configuration: select_feature='patch', remain_2d3d_ViT_type='dual_vits'")
         self.tower, self.B = tower, batch
@@ -438,7 +450,8 @@ class DualEngine(_Engine):
         self.chunks2, b2 = _encoder_bounds(self.u2, names, offs, "vision_tower_stage2.", s2, sp, n_buckets)
         # bucket ids: 0 = packer 2, 1 = packer 1, then the 2E3 chunks, then the 3D-ViT chunks (each in backward-completion order)
         bounds = [(sp2, off), (sp, sp2)] + b2 + b1
-        self._finish(entries, bounds, lr=lr, weight_decay=weight_decay, max_grad_norm=max_grad_norm, group=group)
+        self._finish(entries, bounds, lr=lr, weight_decay=weight_decay, max_grad_norm=max_grad_norm, group=group,
+                     grad_wire=grad_wire, grad_algo=grad_algo)
         for u in (self.u1, self.u2, self.p1, self.p2):
             u.bind()
         self.patches = torch.empty(batch * self.u1.Np, self.u1.Pd, dtype=torch.bfloat16, device=self.dev)
@@ -487,13 +500,14 @@ class DualEngine(_Engine):
         self._join()
         self.buckets.wait()
 
-    def train_step(self, vol: torch.Tensor, image_2d: torch.Tensor) -> None:
-        """one step of L = mean(out^2) over the (B, 256, hidden) projector output."""
+    def train_step(self, vol: torch.Tensor, image_2d: torch.Tensor, optimizer: bool = True) -> None:
+        """one step of L = mean(out^2) over the (B, 256, hidden) projector output (optimizer=False: forward + backward + all-reduce only)."""
         out = self.forward(vol, image_2d)
         self.loss.zero_()
         L.call("hs_mse_grad", out.data_ptr(), self.dout.data_ptr(), self.loss.data_ptr(), out.numel(), Fn._s())
         self.backward(self.dout)
-        self.optimizer_step()
+        if optimizer:
+            self.optimizer_step()
 
 
 def profile_classes() -> List[dict]:

@@ -69,8 +69,52 @@ def _gather(rank, world):
     assert torch.allclose(txt.grad, world * w[rank * 3:(rank + 1) * 3], atol=1e-5)
 
 
+def _wire_and_algo(rank, world):
+    """GradBuckets(wire=, algo=): every rank ends with IDENTICAL gradients (replicas cannot drift), the fp32 rs_ag form equals the
+    all-reduce up to summation order, the bf16 wire within bf16 rounding of it."""
+    from hsenet_amd.dp import GradBuckets
+    torch.manual_seed(300 + rank)
+    base = torch.randn(1003) * torch.logspace(-3, 1, 1003)          # (1003: not divisible by the world size -> the padded rs_ag path)
+    all_ = [torch.empty(1003) for _ in range(world)]
+    dist.all_gather(all_, base)
+    ref = sum(a.double() for a in all_)
+    bounds = [(700, 1003), (256, 700), (0, 256)]
+    worst = {}
+    for wire in ("fp32", "bf16"):
+        for algo in ("allreduce", "rs_ag", "auto"):
+            flat = base.clone()
+            gb = GradBuckets(flat, bounds, wire=wire, algo=algo, rs_ag_min_bytes=1024)
+            for i in range(3):
+                gb.reduce(i)
+            gb.wait()
+            others = [torch.empty(1003) for _ in range(world)]
+            dist.all_gather(others, flat)
+            assert all(torch.equal(o, flat) for o in others), (wire, algo)           # replica-identical
+            err = float((flat.double() - ref).norm() / ref.norm())
+            worst[(wire, algo)] = err
+            assert err < (1e-6 if wire == "fp32" else 4e-3), (wire, algo, err)
+    if rank == 0:
+        print("GradBuckets relative error vs the exact sum:", {f"{k[0]}/{k[1]}": f"{v:.1e}" for k, v in worst.items()})
+    # auto at two ranks or for small buckets falls back to one all-reduce; a muted instance launches nothing
+    gb = GradBuckets(base.clone(), bounds, algo="auto", rs_ag_min_bytes=1 << 30)
+    assert not any(p[0] for p in gb._plan)
+    gb.muted = True
+    gb.reduce(0)
+    gb.wait()
+    try:
+        GradBuckets(base.clone(), bounds, wire="fp16")
+        raise AssertionError("unknown wire format accepted")
+    except ValueError:
+        pass
+
+
 def test_grad_buckets_allreduce_gloo():
     _run(_buckets)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_grad_buckets_wire_formats_and_algorithms_gloo(world):
+    _run(_wire_and_algo, world)
 
 
 def test_gather_features_gloo():

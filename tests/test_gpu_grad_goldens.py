@@ -4,19 +4,19 @@ fused drivers, flat buffers, chunked (l_hi, l_lo) block backward, split-K atomic
 reference-native 32x256x256 geometry and at BASELINE's 256^3 (N = 4097 tokens, L = 12).
 
 Checked per parameter tensor: (1) the gradient norm of EVERY tensor, (2) the values of the stored tensors (full, or rows
-[0, mid, last]) — embeddings, cls, scorer, final norm, packers, blocks 0 / 5 / 11.  Tolerance 2e-2 per tensor (bf16 MFMA inputs in
+[0, mid, last]) — embeddings, cls, scorer, final norm, packers, blocks 0 / 5 / 11.  Tolerance 1.5e-2 per tensor (bf16 MFMA inputs in
 every forward/dgrad/wgrad GEMM against an fp32 reference; measured values are printed); 5e-2 for SMALL-SIGNAL tensors, those whose
 reference gradient norm is below 1 % of the largest tensor's: there the gradient is a small difference of large terms (the packers'
 Wk.weight: d softmax = p (dp - sum p dp) over 16-32 nearly identical children) and the bf16 rounding of the Linear backward's
 output-gradient operand — the reference's own autocast policy — is amplified by the cancellation.  Matrices stored as three rows are
-a sample of the tensor's error and get 1.5 x the tolerance (3e-2); tensors stored in full keep 2e-2."""
+a sample of the tensor's error and get 1.5 x the tolerance (2.25e-2); tensors stored in full keep 1.5e-2."""
 import numpy as np
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
 
-TOL = 2e-2
+TOL = 1.5e-2            # measured worst: 1.4e-2 (a qkv.weight of the 256^3 dual step), norms within 1.1e-2
 TOL_SMALL_SIGNAL = 5e-2
 
 

@@ -9,7 +9,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 TOL_F32 = 1e-3      # north_star: "outputs within 1e-3 of reference"
-TOL_BF16 = 2e-2     # bf16 MFMA inputs through 12 layers (CPU bf16 emulation of the oracle predicts ~5e-3)
+TOL_BF16 = 1e-2     # bf16 MFMA inputs through 12 layers: measured 4.1e-3 ... 6.8e-3 (a CPU bf16 emulation of the oracle predicts ~5e-3)
 
 
 def rel(a, b):
