@@ -59,6 +59,7 @@ _vp, _i, _f, _i64, _sz, _u64 = C.c_void_p, C.c_int, C.c_float, C.c_int64, C.c_si
 # name -> argtypes (restype int unless listed in _RESTYPE); mirrors include/hsenet_hip.h one to one
 SIGNATURES = {
     "hs_version": [],
+    "hs_build_id": [],
     "hs_device_check": [_i],
     "hs_gemm": [C.POINTER(GemmArgs), _i, _vp],
     "hs_gemm_group": [C.POINTER(GemmArgs), _i, _vp],
@@ -124,7 +125,7 @@ SIGNATURES = {
     "hs_debug_gemm_trace": [_vp, _i],
 }
 _RESTYPE = {"hs_vit_workspace_bytes": _sz, "hs_attn_bwd_ws_bytes": _sz, "hs_embed_workspace_bytes": _sz, "hs_packer_workspace_bytes": _sz,
-            "hs_prof_name": C.c_char_p, "hs_debug_set": None, "hs_debug_gemm_stamps": None,
+            "hs_prof_name": C.c_char_p, "hs_build_id": C.c_char_p, "hs_debug_set": None, "hs_debug_gemm_stamps": None,
             "hs_debug_gemm_trace": None}
 
 _lib = None
@@ -153,6 +154,20 @@ def load() -> C.CDLL:
             fn.restype = _RESTYPE.get(name, C.c_int)
         _lib = lib
     return _lib
+
+
+def build_id() -> str:
+    """the content hash the loaded shared object was built from (hsenet_amd/build.py:source_id)."""
+    return load().hs_build_id().decode()
+
+
+def check_fresh() -> str:
+    """raise unless the loaded library was built from the sources in this tree (skipped for an HS_LIB_PATH ablation build)."""
+    from .build import source_id
+    have, want = build_id(), source_id()
+    if have != want and not os.environ.get("HS_LIB_PATH"):
+        raise HsError(f"{LIB_PATH} is stale: built from sources {have}, the tree is {want} (run `python -m hsenet_amd.build`)")
+    return have
 
 
 def call(name: str, *args) -> None:

@@ -3,6 +3,7 @@
 The shared object lands in hsenet_amd/lib/ (git-ignored, but it travels to the GPU box with the tree)."""
 from __future__ import annotations
 
+import hashlib
 import os
 import shutil
 import subprocess
@@ -30,23 +31,44 @@ def _hipcc() -> str:
     return exe
 
 
-def _stale(target: str, deps) -> bool:
-    if not os.path.exists(target):
-        return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps)
+def _hdrs():
+    return [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "driver.h"), os.path.join(CSRC, "attn_util.h"),
+            os.path.join(os.path.dirname(HERE), "include", "hsenet_hip.h")]
+
+
+def source_id(src: str = None) -> str:
+    """content hash (sha256, 16 hex digits) of one source + the headers + its flags, or — src None — of everything the library is built
+    from.  Staleness is decided by CONTENT, not by modification times (a checkout or a copy to another box resets those), and the
+    library-wide id is compiled into the shared object (hs_build_id) so that a loaded .so can be matched to the tree it came from."""
+    h = hashlib.sha256()
+    names = [src] if src else SOURCES
+    for n in names:
+        h.update(n.encode())
+        h.update(open(os.path.join(CSRC, n), "rb").read())
+        h.update(" ".join(FLAGS + EXTRA.get(n, [])).encode())
+    for f in _hdrs():
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def _read(path: str) -> str:
+    try:
+        return open(path).read().strip()
+    except OSError:
+        return ""
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
-    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "driver.h"), os.path.join(CSRC, "attn_util.h"), os.path.join(os.path.dirname(HERE), "include", "hsenet_hip.h")]
     hipcc = _hipcc()
-    objs, jobs = [], []
+    objs, jobs, stamps = [], [], []
     for s in SOURCES:
         src, obj = os.path.join(CSRC, s), os.path.join(LIBDIR, s.replace(".hip", ".o"))
         objs.append(obj)
-        if force or _stale(obj, [src] + hdrs):
+        sid, tag = source_id(s), obj + ".id"
+        if force or not os.path.exists(obj) or _read(tag) != sid:
             jobs.append([hipcc, *FLAGS, *EXTRA.get(s, []), "-c", src, "-o", obj])
+            stamps.append((tag, sid))
 
     def run(cmd):
         if verbose:
@@ -58,8 +80,16 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if jobs:
         with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
             list(ex.map(run, jobs))
-    if jobs or force or _stale(LIB, objs):
-        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs])
+        for tag, sid in stamps:
+            open(tag, "w").write(sid)
+    # the build id: always regenerated and compiled (a few hundred ms) — every build() call runs hipcc at least once
+    lid = source_id()
+    idc, ido = os.path.join(LIBDIR, "build_id.cpp"), os.path.join(LIBDIR, "build_id.o")
+    open(idc, "w").write(f'extern "C" const char* hs_build_id(void) {{ return "{lid}"; }}\n')
+    run([hipcc, "-O1", "-fPIC", "-c", idc, "-o", ido])
+    if jobs or force or not os.path.exists(LIB) or _read(LIB + ".id") != lid:
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, ido])
+        open(LIB + ".id", "w").write(lid)
     return LIB
 
 

@@ -643,9 +643,8 @@ static_assert(EF >= 0, "the 16x16x32 kernels are launched with compile-time epil
             vlo[st] = epi_math(p, flags, 0, acc16[i][J0 + 2 * jp], vlo[st], zl, bias_lo[jp], alpha_n[jp], &k0);
             vhi[st] = epi_math(p, flags, 0, acc16[i][J0 + 2 * jp + 1], vhi[st], zh, bias_hi[jp], alpha_n[jp], &k1);
             zb[st] = u32x4{k0[0], k0[1], k1[0], k1[1]};
-            if (want_aux_in) {
-                const float keep = in[st] ? 1.0f : 0.0f;       // rows / columns outside the matrix contribute nothing
-                cs_lo[jp] += vlo[st] * keep; cs_hi[jp] += vhi[st] * keep;
+            if (want_aux_in && in[st]) {                       // rows / columns outside the matrix contribute nothing: a SELECT, not a multiply by
+                cs_lo[jp] += vlo[st]; cs_hi[jp] += vhi[st];    // 0 (their aux words are row 0's: a NaN there times 0 would poison the whole column sum)
             }
         }
         // bf16 outputs: a lane's two 16-B pieces of row l15 (column halves jp = 0, 1) are HALF lines, 16 rows x 64 B per store
@@ -1293,6 +1292,7 @@ extern "C" int hs_gemm(const hs_gemm_args* a, int prec, void* stream) {
             if (col8 && f == 0) HS_LAUNCH_E(false, false, 0);
             else if (col8 && f == (HS_EPI_BIAS | HS_EPI_RESID)) HS_LAUNCH_E(false, false, HS_EPI_BIAS | HS_EPI_RESID);
             else if (col8 && f == (HS_EPI_BIAS | HS_EPI_GELU | HS_EPI_SAVE_DGELU)) HS_LAUNCH_E(false, false, HS_EPI_BIAS | HS_EPI_GELU | HS_EPI_SAVE_DGELU);
+            else if (col8 && f == (HS_EPI_GELU_BWD | HS_EPI_SAVE_DGELU)) HS_LAUNCH_E(false, false, HS_EPI_GELU_BWD | HS_EPI_SAVE_DGELU);   // fc2's dgrad against W2^T at shapes too small for the 256x256 tile
             else HS_LAUNCH_E(false, false, -1);
         } else if (a->layout == HS_GEMM_NN) {
             if (col8 && f == 0) HS_LAUNCH_E(false, true, 0);

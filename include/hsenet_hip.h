@@ -72,6 +72,9 @@ typedef struct hs_gemm_args {
 
 /* ---- library ------------------------------------------------------------------------------------------ */
 int hs_version(void);
+/* 16 hex digits: content hash of every source, header and compiler flag the loaded library was built from
+ * (hsenet_amd/build.py:source_id).  __graft_entry__.build() and smoke() compare it with the tree: a stale .so is an error. */
+const char* hs_build_id(void);
 /* HS_OK when device `dev` is gfx950 */
 int hs_device_check(int dev);
 

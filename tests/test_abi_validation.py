@@ -10,7 +10,7 @@ import torch
 
 from hsenet_amd import _lib as L
 
-NO_COMPUTE = {"hs_version", "hs_device_check", "hs_prof_enable", "hs_prof_read", "hs_prof_name", "hs_prof_count", "hs_debug_set",
+NO_COMPUTE = {"hs_version", "hs_build_id", "hs_device_check", "hs_prof_enable", "hs_prof_read", "hs_prof_name", "hs_prof_count", "hs_debug_set",
               "hs_debug_gemm_stamps", "hs_debug_gemm_trace"}
 FAKE = 0x10000          # 16-byte aligned, never dereferenced
 has_gpu = torch.cuda.is_available()

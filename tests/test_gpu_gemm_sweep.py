@@ -119,3 +119,25 @@ def test_gemm_batched_strided_bf16(dev):
     torch.cuda.synchronize()
     want = a.double().cpu() @ w.double().cpu().t()
     assert rel(out[:, 1], want) < 1e-5 and torch.isnan(out[:, 0]).all()
+
+
+def test_dgelu_column_sums_ignore_rows_outside_the_matrix(dev):
+    """the 16x16x32 NT kernel's x gelu' epilogue with fused column sums (fc2's dgrad) on a RAGGED M: lanes of rows past M load the aux
+    words of row 0.  With NaN / Inf planted there the products of the real rows must still be right and the column sums finite where the
+    real aux column is finite — out-of-matrix rows are dropped by a select, not by a multiply with 0 (NaN * 0 = NaN)."""
+    from hsenet_amd import functional as Fn, _lib as L
+    M, N, K = 33 * 256 + 20, 768, 192                                  # 34 x 3 tiles of 256x256 > CUs / 2: the big tile, ragged last row tile
+    g = torch.Generator().manual_seed(77)
+    a = torch.randn(M, K, generator=g).bfloat16()
+    b = torch.randn(N, K, generator=g).bfloat16()
+    aux = (0.3 * torch.randn(M, N, generator=g)).bfloat16()
+    aux[0, :8] = float("nan")                                          # row 0, first 8 columns: what an out-of-range lane reads
+    aux[0, 8:16] = float("inf")
+    cs = torch.zeros(N, device=dev)
+    o16 = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    Fn.gemm(a.to(dev), b.to(dev), L.GEMM_NT, prec=L.PREC_BF16, out_bf16=o16, aux=aux.to(dev), flags=L.EPI_GELU_BWD | L.EPI_SAVE_DGELU,
+            colsum_out=cs)
+    want = (a.double() @ b.double().t()) * aux.double()
+    assert rel(o16[1:].float(), want[1:]) < 4e-3
+    # columns 16.. : row 0's aux is finite there -> exact column sums; columns 0..15 hold row 0's own NaN / Inf and nothing else is expected
+    assert torch.isfinite(cs[16:]).all() and rel(cs[16:], want[:, 16:].sum(0)) < 1e-4

@@ -48,10 +48,8 @@ def run(rows, d, variant, dev, reps=50):
 
 
 def product_rule(rows, d):
-    blocks = min(2048, (rows + 3) // 4)
-    if rows // 16 >= 256 and (rows + 15) // 16 < blocks:
-        blocks = (rows + 15) // 16
-    return blocks * 16 >= rows and rows // 32 >= 128 and d <= 768
+    """mirror of hsenet_amd/csrc/norm.hip hs_layernorm_bwd's selection (`bool wide = ...`): keep the two in step."""
+    return rows // 32 >= 128 and rows <= 10 * 4100 and d <= 768
 
 
 def main():
