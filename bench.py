@@ -23,7 +23,8 @@ attention is nearly uniform, trained attention is peaky and the attention kernel
 Prints ONE JSON line (rank 0).  Beside the contract keys: `attention` (credited TFLOP/s and fraction of peak over attention forward +
 both backward sweeps: the north-star's own number), `optimizer_excluded` (the rate of forward + backward + all-reduce alone),
 `peaky_attention` (the same step and attention figures at logit std 1.5), `f32_mode` (volumes/s of the <= 1e-3 parity mode through
-the module API).  Extra objects: `roofline` (dominant kernel class, measured with HIP events on the launch
+the module API), `eval_forward` (forward-only volumes/s at bf16 / fp16 / f32 operands with the fp16 and bf16 outputs' distance from
+the f32 ones: fp16 is the reference's eval-time autocast dtype and lands inside 1e-3 at the bf16 kernels' speed).  Extra objects: `roofline` (dominant kernel class, measured with HIP events on the launch
 stream in a second, instrumented pass over the same steps), `cpu_baseline` (the CPU oracle — a plain-PyTorch fp32 port of the
 reference — timed on this host for the SAME workload, rank 0, N=1 only) and `batch1` (the same step at 1 volume per GPU, the
 per-GPU load of configs[3]/[4]).
@@ -140,6 +141,51 @@ def set_attn_logit_std(models, std):
                 w[:d].mul_(f)
                 first = f if first is None else first
     return first
+
+
+def eval_forward_rates(workload, geom, dev, batch=4, steps=3):
+    """forward-only volumes/s of the module API (torch.no_grad(), eval(): the reference's generation / eval path runs the encoders once per
+    sample) at each operand precision: bf16 (the training dtype), fp16 (the reference's eval-time autocast dtype,
+    Bench/eval/eval_HSENet_CT_Rate_MRG.py:383,423: same kernels with fp16 packs, outputs within 1e-3 of the reference) and exact f32."""
+    import hsenet_amd as H
+    img, patch = geom["img"], geom["patch"]
+    torch.manual_seed(1234)
+    rng = np.random.default_rng(98)
+    vol = torch.from_numpy(rng.random((batch, 1) + img, dtype=np.float32)).to(dev)
+    s2d = torch.from_numpy(rng.standard_normal((batch, 32, 768), dtype=np.float32)).to(dev)
+    if workload in ("dual256", "native_dual"):
+        tower = H.build_vision_tower(TowerCfg(img, patch)).to(dev).eval()
+        pk = dict(grid=geom["grid"], kernel_size=geom["kernel"])
+        p1 = H.VisualPacker_3d_phi_v3(img, patch, 768, OUT_DIM, "mlp", 2, **pk).to(dev).eval()
+        p2 = H.VisualPacker_3d_phi_v3(img, patch, 768, OUT_DIM, "mlp", 2, **pk).to(dev).eval()
+        fwd = lambda: H.encode_images(tower, p1, p2, vol, s2d)
+    elif workload == "vit256":
+        m = H.ViT_stage1(in_channels=1, img_size=img, patch_size=patch, pos_embed="perceptron", classification=True).to(dev).eval()
+        fwd = lambda: m(vol)[0]
+    else:
+        return None
+    res = {"batch_per_gpu": batch, "steps": steps, "unit": "CT-volumes/sec",
+           "what": "forward only, module API under torch.no_grad() (the eval / generation path: encoders once per sample)"}
+    ref = None
+    for prec in ("f32", "bf16", "f16"):
+        H.set_precision(prec)
+        try:
+            with torch.no_grad():
+                y = fwd()                                       # warm-up
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    y = fwd()
+                torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+        finally:
+            H.set_precision("bf16")
+        res[prec] = round(batch / dt, 3)
+        if prec == "f32":
+            ref = y.double()
+        else:
+            res[prec + "_rel_err_vs_f32"] = float(f"{float((y.double() - ref).norm() / ref.norm()):.3e}")
+    return res
 
 
 def f32_mode_rate(workload, geom, dev, steps=2):
@@ -370,7 +416,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-batch1", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the optimizer_excluded / peaky_attention / f32_mode legs")
+    ap.add_argument("--no-extras", action="store_true", help="skip the optimizer_excluded / peaky_attention / f32_mode / eval_forward legs")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: --batch volumes on EVERY GPU; strong: --global-batch volumes in total, split over the GPUs")
     ap.add_argument("--global-batch", type=int, default=None, help="--scaling strong: total volumes per step (default 56 = 7 per GPU at 8 GPUs; "
@@ -616,6 +662,10 @@ def main():
         f32 = f32_mode_rate(a.workload, geom, dev)
         if f32:
             out["f32_mode"] = f32
+        torch.cuda.empty_cache()
+        ev = eval_forward_rates(a.workload, geom, dev)
+        if ev:
+            out["eval_forward"] = ev
     if rank == 0 and world == 1 and not a.no_cpu_baseline and a.workload != "mrg_c5":      # (the LLM-dominated step has no CPU leg)
         out["cpu_baseline"] = cpu_baseline(a.workload, geom)
     if rank == 0:

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HS_LIB_PATH") or os.path.join(HERE, "lib", "libhsenet_hip.so")   # override: ablation builds only
 
 HS_OK, HS_ERR_SHAPE, HS_ERR_ARCH, HS_ERR_LAUNCH, HS_ERR_ARG = 0, -1, -2, -3, -4
-PREC_BF16, PREC_F32 = 0, 1
+PREC_BF16, PREC_F32, PREC_F16 = 0, 1, 2
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 EPI_BIAS, EPI_GELU, EPI_GELU_BWD, EPI_RESID, EPI_ATOMIC, EPI_BIAS_M, EPI_SAVE_DGELU = 1, 2, 4, 8, 16, 32, 64
 ATTN_Q_PRESCALED, ATTN_F32, ATTN_ONE_SWEEP, ATTN_ONE_SWEEP_TILES = 1, 2, 4, 8
@@ -85,6 +85,7 @@ SIGNATURES = {
     "hs_colsum": [_vp, _i, _vp, _i, _i, _i64, _vp],
     "hs_cast_bf16": [_vp, _vp, _i64, _vp],
     "hs_cast_f32": [_vp, _vp, _i64, _vp],
+    "hs_cast_f16": [_vp, _vp, _i64, _vp],
     "hs_gelu_fwd": [_vp, _vp, _i64, _vp],
     "hs_gelu_bwd": [_vp, _vp, _vp, _i64, _vp],
     "hs_l2norm_fwd": [_vp, _vp, _i, _i, _f, _vp],

@@ -43,7 +43,7 @@ __device__ __forceinline__ void attn_block_coords(int nblk, int H, int& blk, int
 // ------------------------------------------------------------------------------------------------------
 // GUARD: run only the 128-query blocks in which the fast kernel (below) left a NaN lse, i.e. rows whose optimistic
 // softmax left the f32 window; every other block exits after one load.
-template <bool GUARD>
+template <bool GUARD, bool F16 = false>
 __global__ __launch_bounds__(256, 3) void attn_fwd_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
                                                             float* __restrict__ lse, int N, int H, float c2) {
     // c2 = log2(e) x the factor still to be applied to q.k (dh^-0.5, or 1/log2(e) when q arrives pre-scaled)
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_bf16_kernel(const bf16_t* __r
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
-                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Kl, kb * 32 + c, ks, h), qf[ks], s[kb], 0, 0, 0);
+                s[kb] = mfma32<F16>(row_frag(Kl, kb * 32 + c, ks, h), qf[ks], s[kb]);
         if (LAST) {
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
@@ -143,11 +143,10 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_bf16_kernel(const bf16_t* __r
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int sp = 0; sp < 2; ++sp) {
-                const bf16x8 pf = pack8(s[kb], sp);
+                const bf16x8 pf = pack8<F16>(s[kb], sp);
 #pragma unroll
                 for (int db = 0; db < 2; ++db)
-                    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Vl, kb * 32 + 16 * sp, db, lane), pf,
-                                                                      oacc[db], 0, 0, 0);
+                    oacc[db] = mfma32<F16>(tr_frag(Vl, kb * 32 + 16 * sp, db, lane), pf, oacc[db]);
             }
     };
     typedef std::integral_constant<int, 0> S0;
@@ -177,7 +176,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_bf16_kernel(const bf16_t* __r
     }
     const int query = q0 + c;
     if (query < N) {
-        store_dT(o + ((long)b * N + query) * Dm + head * 64, oacc, 1.0f / l, h);
+        store_dT<F16>(o + ((long)b * N + query) * Dm + head * 64, oacc, 1.0f / l, h);
         if (h == 0) lse[((long)b * H + head) * N + query] = m * (c2 * 0.69314718055994531f) + __logf(l);
     }
 }
@@ -1151,7 +1150,7 @@ extern "C" int hs_attn_fwd(const void* qkv, void* o, float* lse, int B, int N, i
     if (!qkv || !o) return HS_ERR_ARG;
     if (dh != 64 || B < 1 || N < 1 || H < 1) return HS_ERR_SHAPE;
     if (flags & ~HS_ATTN_Q_PRESCALED) return HS_ERR_ARG;
-    const size_t esz = prec == HS_PREC_BF16 ? 2 : 4;
+    const size_t esz = prec == HS_PREC_F32 ? 4 : 2;
     if ((size_t)N * 3 * H * 64 * esz >= HS_MAX_RECORDS) return HS_ERR_SHAPE;
     if (((uintptr_t)qkv | (uintptr_t)o) & 15) return HS_ERR_SHAPE;
     const float LOG2E = 1.44269504088896341f;
@@ -1175,6 +1174,11 @@ extern "C" int hs_attn_fwd(const void* qkv, void* o, float* lse, int B, int N, i
         }
     } else if (prec == HS_PREC_F32) {
         hipLaunchKernelGGL(attn_fwd_f32_kernel, grid, dim3(256), 0, s, (const float*)qkv, (float*)o, lse, N, H, c2);
+    } else if (prec == HS_PREC_F16) {
+        // fp16 operands (forward only): the running-maximum kernel -- P = exp2(s - max) <= 1 sits in fp16's range, as the softmax ->
+        // .half() of the reference's autocast does; the optimistic kernel's un-referenced exp2(s) would leave it beyond +-16
+        if (!lse) return HS_ERR_ARG;
+        hipLaunchKernelGGL((attn_fwd_bf16_kernel<false, true>), grid1, dim3(256), 0, s, (const bf16_t*)qkv, (bf16_t*)o, lse, N, H, c2);
     } else {
         return HS_ERR_ARG;
     }

@@ -9,12 +9,13 @@ __device__ __forceinline__ f32x16 zero16() {
     for (int r = 0; r < 16; ++r) z[r] = 0.f;
     return z;
 }
-__device__ __forceinline__ bf16x8 pack8(const f32x16& a, int s) {  // registers 8s..8s+7 -> bf16x8 (k-step s)
+template <bool F16 = false>
+__device__ __forceinline__ bf16x8 pack8(const f32x16& a, int s) {  // registers 8s..8s+7 -> bf16x8 / f16x8 (k-step s)
     u32x4 u;
-    u[0] = pack2bf(a[8 * s + 0], a[8 * s + 1]);
-    u[1] = pack2bf(a[8 * s + 2], a[8 * s + 3]);
-    u[2] = pack2bf(a[8 * s + 4], a[8 * s + 5]);
-    u[3] = pack2bf(a[8 * s + 6], a[8 * s + 7]);
+    u[0] = pack2h<F16>(a[8 * s + 0], a[8 * s + 1]);
+    u[1] = pack2h<F16>(a[8 * s + 2], a[8 * s + 3]);
+    u[2] = pack2h<F16>(a[8 * s + 4], a[8 * s + 5]);
+    u[3] = pack2h<F16>(a[8 * s + 6], a[8 * s + 7]);
     return __builtin_bit_cast(bf16x8, u);
 }
 // column (transposed) fragment of image R: element j <-> row rowbase + 8(j>>2) + 4h + (j&3), column db*32 + (lane&31)
@@ -30,14 +31,15 @@ __device__ __forceinline__ bf16x8 row_frag(const char* img, int row, int ks, int
     return *(const bf16x8*)(img + offR(row, 2 * ks + h));
 }
 // store a [d][query] accumulator pair as rows of a [..][ld] bf16 matrix: lane owns one query row
+template <bool F16 = false>
 __device__ __forceinline__ void store_dT(bf16_t* rowptr, const f32x16 (&acc)[2], float mul, int h) {
 #pragma unroll
     for (int db = 0; db < 2; ++db)
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
             u32x2 v;
-            v[0] = pack2bf(acc[db][4 * g4 + 0] * mul, acc[db][4 * g4 + 1] * mul);
-            v[1] = pack2bf(acc[db][4 * g4 + 2] * mul, acc[db][4 * g4 + 3] * mul);
+            v[0] = pack2h<F16>(acc[db][4 * g4 + 0] * mul, acc[db][4 * g4 + 1] * mul);
+            v[1] = pack2h<F16>(acc[db][4 * g4 + 2] * mul, acc[db][4 * g4 + 3] * mul);
             *(u32x2*)(rowptr + db * 32 + 8 * g4 + 4 * h) = v;
         }
 }

@@ -34,6 +34,42 @@ __device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
     return __builtin_bit_cast(unsigned, r);
 }
 
+// ---- 16-bit operand format as a template flag: bf16 (F16 = false: training, the reference's torch.autocast(bf16)) or IEEE fp16 (F16 = true:
+// HS_PREC_F16, forward only -- the reference's generation / eval scripts run under torch.cuda.amp.autocast()'s default dtype, fp16).
+// Same kernels, same LDS images, same data flow: only the packs / unpacks and the MFMA opcode differ (fp16 MFMA runs at the bf16 rate).
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+template <bool F16> __device__ __forceinline__ unsigned pack2h(float lo, float hi) {
+    if constexpr (F16) {
+        typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+        typedef __attribute__((ext_vector_type(2))) float f2;
+        f2 v = {lo, hi};
+        h2 r = __builtin_convertvector(v, h2);           // round to nearest even (v_cvt_pk_f16_f32); overflow -> inf, as torch's .half()
+        return __builtin_bit_cast(unsigned, r);
+    } else {
+        return pack2bf(lo, hi);
+    }
+}
+template <bool F16> __device__ __forceinline__ bf16_t f2h(float f) {
+    if constexpr (F16) { _Float16 h = (_Float16)f; return __builtin_bit_cast(unsigned short, h); } else return f2bf(f);
+}
+template <bool F16> __device__ __forceinline__ float h2f(bf16_t v) {
+    if constexpr (F16) return (float)__builtin_bit_cast(_Float16, v); else return bf2f(v);
+}
+template <bool F16> __device__ __forceinline__ float unpack_lo(unsigned u) {
+    if constexpr (F16) return (float)__builtin_bit_cast(_Float16, (unsigned short)(u & 0xffffu)); else return __uint_as_float(u << 16);
+}
+template <bool F16> __device__ __forceinline__ float unpack_hi(unsigned u) {
+    if constexpr (F16) return (float)__builtin_bit_cast(_Float16, (unsigned short)(u >> 16)); else return __uint_as_float(u & 0xffff0000u);
+}
+template <bool F16> __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+template <bool F16> __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
 // row in a 32x32 MFMA accumulator held in register r by a lane of half h (cdna guide section 3)
 __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 

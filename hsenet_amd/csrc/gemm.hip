@@ -23,6 +23,7 @@ struct GemmP {
     int nt;                                // streaming (nontemporal) output stores, see hs_gemm
     int nblocks;                           // tiles_m * tiles_n * zdim
     int gm;                                // row tiles per group of the tile order (chosen by hs_gemm, see tile_order)
+    int np;                                // column tiles per PANEL of the tile order (0: one panel = every column tile)
     // diagnostic (tools/kbench, HS_GEMM_DBG): 1 = skip the epilogue, 2 = one K-tile only, 3 = epilogue without its stores, 4 = s_memtime
     // phase sums (hs_debug_gemm_stamps), 5 = every K-tile re-reads the first (cache hits), 7 = 3 + 4, 22 = per-block timeline
     // (hs_debug_gemm_trace).  Compiled in only under -DHS_DEBUG_HOOKS (tools/build_variant.sh): in the product build HS_DBG(x) is the
@@ -30,29 +31,29 @@ struct GemmP {
     int dbg_;
 };
 
-template <bool F32AUX>
+template <bool F32AUX, bool F16 = false>
 __device__ __forceinline__ void epilogue_store(const GemmP& p, long cz, int m, int n, float v) {
     if (m >= p.M || n >= p.N) return;
     v *= n < p.scale_cols ? p.alpha * p.scale_alpha : p.alpha;
     if (p.flags & HS_EPI_BIAS) v += p.bias[(p.flags & HS_EPI_BIAS_M) ? m : n];
     const long idx = cz + (long)m * p.ldc + n;
     if (p.flags & HS_EPI_GELU) {
-        if (!F32AUX) v = bf2f(f2bf(v));  // autocast: linear1 emits bf16, GELU runs on that
+        if (!F32AUX) v = h2f<F16>(f2h<F16>(v));  // autocast: linear1 emits bf16 (fp16), GELU runs on that
         if (p.aux_out) {
             const float keep = (p.flags & HS_EPI_SAVE_DGELU) ? gelu_grad_f(v) : v;
-            if (F32AUX) ((float*)p.aux_out)[idx] = keep; else ((bf16_t*)p.aux_out)[idx] = f2bf(keep);
+            if (F32AUX) ((float*)p.aux_out)[idx] = keep; else ((bf16_t*)p.aux_out)[idx] = f2h<F16>(keep);
         }
         v = gelu_f(v);
     }
     if (p.flags & HS_EPI_GELU_BWD) {
-        const float z = F32AUX ? ((const float*)p.aux)[idx] : bf2f(((const bf16_t*)p.aux)[idx]);
+        const float z = F32AUX ? ((const float*)p.aux)[idx] : h2f<F16>(((const bf16_t*)p.aux)[idx]);
         v *= (p.flags & HS_EPI_SAVE_DGELU) ? z : gelu_grad_f(z);
     }
     if (p.flags & HS_EPI_RESID) v += p.resid[idx];
     if (p.out_f32) {
         if (p.flags & HS_EPI_ATOMIC) atomicAdd(&p.out_f32[idx], v); else p.out_f32[idx] = v;
     }
-    if (p.out_bf16) ((bf16_t*)p.out_bf16)[idx] = f2bf(v);
+    if (p.out_bf16) ((bf16_t*)p.out_bf16)[idx] = f2h<F16>(v);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -135,6 +136,7 @@ __device__ __forceinline__ bf16x8 g_frag(const char* lds, int sub, int ks, int l
 // hipcc waits vmcnt(0) before every use of a loaded value — with a store between two uses that is one store round trip
 // per step (~32 per block), which cost more than the K=768 main loop.
 // epi_math: v -> final value (bias, GELU(+value to save), GELU', residual); *keep = bf16x4 to store to aux_out.
+template <bool F16 = false>
 __device__ __forceinline__ f32x4 epi_math(const GemmP& p, const int flags, int m, f32x4 v, f32x4 res, u32x2 zb_in, f32x4 bias_n, float alpha_n, u32x2* keep) {
     v *= alpha_n;
     if (flags & HS_EPI_BIAS) {
@@ -142,20 +144,19 @@ __device__ __forceinline__ f32x4 epi_math(const GemmP& p, const int flags, int m
     }
     if (flags & HS_EPI_GELU) {
         u32x2 zb;
-        zb[0] = pack2bf(v[0], v[1]); zb[1] = pack2bf(v[2], v[3]);       // autocast: linear1 emits bf16
-        v[0] = __uint_as_float(zb[0] << 16); v[1] = __uint_as_float(zb[0] & 0xffff0000u);
-        v[2] = __uint_as_float(zb[1] << 16); v[3] = __uint_as_float(zb[1] & 0xffff0000u);
+        zb[0] = pack2h<F16>(v[0], v[1]); zb[1] = pack2h<F16>(v[2], v[3]);       // autocast: linear1 emits bf16 (fp16)
+        v[0] = unpack_lo<F16>(zb[0]); v[1] = unpack_hi<F16>(zb[0]);
+        v[2] = unpack_lo<F16>(zb[1]); v[3] = unpack_hi<F16>(zb[1]);
         f32x4 dg;
 #pragma unroll
         for (int e = 0; e < 4; ++e) { float c, px; gelu_parts(v[e], c, px); v[e] *= c; dg[e] = c + px; }
         // HS_EPI_SAVE_DGELU: keep gelu'(z) (it shares exp(-z^2/2) with gelu) instead of z, so the backward epilogue is
         // one multiply instead of an erf + exp per element
-        if (flags & HS_EPI_SAVE_DGELU) { zb[0] = pack2bf(dg[0], dg[1]); zb[1] = pack2bf(dg[2], dg[3]); }
+        if (flags & HS_EPI_SAVE_DGELU) { zb[0] = pack2h<F16>(dg[0], dg[1]); zb[1] = pack2h<F16>(dg[2], dg[3]); }
         *keep = zb;
     }
     if (flags & HS_EPI_GELU_BWD) {
-        const float z[4] = {__uint_as_float(zb_in[0] << 16), __uint_as_float(zb_in[0] & 0xffff0000u),
-                            __uint_as_float(zb_in[1] << 16), __uint_as_float(zb_in[1] & 0xffff0000u)};
+        const float z[4] = {unpack_lo<F16>(zb_in[0]), unpack_hi<F16>(zb_in[0]), unpack_lo<F16>(zb_in[1]), unpack_hi<F16>(zb_in[1])};
         if (flags & HS_EPI_SAVE_DGELU) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] *= z[e];                  // aux already holds gelu'(z)
@@ -167,12 +168,13 @@ __device__ __forceinline__ f32x4 epi_math(const GemmP& p, const int flags, int m
     if (flags & HS_EPI_RESID) v += res;
     return v;
 }
+template <bool F16 = false>
 __device__ __forceinline__ void epi_store(const GemmP& p, long idx, f32x4 v, u32x2 keep) {
     if ((p.flags & HS_EPI_GELU) && p.aux_out) *(u32x2*)((bf16_t*)p.aux_out + idx) = keep;
     if (p.out_f32) *(f32x4*)(p.out_f32 + idx) = v;
     if (p.out_bf16) {
         u32x2 o;
-        o[0] = pack2bf(v[0], v[1]); o[1] = pack2bf(v[2], v[3]);
+        o[0] = pack2h<F16>(v[0], v[1]); o[1] = pack2h<F16>(v[2], v[3]);
         *(u32x2*)((bf16_t*)p.out_bf16 + idx) = o;
     }
 }
@@ -223,7 +225,7 @@ __device__ __forceinline__ void tr_settle(u32x4& a, u32x4& b, u32x4& c, u32x4& d
 
 // one K-tile of MFMA work for a wave, with the DMA pieces of the prefetched K-tile (if any: `issue`, wave-uniform)
 // issued behind the MFMA groups.  A single code path keeps the 64-128 accumulator registers out of phi copies.
-template <bool ATR, bool BTR, bool BIG>
+template <bool ATR, bool BTR, bool BIG, bool F16 = false>
 __device__ __forceinline__ void ktile_step(f32x16 (&acc)[GCfg<BIG>::MB][2], const char* a_l, const char* b_l, char* nxt, int row0, int col0,
                                            int wave, int lane, __amdgpu_buffer_rsrc_t rsA, __amdgpu_buffer_rsrc_t rsB,
                                            const unsigned (&va)[4], const unsigned (&vb)[GCfg<BIG>::PB], unsigned sa, unsigned sb, bool issue) {
@@ -259,8 +261,8 @@ __device__ __forceinline__ void ktile_step(f32x16 (&acc)[GCfg<BIG>::MB][2], cons
 #pragma unroll
             for (int i = 0; i < C::MB; ++i) {
                 const bf16x8 a = g_frag<ATR>(a_l, row0 + 32 * i, KS, lane);   // (TN never uses the big tile: hs_gemm)
-                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, as_frag(b0), acc[i][0], 0, 0, 0);
-                acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, as_frag(b1), acc[i][1], 0, 0, 0);
+                acc[i][0] = mfma32<F16>(a, as_frag(b0), acc[i][0]);
+                acc[i][1] = mfma32<F16>(a, as_frag(b1), acc[i][1]);
             }
             piece(2 * KS);
             piece(2 * KS + 1);                                       // 8 pieces: 2 per k-step
@@ -297,7 +299,7 @@ __device__ __forceinline__ void ktile_step(f32x16 (&acc)[GCfg<BIG>::MB][2], cons
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(fa[CUR][i]), as_frag(fb[CUR][j]), acc[i][j], 0, 0, 0);
+                    acc[i][j] = mfma32<F16>(as_frag(fa[CUR][i]), as_frag(fb[CUR][j]), acc[i][j]);
             if (KS < 2) { piece(2 * KS); piece(2 * KS + 1); } else piece(KS + 2);   // 6 pieces: (0,1)(2,3)(4)(5)
             if (KS < 3) settle(std::integral_constant<int, NX>{});
         };
@@ -322,7 +324,7 @@ __device__ unsigned long long g_gemm_stamps[8];
 //                                     lgkmcnt(0) (every read of stage s retired), vmcnt(0) (tile t+1 landed), s_barrier
 //                                     ks3: read F(t+1,0) from stage s^1 | MFMA F(t,3) | DMA pieces 0-3 of tile t+2 -> stage s
 // Requires K % 64 == 0 (hs_gemm picks the 256x128 tile otherwise).
-template <bool BTR>
+template <bool BTR, bool F16 = false>
 __device__ __forceinline__ void big_mainloop(f32x16 (&acc)[4][2], char* smem, int row0, int col0, int wave, int lane,
                                              __amdgpu_buffer_rsrc_t rsA, __amdgpu_buffer_rsrc_t rsB, const unsigned (&va)[4],
                                              const unsigned (&vb)[4], unsigned ka, unsigned kb, int kt0, int kt1, int dbg) {
@@ -363,7 +365,7 @@ __device__ __forceinline__ void big_mainloop(f32x16 (&acc)[4][2], char* smem, in
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(fa[S][i]), as_frag(fb[S][j]), acc[i][j], 0, 0, 0);
+                acc[i][j] = mfma32<F16>(as_frag(fa[S][i]), as_frag(fb[S][j]), acc[i][j]);
     };
     auto dma = [&](int kt, unsigned so, int q0) {          // pieces q0 .. q0+3 of tile kt (0-3: A, 4-7: B)
         if (HS_DBG(dbg) == 5) kt = kt0;                              // diagnostic: every tile re-reads the first one (cache hits)
@@ -426,6 +428,7 @@ __device__ __forceinline__ void lds_wait8g(u32x4& a, u32x4& b, u32x4& c, u32x4& 
 // of tile t (1.75 K-tiles before the barrier that needs it), B(t+2) in phase 3 of tile t (1.0 K-tile); the issue ORDER B(t+1) < A(t+2)
 // makes "everything but the newest 4 pieces" exactly the pieces barrier(t) needs (A(t+1), B(t+1)), so the wait is a counted vmcnt(4).
 //   LDS: A stages at 0 / 32 K / 64 K, B stages at 96 K / 128 K.
+template <bool F16 = false>
 __device__ __forceinline__ void big_mainloop16(f32x4 (&acc)[8][4], char* smem, int row0, int col0, int wave, int lane,
                                                   __amdgpu_buffer_rsrc_t rsA, __amdgpu_buffer_rsrc_t rsB, const unsigned (&va)[4],
                                                   const unsigned (&vb)[4], unsigned ka, unsigned kb, int kt0, int kt1) {
@@ -455,7 +458,7 @@ __device__ __forceinline__ void big_mainloop16(f32x4 (&acc)[8][4], char* smem, i
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                acc[HF * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(fb[SB][j]), as_frag(fa[SA][i]), acc[HF * 4 + i][j], 0, 0, 0);
+                acc[HF * 4 + i][j] = mfma16<F16>(as_frag(fb[SB][j]), as_frag(fa[SA][i]), acc[HF * 4 + i][j]);
     };
     auto dmaA = [&](int kt, unsigned sa) {
 #pragma unroll
@@ -529,17 +532,28 @@ __device__ __forceinline__ void keep_alive(const f32x16& v) { asm volatile("" ::
 __device__ __forceinline__ void keep4(const f32x4& v) { asm volatile("" ::"v"(v)); }
 
 // virtual block b of nb -> (row tile, column tile, slice): see the comment on the XCD-aware order in gemm_bf16_kernel
-__device__ __forceinline__ void tile_order(int b, int nb, int tiles_m, int tiles_n, int& tm, int& tn, int& z, int GM) {
+__device__ __forceinline__ void tile_order(int b, int nb, int tiles_m, int tiles_n, int& tm, int& tn, int& z, int GM, int NP = 0) {
     const int q = nb >> 3, r = nb & 7, x = b & 7;
     int v = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
     const int tiles = tiles_m * tiles_n;
     z = v / tiles;
     v -= z * tiles;
-    const int per_group = GM * tiles_n;
+    // column panels (NP column tiles each, the last one possibly narrower), slowest inside a slice: the B rows of ONE panel stay in the
+    // XCD's L2 while every row tile passes by (a 3072-column weight is 4.7 MB: as one panel it streams through the 4-MiB L2 once per
+    // group of row tiles)
+    int c0 = 0, wdt = tiles_n;
+    if (NP > 0 && NP < tiles_n) {
+        const int per_panel = tiles_m * NP, last = (tiles_n - 1) / NP;
+        const int pi = min(v / per_panel, last);
+        c0 = pi * NP;
+        wdt = min(NP, tiles_n - c0);
+        v -= pi * per_panel;
+    }
+    const int per_group = GM * wdt;
     const int g = v / per_group, w = v - g * per_group;
     const int gm = min(GM, tiles_m - g * GM);
     tm = g * GM + w % gm;
-    tn = w / gm;
+    tn = c0 + w / gm;
 }
 
 // lanes l and l ^ 8 (same 16-lane row) trade one 16-B piece: afterwards a (lanes & 15) < 8 lane holds {own a, partner's a} and the
@@ -552,7 +566,7 @@ __device__ __forceinline__ void half_line_swap(u32x4& a, u32x4& b, bool lo8) {
         if (lo8) b[e] = got; else a[e] = got;
     }
 }
-template <int EF, int NJ = 4, int J0 = 0>
+template <int EF, int NJ = 4, int J0 = 0, bool F16 = false>
 __device__ __forceinline__ void epilogue16(const GemmP& p, const f32x4 (&acc16)[8][NJ], int mw, int nw, long cz, int lane) {
     // ---- 16x16x32 form: the MFMAs ran with the operands SWAPPED (D' = B-tile x A-tile), so a lane holds, for output row
     // m = 16 i + (lane & 15), the columns 16 j + 4 (lane >> 4) + r of the B IMAGE -- which permN laid out so that tiles
@@ -640,8 +654,8 @@ static_assert(EF >= 0, "the 16x16x32 kernels are launched with compile-time epil
             const int i = 2 * g + (st >> 1), jp = st & 1;
             u32x2 k0 = {0u, 0u}, k1 = {0u, 0u}, zl = {0u, 0u}, zh = {0u, 0u};
             if (want_aux_in) { zl = u32x2{zin[g & 1][st][0], zin[g & 1][st][1]}; zh = u32x2{zin[g & 1][st][2], zin[g & 1][st][3]}; }
-            vlo[st] = epi_math(p, flags, 0, acc16[i][J0 + 2 * jp], vlo[st], zl, bias_lo[jp], alpha_n[jp], &k0);
-            vhi[st] = epi_math(p, flags, 0, acc16[i][J0 + 2 * jp + 1], vhi[st], zh, bias_hi[jp], alpha_n[jp], &k1);
+            vlo[st] = epi_math<F16>(p, flags, 0, acc16[i][J0 + 2 * jp], vlo[st], zl, bias_lo[jp], alpha_n[jp], &k0);
+            vhi[st] = epi_math<F16>(p, flags, 0, acc16[i][J0 + 2 * jp + 1], vhi[st], zh, bias_hi[jp], alpha_n[jp], &k1);
             zb[st] = u32x4{k0[0], k0[1], k1[0], k1[1]};
             if (want_aux_in && in[st]) {                       // rows / columns outside the matrix contribute nothing: a SELECT, not a multiply by
                 cs_lo[jp] += vlo[st]; cs_hi[jp] += vhi[st];    // 0 (their aux words are row 0's: a NaN there times 0 would poison the whole column sum)
@@ -671,10 +685,10 @@ static_assert(EF >= 0, "the 16x16x32 kernels are launched with compile-time epil
                 const long idxA = cz + (long)mA * p.ldc + nAB, idxB = idxA + 8 * p.ldc;
                 if (p.out_bf16) {
                     u32x4 o0, o1;
-                    o0[0] = pack2bf(vlo[s0][0], vlo[s0][1]); o0[1] = pack2bf(vlo[s0][2], vlo[s0][3]);
-                    o0[2] = pack2bf(vhi[s0][0], vhi[s0][1]); o0[3] = pack2bf(vhi[s0][2], vhi[s0][3]);
-                    o1[0] = pack2bf(vlo[s1][0], vlo[s1][1]); o1[1] = pack2bf(vlo[s1][2], vlo[s1][3]);
-                    o1[2] = pack2bf(vhi[s1][0], vhi[s1][1]); o1[3] = pack2bf(vhi[s1][2], vhi[s1][3]);
+                    o0[0] = pack2h<F16>(vlo[s0][0], vlo[s0][1]); o0[1] = pack2h<F16>(vlo[s0][2], vlo[s0][3]);
+                    o0[2] = pack2h<F16>(vhi[s0][0], vhi[s0][1]); o0[3] = pack2h<F16>(vhi[s0][2], vhi[s0][3]);
+                    o1[0] = pack2h<F16>(vlo[s1][0], vlo[s1][1]); o1[1] = pack2h<F16>(vlo[s1][2], vlo[s1][3]);
+                    o1[2] = pack2h<F16>(vhi[s1][0], vhi[s1][1]); o1[3] = pack2h<F16>(vhi[s1][2], vhi[s1][3]);
                     half_line_swap(o0, o1, lo8);
                     if (p.nt) {
                         if (inA) __builtin_nontemporal_store(o0, (u32x4*)((bf16_t*)p.out_bf16 + idxA));
@@ -721,7 +735,7 @@ static_assert(EF >= 0, "the 16x16x32 kernels are launched with compile-time epil
 // conditions): the flag tests fold away.  Run-time flags (EF = -1) cost ~1500 cycles of branches per epilogue step --
 // 24k cycles per 256x256 tile, more than half of a K = 768 main loop.
 // (the body is shared by the one-problem kernel and the grouped one: b = this block's index among the nb blocks of problem p)
-template <bool ATR, bool BTR, bool BIG, int EF, bool M16 = false>
+template <bool ATR, bool BTR, bool BIG, int EF, bool M16 = false, bool F16 = false>
 __device__ __forceinline__ void gemm_bf16_body(const GemmP& p, const int b_, const int nb_) {
     static_assert(!M16 || (BIG && !ATR && !BTR), "the 16x16x32 main loop exists for the 256x256 NT tile");
     typedef GCfg<BIG> C;
@@ -737,7 +751,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmP& p, const int b_, con
     // (blocks of one slice share A and B, different slices share nothing), and inside a slice groups of GM row tiles x
     // all column tiles, column-major inside a group (GM small: see hs_gemm).  Placement only affects speed, never results.
     int tm, tn, z;
-    tile_order(b_, nb_, p.tiles_m, p.tiles_n, tm, tn, z, p.gm);
+    tile_order(b_, nb_, p.tiles_m, p.tiles_n, tm, tn, z, p.gm, p.np);
     const int m0 = tm * 256, n0 = tn * C::BN;
     const int bz = p.split_k > 1 ? 0 : z;
     const bf16_t* A = (const bf16_t*)p.A + bz * p.sA;
@@ -797,9 +811,9 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmP& p, const int b_, con
     if (HS_DBG(p.dbg_) == 22 && threadIdx.x == 0 && blockIdx.x < 4096)
         g_gemm_trace[blockIdx.x * 4 + 3] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
     if constexpr (M16) {
-        big_mainloop16(acc16, smem, row0, col0, wave, lane, rsA, rsB, va, vb, ka, kb, kt0, kt1);
+        big_mainloop16<F16>(acc16, smem, row0, col0, wave, lane, rsA, rsB, va, vb, ka, kb, kt0, kt1);
     } else if constexpr (BIG) {
-        big_mainloop<BTR>(acc, smem, row0, col0, wave, lane, rsA, rsB, va, vb, ka, kb, kt0, kt1, HS_DBG(p.dbg_));
+        big_mainloop<BTR, F16>(acc, smem, row0, col0, wave, lane, rsA, rsB, va, vb, ka, kb, kt0, kt1, HS_DBG(p.dbg_));
     } else {
     // ring: prefetch distance D = NSTAGE-1 tiles.  At step kt: wait until tile kt has landed (D-1 newer tiles may stay
     // in flight: counted vmcnt), barrier, then issue tile kt+D into the stage every wave finished reading before
@@ -828,7 +842,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmP& p, const int b_, con
             for (int j = 0; j < C::PB; ++j) vb[j] = dma_voff<BTR>(j, n0, p.N, ktn * 64, p.K, p.ldb, wave, lane);
             sa = sb = 0;
         }
-        ktile_step<ATR, BTR, BIG>(acc, a_l, b_l, nxt, row0, col0, wave, lane, rsA, rsB, va, vb, sa, sb, issue);
+        ktile_step<ATR, BTR, BIG, F16>(acc, a_l, b_l, nxt, row0, col0, wave, lane, rsA, rsB, va, vb, sa, sb, issue);
         st = (D == 2) ? (st == 2 ? 0 : st + 1) : (st ^ 1);
     }
     }
@@ -847,7 +861,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmP& p, const int b_, con
         return;
     }
     if constexpr (M16) {
-        epilogue16<EF>(p, acc16, m0 + row0, n0 + col0, cz, lane);
+        epilogue16<EF, 4, 0, F16>(p, acc16, m0 + row0, n0 + col0, cz, lane);
         STAMP(4);
         TRACE(2);
         return;
@@ -916,8 +930,8 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmP& p, const int b_, con
                         const int row = (g * GS + i) * 8 + r8;
                         const f32x4 a = *(const f32x4*)(my + row * G_EPI_LD + c8), b = *(const f32x4*)(my + row * G_EPI_LD + c8 + 4);
                         u32x2 k0 = {0u, 0u}, k1 = {0u, 0u};
-                        vlo[i] = epi_math(p, flags, mw + row, a, vlo[i], u32x2{zb[i][0], zb[i][1]}, bias_lo, alpha_n, &k0);
-                        vhi[i] = epi_math(p, flags, mw + row, b, vhi[i], u32x2{zb[i][2], zb[i][3]}, bias_hi, alpha_n, &k1);
+                        vlo[i] = epi_math<F16>(p, flags, mw + row, a, vlo[i], u32x2{zb[i][0], zb[i][1]}, bias_lo, alpha_n, &k0);
+                        vhi[i] = epi_math<F16>(p, flags, mw + row, b, vhi[i], u32x2{zb[i][2], zb[i][3]}, bias_hi, alpha_n, &k1);
                         zb[i] = u32x4{k0[0], k0[1], k1[0], k1[1]};
                         if (in[i]) { cs_lo += vlo[i]; cs_hi += vhi[i]; }
                     }
@@ -926,8 +940,8 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmP& p, const int b_, con
                         if (in[i] && (HS_DBG(p.dbg_) == 3 || HS_DBG(p.dbg_) == 7)) { keep4(vlo[i]); keep4(vhi[i]); }
                         else if (in[i]) {
                             u32x4 o;
-                            o[0] = pack2bf(vlo[i][0], vlo[i][1]); o[1] = pack2bf(vlo[i][2], vlo[i][3]);
-                            o[2] = pack2bf(vhi[i][0], vhi[i][1]); o[3] = pack2bf(vhi[i][2], vhi[i][3]);
+                            o[0] = pack2h<F16>(vlo[i][0], vlo[i][1]); o[1] = pack2h<F16>(vlo[i][2], vlo[i][3]);
+                            o[2] = pack2h<F16>(vhi[i][0], vhi[i][1]); o[3] = pack2h<F16>(vhi[i][2], vhi[i][3]);
                             if (p.nt) {
                                 if ((flags & HS_EPI_GELU) && p.aux_out) __builtin_nontemporal_store(zb[i], (u32x4*)((bf16_t*)p.aux_out + idx[i]));
                                 if (p.out_f32) { __builtin_nontemporal_store(vlo[i], (f32x4*)(p.out_f32 + idx[i])); __builtin_nontemporal_store(vhi[i], (f32x4*)(p.out_f32 + idx[i] + 4)); }
@@ -988,13 +1002,13 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmP& p, const int b_, con
                         const int row = (g * 8 + i) * 4 + rr;
                         const f32x4 v = *(const f32x4*)(my + row * G_EPI_LD + cc);
                         u32x2 keep = {0u, 0u};
-                        val[i] = epi_math(p, flags, mw + row, v, val[i], zbv[i], bias_n, alpha_n, &keep);
+                        val[i] = epi_math<F16>(p, flags, mw + row, v, val[i], zbv[i], bias_n, alpha_n, &keep);
                         zbv[i] = keep;
                         if (in[i]) csum += val[i];
                     }
 #pragma clang loop unroll(full)
                     for (int i = 0; i < 8; ++i)
-                        if (in[i]) epi_store(p, idx[i], val[i], zbv[i]);
+                        if (in[i]) epi_store<F16>(p, idx[i], val[i], zbv[i]);
                 }
             } else {   // rare path (N or ldc not a multiple of 4): element-wise, rolled
 #pragma unroll 1
@@ -1002,7 +1016,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmP& p, const int b_, con
                     const int row = step * 4 + rr;
                     const f32x4 v = *(const f32x4*)(my + row * G_EPI_LD + cc);
 #pragma unroll 1
-                    for (int e = 0; e < 4; ++e) epilogue_store<false>(p, cz, mw + row, nw + cc + e, v[e]);
+                    for (int e = 0; e < 4; ++e) epilogue_store<false, F16>(p, cz, mw + row, nw + cc + e, v[e]);
                 }
             }
             if (p.colsum) {   // fused bias gradient: column sums of this wave's 64x64 piece, one atomic per column
@@ -1027,9 +1041,9 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmP& p, const int b_, con
     TRACE(2);
 }
 
-template <bool ATR, bool BTR, bool BIG, int EF, bool M16 = false>
+template <bool ATR, bool BTR, bool BIG, int EF, bool M16 = false, bool F16 = false>
 __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmP p) {
-    gemm_bf16_body<ATR, BTR, BIG, EF, M16>(p, blockIdx.x, gridDim.x);
+    gemm_bf16_body<ATR, BTR, BIG, EF, M16, F16>(p, blockIdx.x, gridDim.x);
 }
 
 // Grouped launch: up to HS_GEMM_GROUP_MAX problems of one kernel variant in ONE grid (hs_gemm_group: the four weight-gradient
@@ -1161,10 +1175,12 @@ struct GemmEnv {
     bool no_nt, no_m16;
     char tile;      // 0, 'b' (big) or 's' (small)
     int gm;         // 0, or the tile order's group height
+    int np;         // 0, or the tile order's panel width (column tiles)
     GemmEnv() : no_nt(getenv("HS_GEMM_NO_NT") != nullptr), no_m16(getenv("HS_GEMM_NO_M16") != nullptr), tile(0) {
         const char* t = getenv("HS_GEMM_TILE");
         if (t && (t[0] == 'b' || t[0] == 's')) tile = t[0];
         gm = getenv("HS_GEMM_GM") ? atoi(getenv("HS_GEMM_GM")) : 0;
+        np = getenv("HS_GEMM_NP") ? atoi(getenv("HS_GEMM_NP")) : 0;
     }
 };
 const GemmEnv kEnv;
@@ -1192,6 +1208,7 @@ extern "C" int hs_gemm_group(const hs_gemm_args* args, int count, void* stream) 
         p.tiles_m = (a->M + 255) / 256;
         p.tiles_n = (a->N + 127) / 128;
         p.gm = kEnv.gm > 0 ? kEnv.gm : (p.tiles_n >= 8 ? 4 : 2);
+        p.np = 0;
         p.nblocks = p.tiles_m * p.tiles_n * a->split_k;
         g.first[i] = nblocks;
         nblocks += (p.nblocks + 7) & ~7;
@@ -1214,10 +1231,13 @@ extern "C" int hs_gemm(const hs_gemm_args* a, int prec, void* stream) {
     if ((a->flags & HS_EPI_RESID) && !a->resid) return HS_ERR_ARG;
     if ((a->flags & HS_EPI_GELU_BWD) && !a->aux) return HS_ERR_ARG;
     if (a->split_k > 1 && (!(a->flags & HS_EPI_ATOMIC) || a->batch != 1 || !a->out_f32 || a->out_bf16)) return HS_ERR_SHAPE;
-    if (prec != HS_PREC_BF16 && prec != HS_PREC_F32) return HS_ERR_ARG;
+    if (prec != HS_PREC_BF16 && prec != HS_PREC_F32 && prec != HS_PREC_F16) return HS_ERR_ARG;
+    // fp16 operands: the forward GEMMs only (NT, no gradient epilogues, nothing saved for a backward pass)
+    const bool h16 = prec == HS_PREC_F16;
+    if (h16 && (a->layout != HS_GEMM_NT || (a->flags & (HS_EPI_GELU_BWD | HS_EPI_ATOMIC)) || a->colsum_out || a->aux_out || a->split_k != 1)) return HS_ERR_ARG;
     if (a->scale_cols < 0 || (a->scale_cols & 3) || (a->scale_cols && (a->flags & HS_EPI_ATOMIC))) return HS_ERR_SHAPE;
     if (a->colsum_out && (prec != HS_PREC_BF16 || (a->N & 3) || (a->ldc & 3) || a->batch != 1 || (a->flags & HS_EPI_ATOMIC))) return HS_ERR_SHAPE;
-    const int esz = prec == HS_PREC_BF16 ? 2 : 4;
+    const int esz = prec == HS_PREC_F32 ? 4 : 2;
     const int vec = 16 / esz;  // elements per 16-B chunk
     const bool atr = a->layout == HS_GEMM_TN, btr = a->layout != HS_GEMM_NT;
     // 16-B chunk granularity along the contiguous axis of each operand
@@ -1234,6 +1254,7 @@ extern "C" int hs_gemm(const hs_gemm_args* a, int prec, void* stream) {
     p.scale_cols = a->scale_cols; p.scale_alpha = a->scale_cols_alpha;
     p.dbg_ = HS_DBG(g_hs_dbg[3]);
     p.gm = 0;
+    p.np = 0;
     // Output stores of a GEMM whose result cannot stay in the caches anyway are issued as streaming (nontemporal) stores:
     // ordinary stores park 128 KiB of dirty lines per tile in the XCD's 4-MiB L2 -- 32 tiles per round = the whole L2 --
     // evicting the operand panels the other blocks are about to hit (measured on the 81940-row ViT-B shapes: main-loop vmcnt
@@ -1246,7 +1267,7 @@ extern "C" int hs_gemm(const hs_gemm_args* a, int prec, void* stream) {
     const int zdim = a->split_k > 1 ? a->split_k : a->batch;
     const double mnk = (double)a->M * a->N * a->K * a->batch;
     const double prof_bytes = ((double)a->M * a->K + (double)a->N * a->K) * a->batch * esz + (double)a->M * a->N * a->batch * (a->out_f32 ? 4 : 2);
-    if (prec == HS_PREC_BF16) {
+    if (prec != HS_PREC_F32) {
         // tile choice: the 256x256 tile does twice the MFMA work per barrier / DMA piece / LDS read.  Measured on the layer's shapes
         // at 1-4 volumes (4097-16388 rows): it wins by 4-28 % as soon as the 256x128 tile would need a second round of the chip's CUs
         // (more than ncu/2 big tiles), and loses by 30-37 % below that (one round of half-size tiles)
@@ -1261,6 +1282,7 @@ extern "C" int hs_gemm(const hs_gemm_args* a, int prec, void* stream) {
         // the N = 768 / K = 3072 shapes re-read their 1.5-MiB A panels (measured, tools/gm_sweep.sh at M = 81940: fc2 417 -> 380 us,
         // dgrad fc1 446 -> 420, dgrad qkv 327 -> 315, fc2+resid 491 -> 460 with 2 instead of 16; 9-12 column tiles: 2..8 within noise)
         p.gm = kEnv.gm > 0 ? kEnv.gm : (p.tiles_n >= 8 ? 4 : 2);
+        p.np = kEnv.np;
         dim3 grid(p.tiles_m * p.tiles_n * zdim, 1, 1);
         // epilogue specialisations (compile-time flags); anything else runs the generic kernel (EF = -1)
         const bool col8 = !(a->N & 7) && !(a->ldc & 7) && !(a->scale_cols & 7);
@@ -1270,8 +1292,19 @@ extern "C" int hs_gemm(const hs_gemm_args* a, int prec, void* stream) {
         if (big) hipLaunchKernelGGL((gemm_bf16_kernel<ATR, BTR, true, EF>), grid, dim3(512), 0, s, p);                \
         else hipLaunchKernelGGL((gemm_bf16_kernel<ATR, BTR, false, EF>), grid, dim3(512), 0, s, p);                   \
     } while (0)
+        // the NT kernels again with fp16 operand packs and the fp16 MFMA opcode (HS_PREC_F16)
+#define HS_LAUNCH_E_NT(EF)                                                                                           \
+    do {                                                                                                             \
+        if (!h16) HS_LAUNCH_E(false, false, EF);                                                                     \
+        else if (big) hipLaunchKernelGGL((gemm_bf16_kernel<false, false, true, EF, false, true>), grid, dim3(512), 0, s, p);   \
+        else hipLaunchKernelGGL((gemm_bf16_kernel<false, false, false, EF, false, true>), grid, dim3(512), 0, s, p); \
+    } while (0)
         const bool m16 = big && a->layout == HS_GEMM_NT && (!a->colsum_out || a->flags == (HS_EPI_GELU_BWD | HS_EPI_SAVE_DGELU)) && !kEnv.no_m16;
-#define HS_LAUNCH_M16(EF) hipLaunchKernelGGL((gemm_bf16_kernel<false, false, true, EF, true>), grid, dim3(512), 0, s, p)
+#define HS_LAUNCH_M16(EF)                                                                                            \
+    do {                                                                                                             \
+        if (h16) hipLaunchKernelGGL((gemm_bf16_kernel<false, false, true, EF, true, true>), grid, dim3(512), 0, s, p); \
+        else hipLaunchKernelGGL((gemm_bf16_kernel<false, false, true, EF, true>), grid, dim3(512), 0, s, p);          \
+    } while (0)
         p.nblocks = (int)grid.x;
         const bool m16_ok = m16 && col8 && (f == 0 || f == HS_EPI_BIAS || f == (HS_EPI_BIAS | HS_EPI_RESID) || f == (HS_EPI_BIAS | HS_EPI_GELU | HS_EPI_SAVE_DGELU) ||
                                             (f == (HS_EPI_GELU_BWD | HS_EPI_SAVE_DGELU) && !(((uintptr_t)a->aux) & 15)));
@@ -1286,14 +1319,14 @@ extern "C" int hs_gemm(const hs_gemm_args* a, int prec, void* stream) {
             if (f == 0) HS_LAUNCH_M16(0);
             else if (f == HS_EPI_BIAS) HS_LAUNCH_M16(HS_EPI_BIAS);        // patch embedding, scorer / packer projections (fp32 out)
             else if (f == (HS_EPI_BIAS | HS_EPI_RESID)) HS_LAUNCH_M16(HS_EPI_BIAS | HS_EPI_RESID);
-            else if (f == (HS_EPI_GELU_BWD | HS_EPI_SAVE_DGELU)) HS_LAUNCH_M16(HS_EPI_GELU_BWD | HS_EPI_SAVE_DGELU);
+            else if (f == (HS_EPI_GELU_BWD | HS_EPI_SAVE_DGELU)) hipLaunchKernelGGL((gemm_bf16_kernel<false, false, true, HS_EPI_GELU_BWD | HS_EPI_SAVE_DGELU, true>), grid, dim3(512), 0, s, p);
             else HS_LAUNCH_M16(HS_EPI_BIAS | HS_EPI_GELU | HS_EPI_SAVE_DGELU);
         } else if (a->layout == HS_GEMM_NT) {
-            if (col8 && f == 0) HS_LAUNCH_E(false, false, 0);
-            else if (col8 && f == (HS_EPI_BIAS | HS_EPI_RESID)) HS_LAUNCH_E(false, false, HS_EPI_BIAS | HS_EPI_RESID);
-            else if (col8 && f == (HS_EPI_BIAS | HS_EPI_GELU | HS_EPI_SAVE_DGELU)) HS_LAUNCH_E(false, false, HS_EPI_BIAS | HS_EPI_GELU | HS_EPI_SAVE_DGELU);
+            if (col8 && f == 0) HS_LAUNCH_E_NT(0);
+            else if (col8 && f == (HS_EPI_BIAS | HS_EPI_RESID)) HS_LAUNCH_E_NT(HS_EPI_BIAS | HS_EPI_RESID);
+            else if (col8 && f == (HS_EPI_BIAS | HS_EPI_GELU | HS_EPI_SAVE_DGELU)) HS_LAUNCH_E_NT(HS_EPI_BIAS | HS_EPI_GELU | HS_EPI_SAVE_DGELU);
             else if (col8 && f == (HS_EPI_GELU_BWD | HS_EPI_SAVE_DGELU)) HS_LAUNCH_E(false, false, HS_EPI_GELU_BWD | HS_EPI_SAVE_DGELU);   // fc2's dgrad against W2^T at shapes too small for the 256x256 tile
-            else HS_LAUNCH_E(false, false, -1);
+            else HS_LAUNCH_E_NT(-1);
         } else if (a->layout == HS_GEMM_NN) {
             if (col8 && f == 0) HS_LAUNCH_E(false, true, 0);
             else if (col8 && f == (HS_EPI_GELU_BWD | HS_EPI_SAVE_DGELU)) HS_LAUNCH_E(false, true, HS_EPI_GELU_BWD | HS_EPI_SAVE_DGELU);
@@ -1303,6 +1336,7 @@ extern "C" int hs_gemm(const hs_gemm_args* a, int prec, void* stream) {
             else hipLaunchKernelGGL((gemm_bf16_kernel<true, true, false, -1>), grid, dim3(512), 0, s, p);
         }
 #undef HS_LAUNCH_E
+#undef HS_LAUNCH_E_NT
 #undef HS_LAUNCH_M16
     } else {
         ProfScope prof(HS_PROF_GEMM_NT + a->layout, stream, 2.0 * mnk, prof_bytes);

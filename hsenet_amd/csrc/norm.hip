@@ -8,6 +8,7 @@
 
 #define LN_MAXCH 4  // float4 chunks per lane -> d <= 1024
 
+template <bool F16>   // format of the 16-bit output: bf16, or fp16 (HS_PREC_F16 forward)
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ resid,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             float* __restrict__ y, bf16_t* __restrict__ yb,
@@ -62,8 +63,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
             if (y) *(f32x4*)(y + (long)row * d + ch * 4) = o;
             if (yb) {
                 u32x2 pk;
-                pk[0] = pack2bf(o[0], o[1]);
-                pk[1] = pack2bf(o[2], o[3]);
+                pk[0] = pack2h<F16>(o[0], o[1]);
+                pk[1] = pack2h<F16>(o[2], o[3]);
                 *(u32x2*)(yb + (long)row * d + ch * 4) = pk;
             }
         }
@@ -244,15 +245,22 @@ __global__ __launch_bounds__(WPB * 64, (NCH >= 4 && WPB == 4) ? 3 : 16 / WPB) vo
     }
 }
 
-extern "C" int hs_layernorm_fwd(const float* x, const float* resid, const float* gamma, const float* beta, float* y_f32,
-                                void* y_bf16, float* mean, float* rstd, int rows, int d, float eps, void* stream) {
-    if (!x || !gamma || !beta || (!y_f32 && !y_bf16)) return HS_ERR_ARG;
+// internal form (driver.h): f16 != 0 makes the 16-bit output IEEE fp16 instead of bf16
+int hs_layernorm_fwd16(const float* x, const float* resid, const float* gamma, const float* beta, float* y_f32, void* y_16, float* mean,
+                       float* rstd, int rows, int d, float eps, int f16, void* stream) {
+    if (!x || !gamma || !beta || (!y_f32 && !y_16)) return HS_ERR_ARG;
     if (rows < 1 || d < 4 || (d & 3) || d > LN_MAXCH * 256) return HS_ERR_SHAPE;
-    ProfScope prof(HS_PROF_LN_FWD, stream, 0, (double)rows * d * (4 + (resid ? 4 : 0) + (y_f32 ? 4 : 0) + (y_bf16 ? 2 : 0)));
-    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, resid, gamma, beta,
-                       y_f32, (bf16_t*)y_bf16, mean, rstd, rows, d, eps);
+    ProfScope prof(HS_PROF_LN_FWD, stream, 0, (double)rows * d * (4 + (resid ? 4 : 0) + (y_f32 ? 4 : 0) + (y_16 ? 2 : 0)));
+    if (f16) hipLaunchKernelGGL(layernorm_fwd_kernel<true>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, resid, gamma, beta,
+                                y_f32, (bf16_t*)y_16, mean, rstd, rows, d, eps);
+    else hipLaunchKernelGGL(layernorm_fwd_kernel<false>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, resid, gamma, beta,
+                            y_f32, (bf16_t*)y_16, mean, rstd, rows, d, eps);
     HS_CHECK_LAUNCH();
     return HS_OK;
+}
+extern "C" int hs_layernorm_fwd(const float* x, const float* resid, const float* gamma, const float* beta, float* y_f32,
+                                void* y_bf16, float* mean, float* rstd, int rows, int d, float eps, void* stream) {
+    return hs_layernorm_fwd16(x, resid, gamma, beta, y_f32, y_bf16, mean, rstd, rows, d, eps, 0, stream);
 }
 
 extern "C" int hs_layernorm_bwd(const void* dy, int dy_is_bf16, const float* x, const float* resid, const float* gamma,

@@ -7,7 +7,7 @@
 // Fast path (C == 1, p3 % 8 == 0): a lane reads 8 consecutive voxels along W (32 B), so a wave reads 2 KiB
 // contiguous, and writes them as 8 consecutive features of one patch row.
 // ------------------------------------------------------------------------------------------------------
-template <bool BF16>
+template <int FMT>   // HS_PREC_*: 0 bf16, 1 f32, 2 fp16
 __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ vol, void* __restrict__ out, int B, int D,
                                                        int H, int W, int p1, int p2, int p3) {
     const int W8 = W >> 3;
@@ -27,10 +27,11 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
     const f32x4 a = *(const f32x4*)(vol + g * 8);
     const f32x4 c = *(const f32x4*)(vol + g * 8 + 4);
     const long o = (b * Np + patch) * Pd + feat;
-    if (BF16) {
+    if (FMT != HS_PREC_F32) {
+        constexpr bool F16 = FMT == HS_PREC_F16;
         u32x4 pk;
-        pk[0] = pack2bf(a[0], a[1]); pk[1] = pack2bf(a[2], a[3]);
-        pk[2] = pack2bf(c[0], c[1]); pk[3] = pack2bf(c[2], c[3]);
+        pk[0] = pack2h<F16>(a[0], a[1]); pk[1] = pack2h<F16>(a[2], a[3]);
+        pk[2] = pack2h<F16>(c[0], c[1]); pk[3] = pack2h<F16>(c[2], c[3]);
         *(u32x4*)((bf16_t*)out + o) = pk;
     } else {
         *(f32x4*)((float*)out + o) = a;
@@ -38,7 +39,7 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
     }
 }
 // generic path: one element per thread (any C, any patch size)
-template <bool BF16>
+template <int FMT>
 __global__ __launch_bounds__(256) void patchify_generic_kernel(const float* __restrict__ vol, void* __restrict__ out, int B,
                                                                int C, int D, int H, int W, int p1, int p2, int p3) {
     const long total = (long)B * C * D * H * W;
@@ -56,26 +57,28 @@ __global__ __launch_bounds__(256) void patchify_generic_kernel(const float* __re
     const long patch = ((long)(dd / p1) * gh + hh / p2) * gw + ww / p3;
     const long feat = ((long)((dd % p1) * p2 + hh % p2) * p3 + (ww % p3)) * C + cc;
     const long o = (b * Np + patch) * Pd + feat;
-    if (BF16) ((bf16_t*)out)[o] = f2bf(vol[g]); else ((float*)out)[o] = vol[g];
+    if (FMT != HS_PREC_F32) ((bf16_t*)out)[o] = f2h<FMT == HS_PREC_F16>(vol[g]); else ((float*)out)[o] = vol[g];
 }
 
 extern "C" int hs_patchify(const float* vol, void* out, int B, int C, int D, int H, int W, int p1, int p2, int p3, int prec,
                            void* stream) {
     if (!vol || !out) return HS_ERR_ARG;
     if (B < 1 || C < 1 || p1 < 1 || p2 < 1 || p3 < 1 || D % p1 || H % p2 || W % p3) return HS_ERR_SHAPE;
-    if (prec != HS_PREC_BF16 && prec != HS_PREC_F32) return HS_ERR_ARG;
+    if (prec != HS_PREC_BF16 && prec != HS_PREC_F32 && prec != HS_PREC_F16) return HS_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    ProfScope prof(HS_PROF_PATCHIFY, stream, 0, (double)B * C * D * H * W * (prec == HS_PREC_BF16 ? 6 : 8));
+    ProfScope prof(HS_PROF_PATCHIFY, stream, 0, (double)B * C * D * H * W * (prec == HS_PREC_F32 ? 8 : 6));
     if (C == 1 && (p3 % 8) == 0 && !(((uintptr_t)vol | (uintptr_t)out) & 15)) {
         const long total = (long)B * D * H * (W / 8);
         dim3 grid((unsigned)((total + 255) / 256));
-        if (prec == HS_PREC_BF16) hipLaunchKernelGGL(patchify_kernel<true>, grid, dim3(256), 0, s, vol, out, B, D, H, W, p1, p2, p3);
-        else hipLaunchKernelGGL(patchify_kernel<false>, grid, dim3(256), 0, s, vol, out, B, D, H, W, p1, p2, p3);
+        if (prec == HS_PREC_BF16) hipLaunchKernelGGL(patchify_kernel<HS_PREC_BF16>, grid, dim3(256), 0, s, vol, out, B, D, H, W, p1, p2, p3);
+        else if (prec == HS_PREC_F16) hipLaunchKernelGGL(patchify_kernel<HS_PREC_F16>, grid, dim3(256), 0, s, vol, out, B, D, H, W, p1, p2, p3);
+        else hipLaunchKernelGGL(patchify_kernel<HS_PREC_F32>, grid, dim3(256), 0, s, vol, out, B, D, H, W, p1, p2, p3);
     } else {
         const long total = (long)B * C * D * H * W;
         dim3 grid((unsigned)((total + 255) / 256));
-        if (prec == HS_PREC_BF16) hipLaunchKernelGGL(patchify_generic_kernel<true>, grid, dim3(256), 0, s, vol, out, B, C, D, H, W, p1, p2, p3);
-        else hipLaunchKernelGGL(patchify_generic_kernel<false>, grid, dim3(256), 0, s, vol, out, B, C, D, H, W, p1, p2, p3);
+        if (prec == HS_PREC_BF16) hipLaunchKernelGGL(patchify_generic_kernel<HS_PREC_BF16>, grid, dim3(256), 0, s, vol, out, B, C, D, H, W, p1, p2, p3);
+        else if (prec == HS_PREC_F16) hipLaunchKernelGGL(patchify_generic_kernel<HS_PREC_F16>, grid, dim3(256), 0, s, vol, out, B, C, D, H, W, p1, p2, p3);
+        else hipLaunchKernelGGL(patchify_generic_kernel<HS_PREC_F32>, grid, dim3(256), 0, s, vol, out, B, C, D, H, W, p1, p2, p3);
     }
     HS_CHECK_LAUNCH();
     return HS_OK;
@@ -621,15 +624,16 @@ extern "C" int hs_colsum(const void* x, int is_bf16, float* out, int M, int N, i
     return HS_OK;
 }
 
+template <bool F16>
 __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, long n) {
     const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 8;
     if (i + 8 <= n) {
         const f32x4 a = *(const f32x4*)(x + i), c = *(const f32x4*)(x + i + 4);
         u32x4 pk;
-        pk[0] = pack2bf(a[0], a[1]); pk[1] = pack2bf(a[2], a[3]); pk[2] = pack2bf(c[0], c[1]); pk[3] = pack2bf(c[2], c[3]);
+        pk[0] = pack2h<F16>(a[0], a[1]); pk[1] = pack2h<F16>(a[2], a[3]); pk[2] = pack2h<F16>(c[0], c[1]); pk[3] = pack2h<F16>(c[2], c[3]);
         *(u32x4*)(y + i) = pk;
     } else {
-        for (long j = i; j < n; ++j) y[j] = f2bf(x[j]);
+        for (long j = i; j < n; ++j) y[j] = f2h<F16>(x[j]);
     }
 }
 __global__ __launch_bounds__(256) void cast_f32_kernel(const bf16_t* __restrict__ x, float* __restrict__ y, long n) {
@@ -651,13 +655,23 @@ extern "C" int hs_cast_bf16(const float* x, void* y, int64_t n, void* stream) {
     if (!x || !y) return HS_ERR_ARG;
     if (n < 1 || (((uintptr_t)x | (uintptr_t)y) & 15)) return HS_ERR_SHAPE;
     ProfScope prof(HS_PROF_CAST, stream, 0, (double)n * 6);
-    hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)((n + 2047) / 2048)), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)y, (long)n);
+    hipLaunchKernelGGL(cast_bf16_kernel<false>, dim3((unsigned)((n + 2047) / 2048)), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)y, (long)n);
+    HS_CHECK_LAUNCH();
+    return HS_OK;
+}
+// fp32 -> IEEE fp16, round to nearest even (the operand cast of HS_PREC_F16; = torch's .half())
+extern "C" int hs_cast_f16(const float* x, void* y, int64_t n, void* stream) {
+    if (!x || !y) return HS_ERR_ARG;
+    if (n < 1 || (((uintptr_t)x | (uintptr_t)y) & 15)) return HS_ERR_SHAPE;
+    ProfScope prof(HS_PROF_CAST, stream, 0, (double)n * 6);
+    hipLaunchKernelGGL(cast_bf16_kernel<true>, dim3((unsigned)((n + 2047) / 2048)), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)y, (long)n);
     HS_CHECK_LAUNCH();
     return HS_OK;
 }
 // up to 64 fp32 -> bf16 segments in ONE launch (the fused encoder driver re-casts 4 weight matrices per layer at the start of every
 // forward pass: 48 launches of ~7 us were 0.36 ms per step -- 3.5 % of a one-volume step).  Internal to the library (vit.hip).
 struct CastSegs { const float* src[64]; bf16_t* dst[64]; long n[64]; };
+template <bool F16>
 __global__ __launch_bounds__(256) void cast_bf16_multi_kernel(CastSegs g) {
     const int sgm = blockIdx.y;
     const float* __restrict__ x = g.src[sgm];
@@ -667,14 +681,14 @@ __global__ __launch_bounds__(256) void cast_bf16_multi_kernel(CastSegs g) {
         if (i + 8 <= n) {
             const f32x4 a = *(const f32x4*)(x + i), c = *(const f32x4*)(x + i + 4);
             u32x4 pk;
-            pk[0] = pack2bf(a[0], a[1]); pk[1] = pack2bf(a[2], a[3]); pk[2] = pack2bf(c[0], c[1]); pk[3] = pack2bf(c[2], c[3]);
+            pk[0] = pack2h<F16>(a[0], a[1]); pk[1] = pack2h<F16>(a[2], a[3]); pk[2] = pack2h<F16>(c[0], c[1]); pk[3] = pack2h<F16>(c[2], c[3]);
             *(u32x4*)(y + i) = pk;
         } else {
-            for (long j = i; j < n; ++j) y[j] = f2bf(x[j]);
+            for (long j = i; j < n; ++j) y[j] = f2h<F16>(x[j]);
         }
     }
 }
-int hs_cast_bf16_multi(const float* const* src, void* const* dst, const int64_t* n, int count, void* stream) {
+int hs_cast_bf16_multi(const float* const* src, void* const* dst, const int64_t* n, int count, void* stream, int f16) {
     if (!src || !dst || !n || count < 1) return HS_ERR_ARG;
     for (int c0 = 0; c0 < count; c0 += 64) {
         CastSegs g;
@@ -691,7 +705,8 @@ int hs_cast_bf16_multi(const float* const* src, void* const* dst, const int64_t*
         long bx = (nmax + 2047) / 2048;
         if (bx > 512) bx = 512;                       // grid-stride: 512 x cnt blocks already saturate the memory system
         ProfScope prof(HS_PROF_CAST, stream, 0, bytes);
-        hipLaunchKernelGGL(cast_bf16_multi_kernel, dim3((unsigned)bx, (unsigned)cnt), dim3(256), 0, (hipStream_t)stream, g);
+        if (f16) hipLaunchKernelGGL(cast_bf16_multi_kernel<true>, dim3((unsigned)bx, (unsigned)cnt), dim3(256), 0, (hipStream_t)stream, g);
+        else hipLaunchKernelGGL(cast_bf16_multi_kernel<false>, dim3((unsigned)bx, (unsigned)cnt), dim3(256), 0, (hipStream_t)stream, g);
         HS_CHECK_LAUNCH();
     }
     return HS_OK;

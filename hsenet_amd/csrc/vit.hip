@@ -37,11 +37,11 @@ Layout make_layout(const hs_vit_desc& c) {
     Layout L;
     const size_t M = (size_t)c.B * c.N, d = c.d, mlp = c.mlp;
     const size_t Ls = c.save_for_bwd ? c.L : 1;
-    const size_t es = c.prec == HS_PREC_BF16 ? 2 : 4;
+    const size_t es = c.prec == HS_PREC_F32 ? 4 : 2;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += al256(bytes); return o; };
     L.per_w = 3 * d * d + d * d + mlp * d + d * mlp;
-    L.wbf = take(c.prec == HS_PREC_BF16 ? (size_t)c.L * L.per_w * 2 : 0);
+    L.wbf = take(c.prec != HS_PREC_F32 ? (size_t)c.L * L.per_w * 2 : 0);      // 16-bit (bf16 / fp16) weight copies
     // TRANSPOSED bf16 weight copies for the backward pass' dgrads (see dgrad_nt below): same per-layer order [Wqkv^T | Wo^T | W1^T | W2^T]
     L.wbft = take(c.prec == HS_PREC_BF16 && c.save_for_bwd && dgrad_nt(c) ? (size_t)c.L * L.per_w * 2 : 0);
     L.xmid = take(Ls * M * d * 4);
@@ -75,7 +75,8 @@ int check_desc(const hs_vit_desc* c) {
     if (c->B < 1 || c->N < 1 || c->L < 1 || c->H < 1) return HS_ERR_SHAPE;
     if (c->d != c->H * 64) return HS_ERR_SHAPE;  // attention kernels are specialised for head_dim 64
     if ((c->d & 7) || (c->mlp & 7) || c->d > 1024) return HS_ERR_SHAPE;
-    if (c->prec != HS_PREC_BF16 && c->prec != HS_PREC_F32) return HS_ERR_ARG;
+    if (c->prec != HS_PREC_BF16 && c->prec != HS_PREC_F32 && c->prec != HS_PREC_F16) return HS_ERR_ARG;
+    if (c->prec == HS_PREC_F16 && c->save_for_bwd) return HS_ERR_ARG;    // fp16 operands: forward only
     if (c->ln_eps < 0.f) return HS_ERR_ARG;
     if (c->qkv_bias && c->save_for_bwd) return HS_ERR_ARG;          // the biased projection is forward-only
     return HS_OK;
@@ -103,7 +104,8 @@ extern "C" int hs_vit_blocks_fwd(const hs_vit_desc* desc, const float* x0, const
     char* w = (char*)ws;
     const int M = c.B * c.N, d = c.d, mlp = c.mlp;
     const size_t Md = (size_t)M * d;
-    const bool bf = c.prec == HS_PREC_BF16;
+    const bool bf = c.prec != HS_PREC_F32;          // 16-bit operands: bf16, or fp16 (HS_PREC_F16, forward only)
+    const int f16 = c.prec == HS_PREC_F16;
     const size_t es = bf ? 2 : 4;
     const float eps = c.ln_eps > 0.f ? c.ln_eps : 1e-5f;
 
@@ -119,7 +121,7 @@ extern "C" int hs_vit_blocks_fwd(const hs_vit_desc* desc, const float* x0, const
             src.push_back(p[P_W1]); dst.push_back(wl + 4 * d * d); cnt.push_back((int64_t)mlp * d);
             src.push_back(p[P_W2]); dst.push_back(wl + 4 * d * d + (size_t)mlp * d); cnt.push_back((int64_t)d * mlp);
         }
-        RC(hs_cast_bf16_multi(src.data(), dst.data(), cnt.data(), (int)src.size(), stream));
+        RC(hs_cast_bf16_multi(src.data(), dst.data(), cnt.data(), (int)src.size(), stream, f16));
     }
     for (int l = 0; l < c.L; ++l) {
         const size_t ls = c.save_for_bwd ? l : 0;
@@ -142,7 +144,7 @@ extern "C" int hs_vit_blocks_fwd(const hs_vit_desc* desc, const float* x0, const
         } else {
             wqkv = p[P_WQKV]; wo = p[P_WO]; w1 = p[P_W1]; w2 = p[P_W2];
         }
-        RC(hs_layernorm_fwd(xin, nullptr, p[P_N1W], p[P_N1B], bf ? nullptr : (float*)h1, bf ? h1 : nullptr, st, st + M, M, d, eps, stream));
+        RC(hs_layernorm_fwd16(xin, nullptr, p[P_N1W], p[P_N1B], bf ? nullptr : (float*)h1, bf ? h1 : nullptr, st, st + M, M, d, eps, f16, stream));
         // bf16: the q third leaves the projection already multiplied by dh^-0.5 * log2(e) (one rounding), which is what the
         // attention kernels' exp2-based softmax consumes (HS_ATTN_Q_PRESCALED); the f32 parity path keeps raw q
         const float* qbias = nullptr;
@@ -159,7 +161,7 @@ extern "C" int hs_vit_blocks_fwd(const hs_vit_desc* desc, const float* x0, const
                 nullptr, nullptr, qbias ? HS_EPI_BIAS : 0, 1, stream, nullptr, bf ? d : 0, kQScale));
         RC(hs_attn_fwd(qkv, o, lse, c.B, c.N, c.H, 64, c.prec, bf ? HS_ATTN_Q_PRESCALED : 0, stream));
         RC(gemm(c.prec, HS_GEMM_NT, o, wo, M, d, d, d, d, xmid, nullptr, d, p[P_BO], xin, nullptr, nullptr, HS_EPI_BIAS | HS_EPI_RESID, 1, stream));
-        RC(hs_layernorm_fwd(xmid, nullptr, p[P_N2W], p[P_N2B], bf ? nullptr : (float*)h2, bf ? h2 : nullptr, st + 2 * M, st + 3 * M, M, d, eps, stream));
+        RC(hs_layernorm_fwd16(xmid, nullptr, p[P_N2W], p[P_N2B], bf ? nullptr : (float*)h2, bf ? h2 : nullptr, st + 2 * M, st + 3 * M, M, d, eps, f16, stream));
         RC(gemm(c.prec, HS_GEMM_NT, h2, w1, M, mlp, d, d, d, bf ? nullptr : (float*)a, bf ? a : nullptr, mlp, p[P_B1], nullptr, nullptr,
                 c.save_for_bwd ? z : nullptr, HS_EPI_BIAS | HS_EPI_GELU | HS_EPI_SAVE_DGELU, 1, stream));
         RC(gemm(c.prec, HS_GEMM_NT, a, w2, M, d, mlp, mlp, mlp, xout, nullptr, d, p[P_B2], xmid, nullptr, nullptr, HS_EPI_BIAS | HS_EPI_RESID, 1, stream));
@@ -267,7 +269,8 @@ extern "C" int hs_vit_blocks_bwd(const hs_vit_desc* desc, const float* x0, const
             RC(hs_layernorm_bwd(dh, 1, xin, nullptr, p[P_N1W], st, st + M, dx, dxo, l == 0 ? nullptr : dx_out, g[P_N1W], g[P_N1B], b2_below, M, d, stream));
             // ---- dW2 = dx'^T a, dW1 = dz^T h2, dWqkv = dqkv^T h1, dWo = dxm^T o (largest first)
             const int mn[4][2] = {{d, mlp}, {mlp, d}, {3 * d, d}, {d, d}};
-            const int split = wgrad_group_split(mn, 4, M);
+            static const int split_env = getenv("HS_WGRAD_GROUP_SPLIT") ? atoi(getenv("HS_WGRAD_GROUP_SPLIT")) : 0;   // (A/B runs)
+            const int split = split_env > 0 ? split_env : wgrad_group_split(mn, 4, M);
             hs_gemm_args wg[4] = {};
             const void* dys[4] = {dx_in, dz, dqkv, dx_mid};
             const void* xs[4] = {a, h2, h1, o};

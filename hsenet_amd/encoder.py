@@ -24,12 +24,12 @@ import torch
 import torch.nn as nn
 
 from . import functional as Fn
-from ._lib import PREC_BF16, PREC_F32
+from ._lib import PREC_BF16, PREC_F16, PREC_F32
 
 
 def _prec(module) -> int:
     p = getattr(module, "precision", None) or Fn.get_precision()
-    return {"bf16": PREC_BF16, "f32": PREC_F32}[p]
+    return {"bf16": PREC_BF16, "f32": PREC_F32, "f16": PREC_F16}[p]
 
 
 class _Rearrange(nn.Module):

@@ -12,13 +12,16 @@ import torch
 
 from . import _lib as L
 
-_PREC = {"bf16": L.PREC_BF16, "f32": L.PREC_F32}
+_PREC = {"bf16": L.PREC_BF16, "f32": L.PREC_F32, "f16": L.PREC_F16}
+_DT16 = {L.PREC_BF16: torch.bfloat16, L.PREC_F16: torch.float16}
 _default_precision = "bf16"
 
 
 def set_precision(p: str) -> None:
     """'bf16' (default; the reference's autocast policy: bf16 MFMA inputs, fp32 accumulate/residual) or
-    'f32' (exact-f32 MFMA parity mode: forward and backward, no bf16 rounding anywhere)."""
+    'f32' (exact-f32 MFMA parity mode: forward and backward, no bf16 rounding anywhere), or 'f16' (FORWARD ONLY: the same kernels with
+    fp16 operand packs -- the reference's eval / generation scripts run under torch.cuda.amp.autocast(), default dtype fp16,
+    Bench/eval/eval_HSENet_CT_Rate_MRG.py:383,423; a backward pass through an fp16-mode forward raises)."""
     global _default_precision
     if p not in _PREC:
         raise ValueError(f"precision must be one of {list(_PREC)}")
@@ -69,7 +72,7 @@ def gemm(A: torch.Tensor, Bm: torch.Tensor, layout: int, *, prec: int, out_f32: 
          alpha: float = 1.0, flags: int = 0, split_k: int = 1, scale_cols: int = 0, scale_cols_alpha: float = 1.0) -> None:
     """C[M,N] = sum_k A(m,k) B(n,k); 2-D or batched 3-D operands (see include/hsenet_hip.h)."""
     _need(A, Bm, out_f32, out_bf16, bias, resid, aux, aux_out, colsum_out)
-    want = torch.bfloat16 if prec == L.PREC_BF16 else torch.float32
+    want = _DT16.get(prec, torch.float32)
     if A.dtype != want or Bm.dtype != want:
         raise L.HsError(f"gemm operands must be {want}")
     batch = A.shape[0] if A.dim() == 3 else 1
@@ -124,6 +127,22 @@ def cast_bf16(x: torch.Tensor) -> torch.Tensor:
     return y
 
 
+def cast16(x: torch.Tensor, prec: int) -> torch.Tensor:
+    """fp32 -> the 16-bit operand format of `prec` (bf16 / fp16), round to nearest even."""
+    if prec == L.PREC_BF16:
+        return cast_bf16(x)
+    _need(x)
+    y = torch.empty(x.shape, dtype=torch.float16, device=x.device)
+    L.call("hs_cast_f16", x.data_ptr(), y.data_ptr(), x.numel(), _s())
+    return y
+
+
+def _forward_only(prec: int) -> None:
+    if prec == L.PREC_F16:
+        raise L.HsError("precision 'f16' is forward-only (the reference uses fp16 autocast in its eval / generation scripts only): "
+                        "run it under torch.no_grad(), train in 'bf16'")
+
+
 def cast_f32(x: torch.Tensor) -> torch.Tensor:
     _need(x)
     y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
@@ -152,6 +171,8 @@ def _wgrad_split(Mo: int, No: int, K: int, tile=(256, 128), kt: int = 64) -> int
 def attn_fwd(qkv: torch.Tensor, H: int, prec: int, q_prescaled: bool = False):
     """qkv [B,N,3*H*64] -> (o [B,N,H*64], lse [B,H,N]).  q_prescaled: the q third already carries dh^-0.5*log2(e)."""
     _need(qkv)
+    if qkv.dtype != _DT16.get(prec, torch.float32):
+        raise L.HsError(f"attn_fwd: qkv must be {_DT16.get(prec, torch.float32)} at this precision, got {qkv.dtype}")
     B, N, D3 = qkv.shape
     o = torch.empty(B, N, D3 // 3, dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty(B, H, N, dtype=torch.float32, device=qkv.device)
@@ -230,8 +251,8 @@ class LinearFn(torch.autograd.Function):
         K, N = x.shape[-1], weight.shape[0]
         x2 = x.view(-1, K)
         y = torch.empty(x2.shape[0], N, dtype=torch.float32, device=x.device)
-        if prec == L.PREC_BF16:
-            xa, wa = cast_bf16(x2), cast_bf16(weight)
+        if prec != L.PREC_F32:
+            xa, wa = cast16(x2, prec), cast16(weight, prec)
         else:
             xa, wa = x2, weight.contiguous()
         gemm(xa, wa, L.GEMM_NT, prec=prec, out_f32=y, bias=bias, flags=L.EPI_BIAS if bias is not None else 0)
@@ -243,6 +264,7 @@ class LinearFn(torch.autograd.Function):
     def backward(ctx, dy):
         xa, wa = ctx.saved_tensors
         prec = ctx.prec
+        _forward_only(prec)
         dy2 = _f32(dy).contiguous().view(-1, wa.shape[0])
         dya = cast_bf16(dy2) if prec == L.PREC_BF16 else dy2
         M, N, K = xa.shape[0], wa.shape[0], wa.shape[1]
@@ -341,10 +363,10 @@ class PatchEmbedFn(torch.autograd.Function):
         B, Cc, D, H, W = vol.shape
         p1, p2, p3 = patch_size
         Np, Pd, d = (D // p1) * (H // p2) * (W // p3), Cc * p1 * p2 * p3, weight.shape[0]
-        dt = torch.bfloat16 if prec == L.PREC_BF16 else torch.float32
+        dt = _DT16.get(prec, torch.float32)
         patches = torch.empty(B * Np, Pd, dtype=dt, device=vol.device)
         L.call("hs_patchify", vol.data_ptr(), patches.data_ptr(), B, Cc, D, H, W, p1, p2, p3, prec, _s())
-        wa = cast_bf16(weight) if prec == L.PREC_BF16 else weight.contiguous()
+        wa = cast16(weight, prec) if prec != L.PREC_F32 else weight.contiguous()
         y = torch.empty(B * Np, d, dtype=torch.float32, device=vol.device)
         gemm(patches, wa, L.GEMM_NT, prec=prec, out_f32=y, bias=bias, flags=L.EPI_BIAS)
         ctx.save_for_backward(patches)
@@ -355,6 +377,7 @@ class PatchEmbedFn(torch.autograd.Function):
     def backward(ctx, dy):
         (patches,) = ctx.saved_tensors
         prec = ctx.prec
+        _forward_only(prec)
         N, K = ctx.wshape
         dy2 = _f32(dy).contiguous().view(-1, N)
         dya = cast_bf16(dy2) if prec == L.PREC_BF16 else dy2
@@ -594,6 +617,8 @@ class BlocksFn(torch.autograd.Function):
         Ln = (len(params) - 2) // 11
         # need_grad is decided by the caller (grad mode is off inside Function.forward, and
         # ctx.needs_input_grad ignores torch.no_grad())
+        if need_grad:
+            _forward_only(prec)
         desc = L.VitDesc(B, N, d, H, mlp, Ln, prec, int(need_grad), 0.0, None)
         nbytes = L.load().hs_vit_workspace_bytes(C.byref(desc))
         if nbytes == 0:

@@ -82,7 +82,7 @@ class BiomedClipTrunk(nn.Module):
         Fn._need(x)
         if x.dim() != 4 or tuple(x.shape[1:]) != (self.in_chans, self.img_size, self.img_size):
             raise ValueError(f"expected [n, {self.in_chans}, {self.img_size}, {self.img_size}], got {tuple(x.shape)}")
-        prec = L.PREC_BF16 if Fn.get_precision() == "bf16" else L.PREC_F32
+        prec = Fn._PREC[Fn.get_precision()]
         n, p, d = x.shape[0], self.patch_size, self.embed_dim
         # Conv2d(k = stride = 16) == Linear on patches.  hs_patchify orders a patch's features (ph, pw, c) with c fastest;
         # the conv weight is [d][c][ph][pw] -> permute once per call (768 x 768: parameter plumbing, not data path)

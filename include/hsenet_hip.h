@@ -29,6 +29,11 @@ extern "C" {
 
 #define HS_PREC_BF16 0      /* bf16 MFMA inputs, fp32 accumulate, fp32 residual stream (reference autocast policy) */
 #define HS_PREC_F32 1       /* exact-f32 MFMA (v_mfma_f32_32x32x2_f32): parity mode */
+#define HS_PREC_F16 2       /* IEEE fp16 MFMA inputs, fp32 accumulate, fp32 residual stream: FORWARD ONLY.  The reference's eval /
+                             * generation scripts run the model under torch.cuda.amp.autocast() (default dtype fp16,
+                             * Bench/eval/eval_HSENet_CT_Rate_MRG.py:383,423).  Same kernels as HS_PREC_BF16 with fp16 operand packs;
+                             * accepted by hs_gemm (NT, no gradient epilogue), hs_attn_fwd, hs_patchify, hs_cast_f16 and
+                             * hs_vit_blocks_fwd (save_for_bwd = 0); every backward entry point refuses it (HS_ERR_ARG). */
 
 /* GEMM operand layouts: C[M,N] = sum_k A(m,k) * B(n,k).  "T" = the operand is stored [K][dim] (k is the row). */
 #define HS_GEMM_NT 0        /* A[M][K], B[N][K]   : forward nn.Linear  y = x W^T                      */
@@ -184,6 +189,8 @@ int hs_colsum(const void* x, int is_bf16, float* out, int M, int N, int64_t ldx,
 /* fp32 -> bf16 cast of n elements (weights before each step; activations at module boundaries) */
 int hs_cast_bf16(const float* x, void* y, int64_t n, void* stream);
 int hs_cast_f32(const void* x_bf16, float* y, int64_t n, void* stream);
+/* fp32 -> IEEE fp16, round to nearest even (= torch's .half()): the operand cast of HS_PREC_F16 */
+int hs_cast_f16(const float* x, void* y_f16, int64_t n, void* stream);
 /* y = gelu(x) fp32, exact erf (nn.GELU in proj_mpls, spatial_pooling_projector.py:129) and its backward */
 int hs_gelu_fwd(const float* x, float* y, int64_t n, void* stream);
 int hs_gelu_bwd(const float* x, const float* dy, float* dx, int64_t n, void* stream);

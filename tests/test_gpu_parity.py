@@ -9,6 +9,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 TOL_F32 = 1e-3      # north_star: "outputs within 1e-3 of reference"
+TOL_F16 = 1e-3      # fp16 MFMA inputs (2^-11 operand rounding instead of bf16's 2^-9), forward only = the reference's eval-time autocast dtype: measured 3.2e-4 ... 8.0e-4, i.e. INSIDE the north-star tolerance at the bf16 kernels' speed
 TOL_BF16 = 1e-2     # bf16 MFMA inputs through 12 layers: measured 4.1e-3 ... 6.8e-3 (a CPU bf16 emulation of the oracle predicts ~5e-3)
 
 
@@ -38,7 +39,7 @@ def _load(mod, ref_module, seed, dev):
     return mod.to(dev).eval()         # eval like the reference side: the hard-coded Dropout(0.1) sites are train-mode only
 
 
-@pytest.mark.parametrize("prec,tol", [("f32", TOL_F32), ("bf16", TOL_BF16)])
+@pytest.mark.parametrize("prec,tol", [("f32", TOL_F32), ("bf16", TOL_BF16), ("f16", TOL_F16)])
 def test_tiny_encoders_full(dev, golden, prec, tol):
     import hsenet_amd as H
     from oracle import ref_cpu as R
@@ -70,7 +71,7 @@ def test_tiny_encoders_full(dev, golden, prec, tol):
         H.set_precision("bf16")
 
 
-@pytest.mark.parametrize("prec,tol", [("f32", TOL_F32), ("bf16", TOL_BF16)])
+@pytest.mark.parametrize("prec,tol", [("f32", TOL_F32), ("bf16", TOL_BF16), ("f16", TOL_F16)])
 def test_packer(dev, golden, prec, tol):
     import hsenet_amd as H
     from oracle import ref_cpu as R
@@ -98,7 +99,7 @@ def test_packer(dev, golden, prec, tol):
         H.set_precision("bf16")
 
 
-@pytest.mark.parametrize("prec,tol", [("f32", TOL_F32), ("bf16", TOL_BF16)])
+@pytest.mark.parametrize("prec,tol", [("f32", TOL_F32), ("bf16", TOL_BF16), ("f16", TOL_F16)])
 def test_plumbing_vit_small_128(dev, golden, prec, tol):
     """BASELINE configs[0]: 128^3 volume, ViT-small (6 layers, d=384), forward."""
     import hsenet_amd as H
@@ -128,7 +129,7 @@ class Cfg:
         self.image_size, self.patch_size = image_size, patch_size
 
 
-@pytest.mark.parametrize("prec,tol", [("f32", TOL_F32), ("bf16", TOL_BF16)])
+@pytest.mark.parametrize("prec,tol", [("f32", TOL_F32), ("bf16", TOL_BF16), ("f16", TOL_F16)])
 def test_native_dual_tower_and_packers(dev, golden, prec, tol):
     """reference-native geometry 32x256x256 / (4,16,16): dual tower (P7) + two packers (P8) -> (1,256,3072)."""
     import hsenet_amd as H
@@ -164,7 +165,7 @@ def test_native_dual_tower_and_packers(dev, golden, prec, tol):
         H.set_precision("bf16")
 
 
-@pytest.mark.parametrize("prec,tol", [("f32", TOL_F32), ("bf16", TOL_BF16)])
+@pytest.mark.parametrize("prec,tol", [("f32", TOL_F32), ("bf16", TOL_BF16), ("f16", TOL_F16)])
 def test_vit256_stage1(dev, golden, prec, tol):
     """BASELINE configs[1] geometry: 256^3 volume, patch 16^3, ViT-B (12 layers, d=768), N=4097."""
     import hsenet_amd as H
@@ -240,7 +241,7 @@ def test_packer_backward_vs_oracle(dev):
     assert errs[worst] < 5e-2, (worst, errs[worst])
 
 
-@pytest.mark.parametrize("prec,tol", [("f32", TOL_F32), ("bf16", TOL_BF16)])
+@pytest.mark.parametrize("prec,tol", [("f32", TOL_F32), ("bf16", TOL_BF16), ("f16", TOL_F16)])
 def test_config2_dual_256_with_packers(dev, prec, tol):
     """BASELINE configs[2]: 256^3 volume, dual 3D-ViT + 2E3 encoders, two Spatial Packers on the (16,16,16) token grid
     with the reference-sanctioned (2,4,4) kernel -> (1, 256, 3072).  No golden file (the reference wrapper hard-codes the

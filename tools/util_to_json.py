@@ -4,6 +4,7 @@
 
 Inputs: the three separate --pmc passes of tools/collect_traffic.sh (FETCH_SIZE, WRITE_SIZE) and tools/collect_util.sh (SQ/GRBM).
   hbm_bytes_per_launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024     (KiB counters; FETCH_SIZE doubled on gfx950, MI355X_MICROARCH.md "HBM")
+  fetch_bytes_per_launch / write_bytes_per_launch: the two terms of that sum, kept separately (round 4)
   avg_us               = mean kernel duration in the UTIL pass' own kernel trace (a profiled pass: clocks read ~3 % low)
   hbm_gbs              = hbm_bytes_per_launch / avg_us, frac_of_8TBs against the 8 TB/s spec peak
   mfma_busy_frac       = SQ_VALU_MFMA_BUSY_CYCLES / ((GRBM_GUI_ACTIVE / 8) * 1024)    busy cycles summed over the 1024 SIMDs of the chip /
@@ -18,7 +19,7 @@ import sys
 
 out, batch = sys.argv[1], int(sys.argv[2])
 workload = sys.argv[3] if len(sys.argv) > 3 else "dual256"
-tag = sys.argv[4] if len(sys.argv) > 4 else "r03"
+tag = sys.argv[4] if len(sys.argv) > 4 else "r04"
 # kernel-name substring -> class (= hs_prof_name() of the library's per-kernel timers); first match wins
 CLASS = [("attn_fwd_fast_kernel", "attn_fwd"), ("attn_bwd_dkdv16_w4_kernel", "attn_bwd_dkdv"), ("attn_bwd_dq2_kernel", "attn_bwd_dq"),
          ("gemm_bf16_kernel<false, false, true, 0, true>", "gemm_nt16_plain"), ("gemm_bf16_kernel<false, false, true, 9, true>", "gemm_nt16_bias_resid"),
@@ -79,6 +80,8 @@ for c in sorted(set(list(util) + list(fetch))):
     us = mean(dur[c])
     if fs is not None and ws is not None:
         e["hbm_bytes_per_launch"] = (2 * fs + ws) * 1024
+        e["fetch_bytes_per_launch"], e["write_bytes_per_launch"] = 2 * fs * 1024, ws * 1024      # kept apart: a re-fetched operand panel
+        #   shows up in the first, write-allocate reads behind a streamed output would show up in the first too but scale with the second
     if us:
         e["launches"], e["avg_us"] = len(dur[c]), us
         if "hbm_bytes_per_launch" in e:
@@ -98,5 +101,6 @@ json.dump(res, open(f"profiles/{tag}_pmc.json", "w"), indent=1)
 for k, e in res.items():
     if k.startswith("_"):
         continue
-    print(f"{k:16s} {e.get('avg_us', 0):9.1f} us  hbm {e.get('hbm_bytes_per_launch', 0) / 1e6:8.1f} MB  {e.get('hbm_gbs', 0):7.0f} GB/s  "
+    print(f"{k:16s} {e.get('avg_us', 0):9.1f} us  hbm {e.get('hbm_bytes_per_launch', 0) / 1e6:8.1f} MB (fetch {e.get('fetch_bytes_per_launch', 0) / 1e6:8.1f} "
+          f"write {e.get('write_bytes_per_launch', 0) / 1e6:8.1f})  {e.get('hbm_gbs', 0):7.0f} GB/s  "
           f"mfma busy {100 * e.get('mfma_busy_frac', 0):5.1f} %  executed {e.get('mfma_tflops_executed', 0):7.0f} TF")
