@@ -52,6 +52,8 @@ GEOM = {
     "dual256": dict(img=(256, 256, 256), patch=(16, 16, 16), grid=(16, 16, 16), kernel=(2, 4, 4), cfg="configs[2]"),
     "vit256": dict(img=(256, 256, 256), patch=(16, 16, 16), cfg="configs[1]"),
     "clip_c4a": dict(img=(256, 256, 256), patch=(16, 16, 16), cfg="configs[3]"),
+    "clip_c4b": dict(img=(256, 256, 256), patch=(16, 16, 16), cfg="configs[3], both encoders trainable (SURVEY 8(d) C4-B)"),
+    "clip_s1": dict(img=(256, 256, 256), patch=(16, 16, 16), cfg="the stage-1 CLIP step (CLIP_stage1.py:111-139) at configs[3]'s geometry"),
     "native_dual": dict(img=(32, 256, 256), patch=(4, 16, 16), grid=(8, 16, 16), kernel=(1, 4, 4), cfg="configs[2] at the reference-native geometry"),
     "mrg_c5": dict(img=(256, 256, 256), patch=(16, 16, 16), grid=(16, 16, 16), kernel=(2, 4, 4), cfg="configs[4]"),
 }
@@ -84,6 +86,8 @@ def flops_per_volume(workload, Np, Pd, d=768, L=12, ns=32, cells=128, out=OUT_DI
         return 3.0 * (2 * enc + sga + 2 * packer)
     if workload == "clip_c4a":      # frozen 3D-ViT forward + trainable 2E3 fwd+bwd (CLIP_stage2.py:119-151): 4 forward units
         return enc + 3.0 * (enc + sga)
+    if workload == "clip_c4b":      # both trainable: stage-1 step + stage-2 step sharing the stage-1 forward: 6 forward units
+        return 3.0 * enc + 3.0 * (enc + sga)
     if workload == "mrg_c5":        # vision side only: frozen towers forward, packers forward + backward (the LLM is not counted)
         return 2 * enc + sga + 3.0 * 2 * packer
     return 3.0 * enc
@@ -118,7 +122,7 @@ def attention_aggregate(classes):
 def encoders_of(eng):
     """the ViT modules an engine trains (for --attn-logit-std)."""
     ms = []
-    for nm in ("u1", "u2", "unit"):
+    for nm in ("u1", "u2", "unit", "u"):
         u = getattr(eng, nm, None)
         if u is not None and hasattr(u, "model"):
             ms.append(u.model)
@@ -289,6 +293,19 @@ def cpu_baseline(workload, geom, cap_seconds=150.0):
         from oracle import clip_cpu as RC
         step, mods = RC.c4a_cpu_step(img, patch, x)
         what = "stage-2 CLIP step (frozen 3D-ViT fwd + 2E3 fwd+bwd + InfoNCE + relation MSE)"
+    elif workload == "clip_c4b":
+        from oracle import clip_cpu as RC
+        step, mods = RC.c4b_cpu_step(img, patch, x)
+        what = "both-trainable CLIP step (3D-ViT fwd+bwd + InfoNCE; 2E3 fwd+bwd + InfoNCE + relation MSE)"
+    elif workload == "clip_s1":
+        from oracle import clip_cpu as RC
+        m = RC.M3DCLIPVision_stage1(img, patch)
+        t1 = RC.synthetic_text_features(x.shape[0], 1236)
+        mods = [m]
+
+        def step():
+            m(x, t1)["loss"].backward()
+        what = "stage-1 CLIP step (3D-ViT fwd+bwd + InfoNCE)"
     else:
         m = R.ViT_stage1(in_channels=1, img_size=img, patch_size=patch, pos_embed="perceptron", classification=True)
         mods = [m]
@@ -334,10 +351,20 @@ def build_engine(workload, geom, batch, dev, group=None):
         eng = DualEngine(tower, p1, p2, batch, lr=1e-4, weight_decay=0.1, group=group, two_streams=None if ts is None else ts != "0", **dp)
         pe = tower.vision_tower_stage1.patch_embedding
         return eng, pe, True
-    if workload == "clip_c4a":
+    if workload == "clip_s1":
+        from hsenet_amd.clip import M3DCLIPVision_stage1
+        from hsenet_amd.clip_step import ClipStage1Engine
+        model = M3DCLIPVision_stage1(img, patch).to(dev)
+        eng = ClipStage1Engine(model, batch, lr=1e-4, weight_decay=0.1, group=group, **dp)
+        rng = np.random.default_rng(4321 + int(os.environ.get("RANK", "0")))
+        eng.set_text_features(torch.nn.functional.normalize(torch.from_numpy(rng.standard_normal((batch, 768), dtype=np.float32)), dim=-1).to(dev))
+        return eng, model.vision_encoder.patch_embedding, False
+    if workload in ("clip_c4a", "clip_c4b"):
         from hsenet_amd.clip_step import ClipStage2Engine, make_clip_stage2
         model = make_clip_stage2(img, patch).to(dev)
-        eng = ClipStage2Engine(model, batch, lr=1e-4, weight_decay=0.1, group=group, **dp)
+        if workload == "clip_c4b":
+            model.stage1_pretrained_CLIP.requires_grad_(True)
+        eng = ClipStage2Engine(model, batch, lr=1e-4, weight_decay=0.1, group=group, train_stage1=workload == "clip_c4b", **dp)
         rng = np.random.default_rng(4321 + int(os.environ.get("RANK", "0")))
         txt = [torch.nn.functional.normalize(torch.from_numpy(rng.standard_normal((batch, 768), dtype=np.float32)), dim=-1).to(dev)
                for _ in range(2)]                                   # frozen text embeddings: normalize(N(0,1))
@@ -431,7 +458,7 @@ def main():
     if a.grad_algo:
         os.environ["HS_GRAD_ALGO"] = a.grad_algo
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
-    small = a.workload in ("clip_c4a", "clip_c4b", "mrg_c5")
+    small = a.workload in ("clip_c4a", "clip_c4b", "clip_s1", "mrg_c5")
     if a.scaling == "strong":
         if a.batch is not None:
             sys.exit("--scaling strong takes --global-batch, not --batch")
@@ -610,6 +637,11 @@ def main():
         "vit256": "3D-ViT patch {p} 12 layers d=768 (N={N} tokens), fwd+bwd+grad all-reduce+clipped AdamW",
         "clip_c4a": "stage-2 CLIP step (CLIP_stage2.py:119-151): frozen 3D-ViT forward + 2E3-ViT fwd+bwd (patch {p}, N={N}), cls -> "
                     "mm_vision_proj -> normalize, all-gather, InfoNCE vs frozen text embeds + relation MSE, grad all-reduce+clipped AdamW",
+        "clip_c4b": "both-trainable CLIP step (SURVEY 8(d) C4-B): the stage-1 step (CLIP_stage1.py:111-139: 3D-ViT fwd+bwd, InfoNCE) and the stage-2 "
+                    "step (CLIP_stage2.py:119-151: 2E3-ViT fwd+bwd, InfoNCE + relation MSE against the detached stage-1 logits) on one volume batch "
+                    "(patch {p}, N={N}), one shared stage-1 forward and feature all-gather, two grad all-reduces + clipped AdamW states",
+        "clip_s1": "stage-1 CLIP step (CLIP_stage1.py:111-139): 3D-ViT fwd+bwd (patch {p}, N={N}), cls -> mm_vision_proj -> normalize, all-gather, "
+                   "InfoNCE vs frozen text embeds, grad all-reduce+clipped AdamW",
         "mrg_c5": "MRG finetune step: frozen dual encoders (patch {p}, N={N}) forward, two Spatial Packers fwd+bwd, 256 image tokens spliced "
                   "into 800 token embeddings of a random-init frozen Phi-4-mini-shaped HF decoder (PyTorch-ROCm, out of the HIP path's scope; its "
                   "FLOPs are NOT in model_tflops), LM loss, packer grad all-reduce+clipped AdamW",

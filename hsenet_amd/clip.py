@@ -252,6 +252,16 @@ class M3DCLIPVision_stage1(nn.Module):
         tokens, _ = self.vision_encoder(image)
         return encode_image_cls(tokens, self.mm_vision_proj)
 
+    def image_text_contrastive_learning(self, image_features, text_features, labels=None, group=None):
+        return image_text_contrastive_learning(image_features, text_features, self.logit_scale, labels, self.gather_loss,
+                                               self.local_loss, group)
+
+    def forward(self, images, text_features, global_step=None, group=None):
+        """CLIP_stage1.py:111-139 with the text tower's output given (text_features: its L2-normalised cls features [B, d])."""
+        img = self.encode_image(images)
+        loss, lpi, lpt = self.image_text_contrastive_learning(img, text_features, group=group)
+        return {"loss": loss, "logits": (lpi + lpt) / 2.0}
+
 
 class M3DCLIPVision_stage2(nn.Module):
     """CLIP_stage2.py:58-190 without the BERT towers: trainable ViT_stage2 + mm_vision_proj + logit_scale, and the frozen

@@ -1,4 +1,15 @@
-"""BASELINE configs[3] / SURVEY section 8(d) "C4-A": the reference's stage-2 CLIP train step (CLIP_stage2.py:119-151) as one
+"""The reference's two CLIP train steps as fused engines.
+
+``ClipStage1Engine`` -- M3DCLIP_stage1.forward (CLIP_stage1.py:111-139): ViT_stage1 forward + backward, cls -> mm_vision_proj ->
+normalize, all-gather, InfoNCE against frozen text features, bucketed gradient all-reduce, clipped AdamW.
+``ClipStage2Engine(train_stage1=True)`` -- SURVEY section 8(d) "C4-B": both encoders trainable in one iteration (6 forward units per
+volume): the stage-1 step above and the stage-2 step below share ONE patch matrix, ONE stage-1 forward (its logits also feed the stage-2
+relation term, detached as in the reference) and ONE feature all-gather; each model keeps its own loss (stage 1: InfoNCE with ITS
+logit_scale; stage 2: InfoNCE + w * relation MSE), flat gradient, buckets and AdamW state.  The reference never trains both encoders in
+one step (train_CLIP_stage1.py / train_CLIP_stage2.py): C4-B is the survey's both-trainable FLOP / all-reduce-payload variant, and each
+half of it is tested against a CPU statement of its own reference step (tests/test_gpu_clip.py).
+
+``ClipStage2Engine`` -- BASELINE configs[3] / SURVEY section 8(d) "C4-A": the reference's stage-2 CLIP train step (CLIP_stage2.py:119-151) as one
 fused engine — frozen stage-1 3D-ViT forward (no activations kept: the reference runs it under inference_mode, :124-127),
 trainable 2E3-ViT forward + backward, cls -> mm_vision_proj -> normalize, all-gather of the cls features across ranks (collective
 C2), InfoNCE + relation MSE with the 0.1*(1 - step/5000) schedule, bucketed all-reduce of the 2E3 encoder + mm_vision_proj +
@@ -15,7 +26,7 @@ import torch.distributed as dist
 
 from . import _lib as L
 from . import functional as Fn
-from .clip import M3DCLIPVision_stage2, relation_loss_weight
+from .clip import M3DCLIPVision_stage1, M3DCLIPVision_stage2, relation_loss_weight
 from .engine import EncoderUnit, _Engine, _al, _encoder_bounds, _encoder_entries, decays
 
 
@@ -55,43 +66,163 @@ class _Head:
         L.call("hs_rows_scatter", self.dcls.data_ptr(), u.dy.data_ptr(), u.B, 0, 1, u.N, u.d, s)
 
 
+def _clip_flat(unit: EncoderUnit, model, n_buckets: int):
+    """flat order of one CLIP model: encoder [head.., blocks, norm], then mm_vision_proj and logit_scale (finished FIRST by the backward
+    pass); returns (entries, layer chunks, bucket bounds)."""
+    dec = decays(model)
+    entries = _encoder_entries(unit, "vision_encoder.")
+    entries += [("mm_vision_proj.weight", model.mm_vision_proj.weight, dec["mm_vision_proj.weight"]),
+                ("mm_vision_proj.bias", model.mm_vision_proj.bias, dec["mm_vision_proj.bias"]),
+                ("logit_scale", model.logit_scale, dec["logit_scale"])]
+    names = [n for n, _, _ in entries]
+    offs, off = [], 0
+    for _, p, _ in entries:
+        offs.append(off)
+        off += _al(p.numel())
+    chunks, bounds = _encoder_bounds(unit, names, offs, "vision_encoder.", 0, off, n_buckets)
+    return entries, chunks, bounds
+
+
+class ClipStage1Engine(_Engine):
+    """The stage-1 CLIP step (CLIP_stage1.py:111-139) over an ``M3DCLIPVision_stage1``: ``train_step(images, text_features)``;
+    text features: the L2-normalised cls text features [B_local, d] of the (out-of-scope) BERT tower, frozen inputs."""
+
+    def __init__(self, model: M3DCLIPVision_stage1, batch: int, *, lr=1e-4, weight_decay=0.1, max_grad_norm: Optional[float] = 1.0,
+                 n_buckets=4, group=None, grad_wire="fp32", grad_algo="allreduce"):
+        if model.local_loss or not model.gather_loss:
+            raise L.HsError("ClipStage1Engine drives the shipped configuration: gather_loss=True, local_loss=False")
+        if not all(p.requires_grad for p in model.parameters()):
+            raise L.HsError("ClipStage1Engine trains every parameter of the model: requires_grad_(True) first")
+        self.model, self.B, self.group = model, batch, group
+        self.u = EncoderUnit(model.vision_encoder, batch, trainable=True)
+        self.dev = self.u.dev
+        on = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if on else 1
+        self.rank = dist.get_rank(group) if on else 0
+        entries, self.chunks, bounds = _clip_flat(self.u, model, n_buckets)
+        self._finish(entries, bounds, lr=lr, weight_decay=weight_decay, max_grad_norm=max_grad_norm, group=group,
+                     grad_wire=grad_wire, grad_algo=grad_algo)
+        self.u.bind()
+        self.head = _Head(self.u, model.mm_vision_proj, True)
+        d, n = self.u.d, batch * self.world
+        f32 = dict(dtype=torch.float32, device=self.dev)
+        self.patches = torch.empty(batch * self.u.Np, self.u.Pd, dtype=torch.bfloat16, device=self.dev)
+        self.local = torch.empty(batch, 2 * d, **f32)              # [img | txt] of this rank
+        self.all = torch.empty(n, 2 * d, **f32)                    # ... of every rank (ONE all-gather per step)
+        self.raw, self.logits = torch.empty(n, n, **f32), torch.empty(n, n, **f32)
+        self.dlog, self.draw = torch.empty(n, n, **f32), torch.empty(n, n, **f32)
+        self.dall = torch.empty(n, d, **f32)
+        self.acc = torch.zeros(2, **f32)                           # [CE loss, -]
+        self.global_step = 0
+        self._txt = None
+
+    # ---- pieces shared with the both-trainable step (ClipStage2Engine(train_stage1=True)), which owns the gathered feature matrix ----
+    def loss_from_all(self, all_feats: torch.Tensor, row_stride: int, col_img: int, col_txt: int) -> None:
+        """logits = logit_scale * all_img @ all_txt^T from two d-wide column blocks of ``all_feats`` (CLIP_stage1.py:148-149 with
+        local_loss False), symmetric InfoNCE (:151) into self.acc[0], dL/dlogits into self.dlog."""
+        d, n, s = self.u.d, self.dlog.shape[0], Fn._s()
+        g = L.GemmArgs()
+        g.A, g.B = all_feats.data_ptr() + 4 * col_img * d, all_feats.data_ptr() + 4 * col_txt * d
+        g.M, g.N, g.K, g.lda, g.ldb, g.batch = n, n, d, row_stride, row_stride, 1
+        g.out_f32, g.ldc, g.alpha, g.layout, g.split_k = self.raw.data_ptr(), n, 1.0, L.GEMM_NT, 1
+        L.call("hs_gemm", C.byref(g), L.PREC_F32, s)
+        L.call("hs_scale_dev", self.raw.data_ptr(), self.logits.data_ptr(), self.model.logit_scale.data_ptr(), 1.0, n * n, s)
+        self.acc.zero_()
+        L.call("hs_clip_ce", self.logits.data_ptr(), self.dlog.data_ptr(), self.acc.data_ptr(), n, s)
+
+    def backward_from_all(self, all_feats: torch.Tensor, row_stride: int, col_txt: int) -> None:
+        """self.dlog -> every gradient of this model (flat gradient zeroed here), bucketed all-reduce launched and awaited."""
+        s, d, B, n = Fn._s(), self.u.d, self.B, self.dlog.shape[0]
+        self.grad.zero_()
+        ls = self.model.logit_scale
+        L.call("hs_dot", self.dlog.data_ptr(), self.raw.data_ptr(), ls.grad.data_ptr(), 1.0, n * n, s)              # d/d logit_scale
+        L.call("hs_scale_dev", self.dlog.data_ptr(), self.draw.data_ptr(), ls.data_ptr(), 1.0, n * n, s)
+        L.call("hs_rowmix", self.draw.data_ptr(), all_feats.data_ptr() + 4 * col_txt * d, self.dall.data_ptr(), n, n, d, n, row_stride, d, 0, s)
+        if self.world > 1:       # backward of the all-gather (torch.distributed.nn.all_gather): sum over ranks, keep this rank's rows
+            dist.all_reduce(self.dall, op=dist.ReduceOp.SUM, group=self.group)
+        L.call("hs_rows_copy", self.dall.data_ptr() + 4 * self.rank * B * d, d, self.head.df.data_ptr(), None, d, B, 1, d, s)
+        self.head.backward()
+        self.u.backward(self.patches, self.u.dy, self.chunks, self.buckets.reduce)
+        self.buckets.wait()
+
+    # ---- the stand-alone stage-1 step ------------------------------------------------------------------------------------------
+    def forward_loss(self, images, text_features) -> None:
+        s, d, B = Fn._s(), self.u.d, self.B
+        Fn._need_as(text_features, "text_features", (B, d))
+        self._patchify(images, self.model.vision_encoder.patch_embedding, self.patches)
+        self.u.forward(self.patches)
+        f = self.head.forward()
+        for i, t in enumerate((f, text_features)):
+            L.call("hs_rows_copy", t.data_ptr(), d, self.local.data_ptr() + 4 * i * d, None, 2 * d, B, 1, d, s)
+        if self.world > 1:
+            dist.all_gather_into_tensor(self.all, self.local, group=self.group)                          # collective C2
+        else:
+            self.all.copy_(self.local)
+        self.loss_from_all(self.all, 2 * d, 0, 1)
+
+    def loss_value(self) -> float:
+        """host read (synchronises): loss = loss_CL_stage1."""
+        return float(self.acc[0])
+
+    def backward(self) -> None:
+        self.backward_from_all(self.all, 2 * self.u.d, 1)
+
+    def train_step(self, images, text_features=None, optimizer: bool = True) -> None:
+        if text_features is None:
+            if self._txt is None:
+                raise L.HsError("train_step(images) needs set_text_features() first (or pass the text features)")
+            text_features = self._txt
+        self.forward_loss(images, text_features)
+        self.backward()
+        if optimizer:
+            self.optimizer_step()
+            self.global_step += 1
+
+    def set_text_features(self, text_features: torch.Tensor) -> None:
+        B, d = self.B, self.u.d
+        if not isinstance(text_features, torch.Tensor) or tuple(text_features.shape) != (B, d):
+            raise L.HsError(f"text_features must be a [B={B}, {d}] tensor")
+        self._txt = text_features.detach().to(device=self.dev, dtype=torch.float32).contiguous()
+
+
 class ClipStage2Engine(_Engine):
     """The stage-2 CLIP step over an ``M3DCLIPVision_stage2``.  ``train_step(images, images_2d, text_features_stage1,
-    text_features)``; text features: L2-normalised [B_local, d] (frozen)."""
+    text_features)``; text features: L2-normalised [B_local, d] (frozen).  ``train_stage1=True``: the both-trainable variant (module
+    docstring): ``self.s1`` is a ``ClipStage1Engine`` over ``model.stage1_pretrained_CLIP`` (whose parameters must then require grad)."""
 
     def __init__(self, model: M3DCLIPVision_stage2, batch: int, *, lr=1e-4, weight_decay=0.1, max_grad_norm: Optional[float] = 1.0,
-                 n_buckets=4, group=None, grad_wire="fp32", grad_algo="allreduce"):
+                 n_buckets=4, group=None, grad_wire="fp32", grad_algo="allreduce", train_stage1: bool = False):
         if model.local_loss or not model.gather_loss:
             raise L.HsError("ClipStage2Engine drives the shipped configuration: gather_loss=True, local_loss=False")
         self.model, self.B, self.group = model, batch, group
-        self.u1 = EncoderUnit(model.stage1_pretrained_CLIP.vision_encoder, batch, trainable=False)
+        self.s1 = None
+        if train_stage1:
+            self.s1 = ClipStage1Engine(model.stage1_pretrained_CLIP, batch, lr=lr, weight_decay=weight_decay, max_grad_norm=max_grad_norm,
+                                       n_buckets=n_buckets, group=group, grad_wire=grad_wire, grad_algo=grad_algo)
+            self.u1 = self.s1.u
+        else:
+            self.u1 = EncoderUnit(model.stage1_pretrained_CLIP.vision_encoder, batch, trainable=False)
         self.u2 = EncoderUnit(model.vision_encoder, batch, trainable=True)
         self.dev = self.u2.dev
         on = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(group) if on else 1
         self.rank = dist.get_rank(group) if on else 0
         # flat order: 2E3 encoder [head.., blocks, norm], then mm_vision_proj and logit_scale (finished FIRST by the backward pass)
-        dec = decays(model)
-        entries = _encoder_entries(self.u2, "vision_encoder.")
-        entries += [("mm_vision_proj.weight", model.mm_vision_proj.weight, dec["mm_vision_proj.weight"]),
-                    ("mm_vision_proj.bias", model.mm_vision_proj.bias, dec["mm_vision_proj.bias"]),
-                    ("logit_scale", model.logit_scale, dec["logit_scale"])]
-        names = [n for n, _, _ in entries]
-        offs, off = [], 0
-        for _, p, _ in entries:
-            offs.append(off)
-            off += _al(p.numel())
-        self.chunks, bounds = _encoder_bounds(self.u2, names, offs, "vision_encoder.", 0, off, n_buckets)
+        entries, self.chunks, bounds = _clip_flat(self.u2, model, n_buckets)
         self._finish(entries, bounds, lr=lr, weight_decay=weight_decay, max_grad_norm=max_grad_norm, group=group,
                      grad_wire=grad_wire, grad_algo=grad_algo)
-        self.u1.bind()
         self.u2.bind()
-        self.h1 = _Head(self.u1, model.stage1_pretrained_CLIP.mm_vision_proj, False)
+        if self.s1 is None:
+            self.u1.bind()
+            self.h1 = _Head(self.u1, model.stage1_pretrained_CLIP.mm_vision_proj, False)
+        else:
+            self.h1 = self.s1.head
         self.h2 = _Head(self.u2, model.mm_vision_proj, True)
         u = self.u2
         d, n = u.d, batch * self.world
         f32 = dict(dtype=torch.float32, device=self.dev)
-        self.patches = torch.empty(batch * u.Np, u.Pd, dtype=torch.bfloat16, device=self.dev)
+        # (both-trainable: ONE patch matrix, the stage-1 engine's -- its embedding backward reads it)
+        self.patches = self.s1.patches if self.s1 is not None else torch.empty(batch * u.Np, u.Pd, dtype=torch.bfloat16, device=self.dev)
         self.local = torch.empty(batch, 4 * d, **f32)              # [img1 | txt1 | img2 | txt2] of this rank
         self.all = torch.empty(n, 4 * d, **f32)                    # ... of every rank (ONE all-gather per step)
         self.raw1, self.raw2 = torch.empty(n, n, **f32), torch.empty(n, n, **f32)
@@ -144,6 +275,8 @@ class ClipStage2Engine(_Engine):
         L.call("hs_relation_mse", self.logits1.data_ptr(), self.logits2.data_ptr(), self.dlog.data_ptr(), self.acc.data_ptr() + 8, n * n,
                float(w), 1, s)
         self._w = w
+        if self.s1 is not None:                                         # the stage-1 model's own InfoNCE, with ITS logit_scale
+            self.s1.loss_from_all(self.all, 4 * d, 0, 1)
 
     def loss_value(self) -> float:
         """host read (synchronises): loss = loss_CL_stage2 + w * loss_relation."""
@@ -163,6 +296,23 @@ class ClipStage2Engine(_Engine):
         self.h2.backward()
         self.u2.backward(self.patches, self.u2.dy, self.chunks, self.buckets.reduce)
         self.buckets.wait()
+        if self.s1 is not None:
+            self.s1.backward_from_all(self.all, 4 * d, 1)
+
+    def optimizer_step(self) -> None:
+        super().optimizer_step()
+        if self.s1 is not None:
+            self.s1.optimizer_step()
+            self.s1.global_step += 1
+
+    def probe_step(self, *inputs) -> None:
+        if self.s1 is not None:
+            self.s1.buckets.muted = True
+        try:
+            super().probe_step(*inputs)
+        finally:
+            if self.s1 is not None:
+                self.s1.buckets.muted = False
 
     def train_step(self, images, images_2d, text_features_stage1=None, text_features=None, optimizer: bool = True) -> None:
         if (text_features_stage1 is None) != (text_features is None):

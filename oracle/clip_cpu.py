@@ -68,6 +68,12 @@ class M3DCLIPVision_stage1(nn.Module):
     def encode_image(self, image):
         return R.clip_encode_image(self.vision_encoder, self.mm_vision_proj, image)
 
+    def forward(self, images, text_features, global_step=None):
+        """CLIP_stage1.py:111-139 with the text tower's cls features given."""
+        img = self.encode_image(images)[:, 0]
+        loss, lpi, lpt = image_text_contrastive_learning(img, text_features, self.logit_scale)                   # :121
+        return {"loss": loss, "logits": (lpi + lpt) / 2.0}
+
 
 class M3DCLIPVision_stage2(nn.Module):
     """CLIP_stage2.py:58-169 minus the text towers: text features are inputs."""
@@ -105,6 +111,33 @@ def synthetic_text_features(batch, seed):
     """frozen text embeddings: normalize(N(0,1)) [B, 768]."""
     import numpy as np
     return F.normalize(torch.from_numpy(np.random.default_rng(seed).standard_normal((batch, 768), dtype=np.float32)), dim=-1)
+
+
+def c4b_cpu_step(img, patch, x):
+    """bench.py's cpu_baseline for --workload clip_c4b (SURVEY section 8(d) "C4-B": both encoders trainable): the stage-1 step and the
+    stage-2 step of the reference on the same volume, the stage-1 forward shared (its logits enter the relation term detached)."""
+    m = M3DCLIPVision_stage2(img, patch)
+    m.stage1_pretrained_CLIP.requires_grad_(True)
+    s = R.synthetic_slices(x.shape[0], 1235)
+    t1, t2 = synthetic_text_features(x.shape[0], 1236), synthetic_text_features(x.shape[0], 1237)
+
+    def step():
+        c4b_losses(m, x, t1, t2, s, 0)[0].backward()
+    return step, [m]
+
+
+def c4b_losses(m, x, t1, t2, s, global_step):
+    """(loss_stage1 + loss_stage2, loss_stage1, loss_stage2) of the both-trainable step: stage 1 = CLIP_stage1.py:111-139 on
+    m.stage1_pretrained_CLIP (its own logit_scale), stage 2 = CLIP_stage2.py:119-151 with the stage-1 features detached."""
+    s1 = m.stage1_pretrained_CLIP
+    img1 = s1.encode_image(x)[:, 0]
+    loss1, _, _ = image_text_contrastive_learning(img1, t1, s1.logit_scale)
+    _, lpi1, lpt1 = image_text_contrastive_learning(img1.detach(), t1, m.logit_scale)                            # CLIP_stage2.py:128
+    img2 = m.encode_image(x, s)[:, 0]
+    loss_cl, lpi2, lpt2 = image_text_contrastive_learning(img2, t2, m.logit_scale)
+    loss_rel = image_text_relation_regulation(lpi1.detach(), lpt1.detach(), lpi2, lpt2)
+    loss2 = loss_cl + relation_loss_weight(global_step) * loss_rel
+    return loss1 + loss2, loss1, loss2
 
 
 def c4a_cpu_step(img, patch, x):

@@ -284,3 +284,109 @@ def test_stage2_clip_engine_refuses_wrong_text_features(dev):
     eng2.set_text_features(t1, t2)
     eng2.train_step(x, s)
     assert abs(eng2.loss_value() - ref_loss) < 1e-6 * max(1.0, abs(ref_loss))
+
+
+# ---- the stage-1 CLIP step (CLIP_stage1.py:111-139) and the both-trainable variant (SURVEY section 8(d) "C4-B") ----------------
+def _models_s1(dev, seed):
+    from hsenet_amd.clip import M3DCLIPVision_stage1
+    from oracle import clip_cpu as RC, ref_cpu as R
+    ref = RC.M3DCLIPVision_stage1(IMG, PATCH, LAYERS).eval()
+    sd = R.seeded_state_dict(ref, seed)
+    sd["logit_scale"] = torch.tensor(SCALE)
+    ref.load_state_dict(sd)
+    m = M3DCLIPVision_stage1(IMG, PATCH, num_layers=LAYERS)
+    assert list(m.state_dict().keys()) == list(ref.state_dict().keys())
+    m.load_state_dict(sd)
+    return ref, m.to(dev).eval()
+
+
+@pytest.mark.parametrize("path", ["engine", "module"])
+def test_stage1_clip_step_vs_oracle(dev, path):
+    """M3DCLIP_stage1.forward in miniature, batch 8: loss, logits and every gradient (3D-ViT, mm_vision_proj, logit_scale) of
+    InfoNCE against frozen text features vs the oracle's autograd, through the fused engine and through the module API."""
+    from hsenet_amd.clip_step import ClipStage1Engine
+    from oracle import clip_cpu as RC, ref_cpu as R
+    B = 8
+    ref, m = _models_s1(dev, 1750)
+    x, t1 = R.synthetic_volume((B, 1) + IMG, 1751), RC.synthetic_text_features(B, 1753)
+    out_r = ref(x, t1)
+    out_r["loss"].backward()
+    xd, t1d = x.to(dev), t1.to(dev)
+    if path == "engine":
+        eng = ClipStage1Engine(m, B)
+        eng.forward_loss(xd, t1d)
+        eng.backward()
+        torch.cuda.synchronize()
+        loss = eng.loss_value()
+        assert rel((eng.logits + eng.logits.t()) / 2, out_r["logits"].detach()) < 2e-2
+        assert set(eng.params.names) == set(dict(m.named_parameters()))
+    else:
+        out = m(xd, t1d)
+        out["loss"].backward()
+        loss = float(out["loss"])
+        assert rel(out["logits"], out_r["logits"].detach()) < 2e-2
+    lr_ = float(out_r["loss"])
+    print(f"stage-1 CLIP step ({path}): loss {loss:.5f} vs oracle {lr_:.5f}")
+    assert abs(loss - lr_) < 2e-2 * abs(lr_)
+    _grad_check(list(m.named_parameters()), list(ref.named_parameters()), f"stage-1 CLIP step ({path})")
+
+
+def test_stage1_clip_engine_trains_and_refuses_frozen_models(dev):
+    from hsenet_amd import _lib as L
+    from hsenet_amd.clip_step import ClipStage1Engine
+    from oracle import clip_cpu as RC, ref_cpu as R
+    B = 4
+    _, m = _models_s1(dev, 1770)
+    eng = ClipStage1Engine(m, B, lr=3e-4)
+    x = R.synthetic_volume((B, 1) + IMG, 1771).to(dev)
+    with pytest.raises(L.HsError):
+        eng.train_step(x)                                          # no text features yet
+    eng.set_text_features(RC.synthetic_text_features(B, 1773).to(dev).half())       # an autocast text tower hands over fp16: converted
+    losses = []
+    for _ in range(6):
+        eng.train_step(x)
+        losses.append(eng.loss_value())
+    assert np.isfinite(losses).all() and losses[-1] < losses[0], losses
+    assert eng.global_step == 6 and float(m.logit_scale) != SCALE
+    _, frozen = _models_s1(dev, 1771)
+    frozen.requires_grad_(False)
+    with pytest.raises(L.HsError):
+        ClipStage1Engine(frozen, B)
+
+
+def test_both_trainable_clip_step_vs_oracle(dev):
+    """SURVEY section 8(d) C4-B in miniature, batch 8: ONE iteration trains the stage-1 CLIP (its own InfoNCE, its own logit_scale)
+    and the stage-2 CLIP (InfoNCE + relation MSE against the DETACHED stage-1 logits) on a shared stage-1 forward: both losses and
+    every gradient of both models vs the oracle's autograd of loss_stage1 + loss_stage2; then both optimizers step."""
+    from hsenet_amd.clip_step import ClipStage2Engine
+    from oracle import clip_cpu as RC, ref_cpu as R
+    B, step = 8, 1000
+    ref, m = _models(dev, 1850)
+    ref.stage1_pretrained_CLIP.requires_grad_(True)
+    m.stage1_pretrained_CLIP.requires_grad_(True)
+    with torch.no_grad():                                           # a stage-1 logit_scale of its own: the two models' scales differ
+        ref.stage1_pretrained_CLIP.logit_scale.fill_(2.0)
+        m.stage1_pretrained_CLIP.logit_scale.fill_(2.0)
+    x, s = R.synthetic_volume((B, 1) + IMG, 1851), R.synthetic_slices(B, 1852)
+    t1, t2 = RC.synthetic_text_features(B, 1853), RC.synthetic_text_features(B, 1854)
+    total, l1, l2 = RC.c4b_losses(ref, x, t1, t2, s, step)
+    total.backward()
+    eng = ClipStage2Engine(m, B, train_stage1=True)
+    eng.global_step = step
+    eng.forward_loss(x.to(dev), s.to(dev), t1.to(dev), t2.to(dev))
+    eng.backward()
+    torch.cuda.synchronize()
+    mine1, mine2 = eng.s1.loss_value(), eng.loss_value()
+    print(f"both-trainable CLIP step: stage-1 loss {mine1:.5f} vs {float(l1):.5f}, stage-2 loss {mine2:.5f} vs {float(l2):.5f}")
+    assert abs(mine1 - float(l1)) < 2e-2 * abs(float(l1)) and abs(mine2 - float(l2)) < 2e-2 * abs(float(l2))
+    assert not set(eng.params.names) & {"stage1_pretrained_CLIP." + n for n in eng.s1.params.names}
+    s1_ref = [(n, p) for n, p in ref.named_parameters() if n.startswith("stage1_pretrained_CLIP.")]
+    s2_ref = [(n, p) for n, p in ref.named_parameters() if not n.startswith("stage1_pretrained_CLIP.")]
+    _grad_check([(n, p) for n, p in m.named_parameters() if n.startswith("stage1_pretrained_CLIP.")], s1_ref, "C4-B stage-1 half")
+    _grad_check([(n, p) for n, p in m.named_parameters() if not n.startswith("stage1_pretrained_CLIP.")], s2_ref, "C4-B stage-2 half")
+    before = [float(m.logit_scale), float(m.stage1_pretrained_CLIP.logit_scale)]
+    eng.train_step(x.to(dev), s.to(dev), t1.to(dev), t2.to(dev))
+    torch.cuda.synchronize()
+    assert eng.global_step == step + 1 and eng.s1.global_step == 1
+    assert float(m.logit_scale) != before[0] and float(m.stage1_pretrained_CLIP.logit_scale) != before[1]
+    assert bool(torch.isfinite(eng.flat).all()) and bool(torch.isfinite(eng.s1.flat).all())
