@@ -42,7 +42,10 @@ class _Rearrange(nn.Module):
 
 
 class PatchEmbeddingBlock(nn.Module):
-    """MONAI 1.3.0 PatchEmbeddingBlock with pos_embed='perceptron' (reference ctor call vit.py:428-437)."""
+    """MONAI 1.3.0 PatchEmbeddingBlock (reference ctor call vit.py:428-437).  pos_embed='perceptron' (what every shipped call site
+    passes: Rearrange + Linear, keys ``patch_embeddings.1.*``) or 'conv' (the constructors' DEFAULT, vit.py:237,375: a Conv3d with
+    kernel = stride = patch, keys ``patch_embeddings.weight / .bias``).  A strided convolution over non-overlapping patches IS the
+    perceptron form with the weight's axes in (c, p1, p2, p3) instead of (p1, p2, p3, c) order, so both run the same patchify + MFMA GEMM."""
 
     def __init__(self, in_channels, img_size, patch_size, hidden_size, num_heads, pos_embed="perceptron",
                  dropout_rate=0.0, spatial_dims=3):
@@ -51,8 +54,9 @@ class PatchEmbeddingBlock(nn.Module):
             raise ValueError("dropout_rate should be between 0 and 1.")
         if hidden_size % num_heads != 0:
             raise ValueError("hidden size should be divisible by num_heads.")
-        if pos_embed != "perceptron":
-            raise ValueError(f"pos_embed={pos_embed!r}: only 'perceptron' is on the HSENet hot path (vit.py:895-924)")
+        if pos_embed not in ("perceptron", "conv"):
+            raise ValueError(f"pos_embed={pos_embed!r}: 'perceptron' or 'conv' (MONAI PatchEmbeddingBlock)")
+        self.pos_embed = pos_embed
         if spatial_dims != 3:
             raise ValueError("only 3-D volumes are supported")
         img_size = tuple(img_size) if isinstance(img_size, Sequence) else (img_size,) * 3
@@ -65,12 +69,25 @@ class PatchEmbeddingBlock(nn.Module):
         self.img_size, self.patch_size = img_size, patch_size
         self.n_patches = int(np.prod([i // p for i, p in zip(img_size, patch_size)]))
         self.patch_dim = int(in_channels * np.prod(patch_size))
-        self.patch_embeddings = nn.Sequential(_Rearrange(patch_size), nn.Linear(self.patch_dim, hidden_size))
+        if pos_embed == "conv":        # (MONAI's _init_weights touches nn.Linear / nn.LayerNorm only: the conv keeps torch's default init)
+            self.patch_embeddings = nn.Conv3d(in_channels, hidden_size, kernel_size=patch_size, stride=patch_size)
+        else:
+            self.patch_embeddings = nn.Sequential(_Rearrange(patch_size), nn.Linear(self.patch_dim, hidden_size))
         self.position_embeddings = nn.Parameter(torch.zeros(1, self.n_patches, hidden_size))
         self.dropout = nn.Dropout(dropout_rate)
         nn.init.trunc_normal_(self.position_embeddings, mean=0.0, std=0.02, a=-2.0, b=2.0)
-        nn.init.trunc_normal_(self.patch_embeddings[1].weight, mean=0.0, std=0.02, a=-2.0, b=2.0)
-        nn.init.zeros_(self.patch_embeddings[1].bias)
+        if pos_embed == "perceptron":
+            nn.init.trunc_normal_(self.patch_embeddings[1].weight, mean=0.0, std=0.02, a=-2.0, b=2.0)
+            nn.init.zeros_(self.patch_embeddings[1].bias)
+
+    def linear_weight_bias(self):
+        """(weight [hidden, p1*p2*p3*c], bias) of the patch projection in the rearranged feature order '(p1 p2 p3 c)' the patchify
+        kernel emits; for 'conv' a (differentiable) re-ordering of the Conv3d weight [hidden, c, p1, p2, p3]."""
+        if self.pos_embed == "conv":
+            w = self.patch_embeddings.weight
+            return w.permute(0, 2, 3, 4, 1).reshape(w.shape[0], -1), self.patch_embeddings.bias
+        lin = self.patch_embeddings[1]
+        return lin.weight, lin.bias
 
 
 class MLPBlock(nn.Module):
@@ -167,10 +184,10 @@ class _ViTBase(nn.Module):
 
     def _embed(self, x, prec):
         pe = self.patch_embedding
-        lin = pe.patch_embeddings[1]
         if tuple(x.shape[2:]) != pe.img_size:
             raise ValueError(f"input volume {tuple(x.shape[2:])} does not match img_size {pe.img_size}")
-        return Fn.PatchEmbedFn.apply(x, lin.weight, lin.bias, pe.patch_size, prec)
+        w, b = pe.linear_weight_bias()
+        return Fn.PatchEmbedFn.apply(x, w, b, pe.patch_size, prec)
 
     def _stack(self, tokens, prec):
         params = [p for blk in self.blocks for p in blk.ordered_params()] + [self.norm.weight, self.norm.bias]

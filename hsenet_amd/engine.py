@@ -125,6 +125,9 @@ def _seeds(desc, train: bool) -> None:
 def encoder_head_params(m) -> List[Tuple[str, nn.Parameter]]:
     """embedding-driver parameters in ITS order (hs_embed_*: cls, pos, pe.w, pe.b [, scorer x12]) with their state-dict names."""
     out = []
+    if getattr(m.patch_embedding, "pos_embed", "perceptron") != "perceptron":
+        raise L.HsError("the fused engines drive pos_embed='perceptron' encoders (every shipped configuration); "
+                        "a pos_embed='conv' encoder runs through the module API")
     if hasattr(m, "cls_token"):
         out.append(("cls_token", m.cls_token))
     out += [("patch_embedding.position_embeddings", m.patch_embedding.position_embeddings),

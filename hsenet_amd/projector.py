@@ -115,3 +115,52 @@ def encode_images(vision_tower, mm_projector, mm_projector2, images, images_2d):
         b = (mm_projector2 if mm_projector2 is not None else mm_projector)(f2.contiguous())
         return torch.cat([a, b], dim=1)
     return mm_projector(image_features.contiguous())
+
+
+class LamedMetaForCausalLM:
+    """The mixin form of the reference's LamedMetaForCausalLM (lamed_arch.py:114-155) for the methods on the vision path: a caller's
+    model class lists this mixin where it listed the reference's and keeps ``get_model()`` (an object with ``get_vision_tower()``,
+    ``mm_projector`` and, for the dual branch, ``mm_projector2``).  ``encode_images`` reproduces the reference's dispatch line by line in
+    behaviour: the tuple test, the token-count tests on the LAST element (2048 = the native 8x16x16 patch grid -> two packers + cat;
+    32 -> the legacy three-argument projector call), the bare-except fallback to the shared projector when ``mm_projector2`` is missing
+    or fails (:129-131), the single-tensor branch.  Like the reference, a tuple with any other token count is returned UNCHANGED (the
+    reference's caller then fails in its ``torch.cat``): geometries beyond the native one -- BASELINE configs[2]'s 256^3 volume has
+    4096 patch tokens -- are admitted by listing their token count in ``dual_token_counts``."""
+
+    dual_token_counts = (2048,)       # lamed_arch.py:125
+
+    def get_model(self):
+        raise NotImplementedError
+
+    def get_vision_tower(self):
+        return self.get_model().get_vision_tower()
+
+    def encode_images(self, images, text_feature=None, images_2d=None):
+        model = self.get_model()
+        image_features = model.get_vision_tower()(images, images_2d)
+        if isinstance(image_features, tuple):
+            n = image_features[-1].shape[1]
+            if n in self.dual_token_counts:
+                ori, sec = image_features[0], image_features[1]
+                ori = model.mm_projector(ori.contiguous())
+                try:
+                    sec = model.mm_projector2(sec.contiguous())
+                except Exception:          # (the reference's bare except, :130: no second projector -> the shared one)
+                    sec = model.mm_projector(sec.contiguous())
+                image_features = torch.cat([ori, sec], dim=1)
+            elif n == 32:
+                image_features = model.mm_projector(image_features[0], image_features[1], text_feature)
+        else:
+            image_features = model.mm_projector(image_features.contiguous())
+        return image_features
+
+    def prepare_inputs_for_multimodal(self, input_ids, position_ids, attention_mask, past_key_values, labels, images, images_2d):
+        """lamed_arch.py:143-155: image tokens replace positions 1..n of the token embeddings."""
+        vision_tower = self.get_vision_tower()
+        if vision_tower is None or images is None or input_ids.shape[1] == 1:
+            return input_ids, position_ids, attention_mask, past_key_values, None, labels
+        inputs_embeds = self.get_model().embed_tokens(input_ids)
+        image_features = self.encode_images(images, inputs_embeds, images_2d)
+        n = image_features.shape[1]
+        inputs_embeds = torch.cat((inputs_embeds[:, :1, :], image_features.to(inputs_embeds.dtype), inputs_embeds[:, (n + 1):, :]), dim=1)
+        return None, position_ids, attention_mask, past_key_values, inputs_embeds, labels

@@ -78,23 +78,32 @@ class _Rearrange(nn.Module):
 
 
 class PatchEmbeddingBlock(nn.Module):
-    """MONAI PatchEmbeddingBlock, pos_embed='perceptron' (ctor call vit.py:428-437, use :455)."""
+    """MONAI PatchEmbeddingBlock (ctor call vit.py:428-437, use :455): pos_embed='perceptron' (Rearrange + Linear: every shipped call
+    site) or 'conv' (the constructors' default, vit.py:237,375: Conv3d with kernel = stride = patch, then flatten(2).transpose(-1, -2),
+    MONAI 1.3.0 patchembedding.py forward)."""
 
     def __init__(self, in_channels, img_size, patch_size, hidden_size, num_heads,
                  pos_embed="perceptron", dropout_rate=0.0, spatial_dims=3):
         super().__init__()
-        if pos_embed != "perceptron":
-            raise ValueError("oracle restates pos_embed='perceptron' only (the only one on the hot path)")
+        if pos_embed not in ("perceptron", "conv"):
+            raise ValueError("pos_embed: 'perceptron' or 'conv'")
+        self.pos_embed = pos_embed
         img_size = tuple(img_size)
         patch_size = tuple(patch_size)
         self.n_patches = int(np.prod([i // p for i, p in zip(img_size, patch_size)]))
         self.patch_dim = int(in_channels * np.prod(patch_size))
-        self.patch_embeddings = nn.Sequential(_Rearrange(patch_size), nn.Linear(self.patch_dim, hidden_size))
+        if pos_embed == "conv":
+            self.patch_embeddings = nn.Conv3d(in_channels, hidden_size, kernel_size=patch_size, stride=patch_size)
+        else:
+            self.patch_embeddings = nn.Sequential(_Rearrange(patch_size), nn.Linear(self.patch_dim, hidden_size))
         self.position_embeddings = nn.Parameter(torch.zeros(1, self.n_patches, hidden_size))
         self.dropout = nn.Dropout(dropout_rate)
         nn.init.trunc_normal_(self.position_embeddings, mean=0.0, std=0.02, a=-2.0, b=2.0)
 
     def forward(self, x):
+        if self.pos_embed == "conv":
+            x = self.patch_embeddings(x).flatten(2).transpose(-1, -2)
+            return self.dropout(x + self.position_embeddings)
         t = self.patch_embeddings[0](x)
         lin = self.patch_embeddings[1]
         x = _linear(t, lin.weight, lin.bias)

@@ -118,6 +118,40 @@ def test_plumbing_vit_small_128(dev, golden, prec, tol):
         H.set_precision("bf16")
 
 
+@pytest.mark.parametrize("prec,tol", [("f32", TOL_F32), ("bf16", TOL_BF16)])
+def test_conv_patch_embedding_vs_oracle(dev, prec, tol):
+    """pos_embed='conv' (the constructors' default, vit.py:237,375; MONAI Conv3d patch embedding): forward and the gradients of the
+    conv weight / bias / position embedding vs the oracle's F.conv3d form, 2 input channels (so the weight re-ordering is not trivial)."""
+    import hsenet_amd as H
+    from oracle import ref_cpu as R
+    kw = dict(in_channels=2, img_size=(8, 64, 64), patch_size=(4, 16, 16), num_layers=2, pos_embed="conv", classification=True)
+    ref = R.ViT_stage1(**kw).eval()
+    sd = R.seeded_state_dict(ref, 4242)
+    ref.load_state_dict(sd)
+    x = R.synthetic_volume((2, 2, 8, 64, 64), 4243)
+    yr, _ = ref(x)
+    (yr * yr).mean().backward()
+    H.set_precision(prec)
+    try:
+        m = H.ViT_stage1(**kw).eval()
+        m.load_state_dict(sd)
+        m = m.to(dev)
+        y, _ = m(x.to(dev))
+        (y * y).mean().backward()
+    finally:
+        H.set_precision("bf16")
+    e = rel(y.detach(), yr.detach())
+    gw = rel(m.patch_embedding.patch_embeddings.weight.grad, ref.patch_embedding.patch_embeddings.weight.grad)
+    gb = rel(m.patch_embedding.patch_embeddings.bias.grad, ref.patch_embedding.patch_embeddings.bias.grad)
+    gp = rel(m.patch_embedding.position_embeddings.grad, ref.patch_embedding.position_embeddings.grad)
+    print(f"conv patch embedding {prec}: fwd {e:.2e}; grads conv.weight {gw:.2e} conv.bias {gb:.2e} pos {gp:.2e}")
+    assert e < tol and max(gw, gb, gp) < (1e-3 if prec == "f32" else 3e-2)
+    from hsenet_amd import _lib as L
+    from hsenet_amd.engine import FlatEncoder
+    with pytest.raises(L.HsError):
+        FlatEncoder(m, 2)                     # the fused engines drive the perceptron form only
+
+
 class Cfg:
     vision_select_layer = -1
     vision_select_feature = "patch"
@@ -161,6 +195,19 @@ def test_native_dual_tower_and_packers(dev, golden, prec, tol):
             e = rel(y[:, list(g["enc_rows"])], g["enc_out_rows"]); en = rel(y.norm(dim=-1), g["enc_row_norms"])
             print(f"encode_images native {prec}: rows {e:.2e} norms {en:.2e}")
             assert e < tol and en < tol
+            # the MIXIN form (lamed_arch.py:114-141): 2048 patch tokens -> the dual branch; bit-identical to the function form, and
+            # without mm_projector2 the shared projector serves both halves (the reference's bare-except fallback)
+
+            class Model:
+                mm_projector, mm_projector2 = p1, p2
+                get_vision_tower = staticmethod(lambda: tower)
+
+            class LM(H.LamedMetaForCausalLM):
+                def get_model(self):
+                    return Model
+            assert torch.equal(LM().encode_images(x, None, s), y)
+            del Model.mm_projector2
+            assert torch.equal(LM().encode_images(x, None, s), H.encode_images(tower, p1, None, x, s))
     finally:
         H.set_precision("bf16")
 
