@@ -18,6 +18,8 @@ def test_algorithmic_flops_are_the_survey_numbers():
     dual = bench.flops_per_volume("dual256", Np, Pd)
     assert abs(dual / 3.0 - 2.717e12) < 1e9 and abs(dual - 8.15e12) < 5e9           # configs[2]: C3 forward 2.717e12
     assert abs(bench.flops_per_volume("clip_c4a", Np, Pd) - 5.39e12) < 2e10         # configs[3], the reference-faithful C4-A step
+    assert abs(bench.flops_per_volume("clip_c4b", Np, Pd) - 8.07e12) < 3e10         # both trainable, 6 forward units
+    assert abs(bench.flops_per_volume("clip_s1", Np, Pd) - 4.0215e12) < 1e9          # the stage-1 CLIP step = one encoder forward + backward
     # the native geometry (32x256x256, patch 4x16x16): ViT-B forward 5.061e11
     assert abs(bench.flops_per_volume("vit256", 2048, 1024) / 3.0 - 5.061e11) < 1e8
 
@@ -28,12 +30,16 @@ def test_default_batch_and_pmc_summary_are_consistent():
     blocks = bench.DEFAULT_BATCH * 33 * 12                   # attention-backward grid: 33 blocks of 128 keys/queries x 12 heads per volume
     assert abs(blocks / 512.0 - round(blocks / 512.0)) < 0.02 and blocks / 512.0 < round(blocks / 512.0)      # just under a whole number of rounds
     pmc = bench.measured_pmc("attn_bwd_dkdv", bench.DEFAULT_BATCH, "dual256")
-    assert pmc and pmc["source"].startswith("profiles/") and pmc["hbm_bytes_per_launch"] > 1e9 and 0.4 < pmc["mfma_busy_frac"] < 0.8
+    assert pmc and pmc["source"] == "profiles/r04_pmc.json" and pmc["hbm_bytes_per_launch"] > 1e9 and 0.4 < pmc["mfma_busy_frac"] < 0.8
+    # round 4: FETCH_SIZE and WRITE_SIZE are kept apart in the committed summary (the verdict's item 3(0)), and sum to the total
+    e = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc.json")))
+    for k in ("gemm_nt16_bias_gelu", "gemm_nt16_dgelu", "gemm_tn_group", "attn_bwd_dkdv"):
+        assert abs(e[k]["fetch_bytes_per_launch"] + e[k]["write_bytes_per_launch"] - e[k]["hbm_bytes_per_launch"]) < 1.0, k
     assert bench.measured_pmc("attn_bwd_dkdv", 7, "dual256") == {}                  # nothing committed for that batch: traffic = null
 
 
 def test_committed_bench_line_keeps_the_contract():
-    lines = sorted(glob.glob(os.path.join(ROOT, "profiles", "r03_*_bench_dual_batch53.json")))
+    lines = sorted(glob.glob(os.path.join(ROOT, "profiles", "r04_bench_dual_batch53.json")))
     assert lines, "the bench line of the default run is committed with the profiles"
     d = json.load(open(lines[-1]))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
@@ -47,8 +53,32 @@ def test_committed_bench_line_keeps_the_contract():
     # achieved = algorithmic FLOPs per launch / average launch time (6 N^2 d per (batch, head): dV, dP, dK of SURVEY 8(d)'s 8 N^2 d backward)
     assert abs(r["flops_per_launch"] - 6.0 * 4097 ** 2 * 64 * 12 * 53) < 1e6
     assert abs(r["achieved"] - r["flops_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e12) < 1.0
+    # round 4: the north-star's own numbers ride in the line
+    a = d["attention"]
+    assert a["kernels"] == ["attn_bwd_dkdv", "attn_bwd_dq", "attn_fwd"] and abs(a["frac"] - a["credited_tflops"] / 2500.0) < 1e-3
+    per_step = 12.0 * 4097 ** 2 * 64 * 12 * 53 * 24          # (4 forward + 8 backward) N^2 d per (batch, head), 24 encoder layers per step
+    assert abs(a["credited_tflops"] - per_step * 3 / (a["total_ms"] * 1e-3) / 1e12) < 2.0       # total_ms covers the 3 instrumented steps
+    assert d["optimizer_excluded"]["value"] >= d["value"] * 0.99 and d["optimizer_excluded"]["unit"] == "CT-volumes/sec"
+    p = d["peaky_attention"]
+    assert p["attn_logit_std"] == 1.5 and p["value"] > 0 and 0 < p["attention"]["frac"] < 1 and p["roofline"]["kernel"] == "attn_bwd_dkdv"
+    assert d["f32_mode"]["value"] > 0 and d["f32_mode"]["batch_per_gpu"] == 1
+    ev = d["eval_forward"]
+    assert ev["f16"] > 0 and ev["bf16"] > 0 and ev["f32"] > 0 and ev["f16_rel_err_vs_f32"] < 1e-3 < ev["bf16_rel_err_vs_f32"]
+    assert d["batch1"]["value"] > 0 and d["config"]["grad_exchange"] == "fp32/allreduce" and d["config"]["batch_changed_from"] == 20
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     # the step is the sum of its kernels: per-class totals of the instrumented pass (3 steps) against ms_per_step
     total = sum(k["total_ms"] for k in d["kernels"]) / 3.0
     assert abs(total - d["ms_per_step"]) < 0.03 * d["ms_per_step"], (total, d["ms_per_step"])
+
+
+def test_bench_cli_has_the_round4_flags():
+    """--scaling strong / --global-batch, --attn-logit-std, --workload clip_c4b / clip_s1, the gradient-exchange options (host logic only)."""
+    import bench
+    for w in ("dual256", "vit256", "clip_c4a", "clip_c4b", "clip_s1", "native_dual", "mrg_c5"):
+        assert w in bench.GEOM
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    for flag in ("--scaling", "--global-batch", "--attn-logit-std", "--grad-wire", "--grad-algo", "--no-extras"):
+        assert f'"{flag}"' in src, flag
+    for key in ('"attention"', '"optimizer_excluded"', '"peaky_attention"', '"f32_mode"', '"eval_forward"'):
+        assert key in src, key

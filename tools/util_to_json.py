@@ -22,9 +22,9 @@ workload = sys.argv[3] if len(sys.argv) > 3 else "dual256"
 tag = sys.argv[4] if len(sys.argv) > 4 else "r04"
 # kernel-name substring -> class (= hs_prof_name() of the library's per-kernel timers); first match wins
 CLASS = [("attn_fwd_fast_kernel", "attn_fwd"), ("attn_bwd_dkdv16_w4_kernel", "attn_bwd_dkdv"), ("attn_bwd_dq2_kernel", "attn_bwd_dq"),
-         ("gemm_bf16_kernel<false, false, true, 0, true>", "gemm_nt16_plain"), ("gemm_bf16_kernel<false, false, true, 9, true>", "gemm_nt16_bias_resid"),
-         ("gemm_bf16_kernel<false, false, true, 1, true>", "gemm_nt16_bias"),
-         ("gemm_bf16_kernel<false, false, true, 67, true>", "gemm_nt16_bias_gelu"), ("gemm_bf16_kernel<false, false, true, 68, true>", "gemm_nt16_dgelu"),
+         ("gemm_bf16_kernel<false, false, true, 0, true", "gemm_nt16_plain"), ("gemm_bf16_kernel<false, false, true, 9, true", "gemm_nt16_bias_resid"),
+         ("gemm_bf16_kernel<false, false, true, 1, true", "gemm_nt16_bias"),
+         ("gemm_bf16_kernel<false, false, true, 67, true", "gemm_nt16_bias_gelu"), ("gemm_bf16_kernel<false, false, true, 68, true", "gemm_nt16_dgelu"),
          ("gemm_bf16_group_kernel<true, true", "gemm_tn_group"), ("gemm_bf16_kernel<false, false", "gemm_nt"), ("gemm_bf16_kernel<false, true", "gemm_nn"),
          ("gemm_bf16_kernel<true, true", "gemm_tn"), ("layernorm_bwd_kernel", "layernorm_bwd"), ("layernorm_fwd_kernel", "layernorm_fwd"),
          ("adamw_masked_kernel", "adamw"), ("patchify_kernel", "patchify")]
@@ -33,8 +33,12 @@ CLASS = [("attn_fwd_fast_kernel", "attn_fwd"), ("attn_bwd_dkdv16_w4_kernel", "at
 def mfma_flops(name):
     """FLOPs of one MFMA instruction of this kernel: v_mfma_f32_32x32x16_bf16 = 32768; the kernels built on 16x16x32 (the dK/dV
     sweep; the NT GEMM's 256x256 tile = gemm_bf16_kernel<..., true> with M16 as the LAST template argument) = 16384."""
-    if "dkdv16" in name or ("gemm_bf16_kernel<" in name and name.split(">")[0].rstrip().endswith("true") and name.count(",") >= 4):
+    if "dkdv16" in name:
         return 2 * 16 * 16 * 32
+    if "gemm_bf16_kernel<" in name:           # template arguments <ATR, BTR, BIG, EF, M16[, F16]>
+        targs = [t.strip() for t in name.split("gemm_bf16_kernel<")[1].split(">")[0].split(",")]
+        if len(targs) >= 5 and targs[4] == "true":
+            return 2 * 16 * 16 * 32
     return 2 * 32 * 32 * 16
 
 
