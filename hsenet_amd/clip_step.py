@@ -83,7 +83,20 @@ def _clip_flat(unit: EncoderUnit, model, n_buckets: int):
     return entries, chunks, bounds
 
 
-class ClipStage1Engine(_Engine):
+class _ClipEngine(_Engine):
+    def _gather(self, local: torch.Tensor, all_feats: torch.Tensor) -> None:
+        """collective C2: every rank's feature rows, in rank order.  A muted engine (``probe_step``: the collective-free fit probe) fills
+        only its own rows — a rank that fails inside its probe must not leave the others waiting in a collective."""
+        if self.world > 1 and not self.buckets.muted:
+            dist.all_gather_into_tensor(all_feats, local, group=self.group)
+        elif self.world > 1:
+            all_feats.zero_()
+            all_feats[self.rank * self.B:(self.rank + 1) * self.B].copy_(local)
+        else:
+            all_feats.copy_(local)
+
+
+class ClipStage1Engine(_ClipEngine):
     """The stage-1 CLIP step (CLIP_stage1.py:111-139) over an ``M3DCLIPVision_stage1``: ``train_step(images, text_features)``;
     text features: the L2-normalised cls text features [B_local, d] of the (out-of-scope) BERT tower, frozen inputs."""
 
@@ -138,7 +151,7 @@ class ClipStage1Engine(_Engine):
         L.call("hs_dot", self.dlog.data_ptr(), self.raw.data_ptr(), ls.grad.data_ptr(), 1.0, n * n, s)              # d/d logit_scale
         L.call("hs_scale_dev", self.dlog.data_ptr(), self.draw.data_ptr(), ls.data_ptr(), 1.0, n * n, s)
         L.call("hs_rowmix", self.draw.data_ptr(), all_feats.data_ptr() + 4 * col_txt * d, self.dall.data_ptr(), n, n, d, n, row_stride, d, 0, s)
-        if self.world > 1:       # backward of the all-gather (torch.distributed.nn.all_gather): sum over ranks, keep this rank's rows
+        if self.world > 1 and not self.buckets.muted:   # backward of the all-gather (torch.distributed.nn.all_gather): sum over ranks, keep this rank's rows
             dist.all_reduce(self.dall, op=dist.ReduceOp.SUM, group=self.group)
         L.call("hs_rows_copy", self.dall.data_ptr() + 4 * self.rank * B * d, d, self.head.df.data_ptr(), None, d, B, 1, d, s)
         self.head.backward()
@@ -154,10 +167,7 @@ class ClipStage1Engine(_Engine):
         f = self.head.forward()
         for i, t in enumerate((f, text_features)):
             L.call("hs_rows_copy", t.data_ptr(), d, self.local.data_ptr() + 4 * i * d, None, 2 * d, B, 1, d, s)
-        if self.world > 1:
-            dist.all_gather_into_tensor(self.all, self.local, group=self.group)                          # collective C2
-        else:
-            self.all.copy_(self.local)
+        self._gather(self.local, self.all)
         self.loss_from_all(self.all, 2 * d, 0, 1)
 
     def loss_value(self) -> float:
@@ -185,7 +195,7 @@ class ClipStage1Engine(_Engine):
         self._txt = text_features.detach().to(device=self.dev, dtype=torch.float32).contiguous()
 
 
-class ClipStage2Engine(_Engine):
+class ClipStage2Engine(_ClipEngine):
     """The stage-2 CLIP step over an ``M3DCLIPVision_stage2``.  ``train_step(images, images_2d, text_features_stage1,
     text_features)``; text features: L2-normalised [B_local, d] (frozen).  ``train_stage1=True``: the both-trainable variant (module
     docstring): ``self.s1`` is a ``ClipStage1Engine`` over ``model.stage1_pretrained_CLIP`` (whose parameters must then require grad)."""
@@ -261,10 +271,7 @@ class ClipStage2Engine(_Engine):
         torch.cuda.current_stream().wait_stream(self.side)
         for i, t in enumerate((f1, text_features_stage1, f2, text_features)):
             L.call("hs_rows_copy", t.data_ptr(), d, self.local.data_ptr() + 4 * i * d, None, 4 * d, B, 1, d, s)
-        if self.world > 1:
-            dist.all_gather_into_tensor(self.all, self.local, group=self.group)                          # collective C2
-        else:
-            self.all.copy_(self.local)
+        self._gather(self.local, self.all)
         self._logits(0, 1, self.raw1, self.logits1)                     # stage-1 logits with THIS model's logit_scale (:128), detached
         self._logits(2, 3, self.raw2, self.logits2)
         n = self.all.shape[0]
@@ -290,7 +297,7 @@ class ClipStage2Engine(_Engine):
         L.call("hs_dot", self.dlog.data_ptr(), self.raw2.data_ptr(), ls.grad.data_ptr(), 1.0, n * n, s)            # d/d logit_scale
         L.call("hs_scale_dev", self.dlog.data_ptr(), self.draw.data_ptr(), ls.data_ptr(), 1.0, n * n, s)
         L.call("hs_rowmix", self.draw.data_ptr(), self.all.data_ptr() + 4 * 3 * d, self.dall.data_ptr(), n, n, d, n, 4 * d, d, 0, s)   # d all_img = draw @ all_txt
-        if self.world > 1:       # backward of the all-gather (torch.distributed.nn.all_gather): sum over ranks, keep this rank's rows
+        if self.world > 1 and not self.buckets.muted:   # backward of the all-gather (torch.distributed.nn.all_gather): sum over ranks, keep this rank's rows
             dist.all_reduce(self.dall, op=dist.ReduceOp.SUM, group=self.group)
         L.call("hs_rows_copy", self.dall.data_ptr() + 4 * self.rank * B * d, d, self.h2.df.data_ptr(), None, d, B, 1, d, s)
         self.h2.backward()

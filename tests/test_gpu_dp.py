@@ -330,3 +330,35 @@ def test_dual_engine_rccl_world1_two_streams(dev, tmp_path):
     diff = float((single - got).norm())
     print(f"dual step on RCCL (world 1, two streams): param movement {moved:.3e}, difference {diff:.3e}")
     assert moved > 0 and diff < 2e-2 * moved
+
+
+@pytest.mark.parametrize("workload,extra", [("dual256", ["--batch", "1"]), ("dual256", ["--scaling", "strong", "--global-batch", "2"]),
+                                            ("clip_c4b", []), ("clip_s1", ["--grad-wire", "bf16", "--grad-algo", "rs_ag"])])
+def test_bench_two_rank_rehearsal(workload, extra):
+    """bench.py exactly as the driver launches it for N > 1 (python -m torch.distributed.run ... bench.py --gpus N), two ranks on the one
+    GPU of this box over gloo (HS_BENCH_BACKEND=gloo; on a multi-GPU node the same control flow runs over RCCL): per-rank collective-free
+    fit probe, the batch vote, barrier-bracketed timing with the max over ranks, ONE JSON line from rank 0, whole-job aggregate."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HS_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--workload", workload, "--no-cpu-baseline", "--no-roofline"] + extra
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    strong = "strong" in extra
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == ("strong" if strong else "weak")
+    assert d["config"]["parallelism"] == "dp2" and d["config"]["batch_per_gpu"] == 1 and d["config"]["global_batch"] == 2
+    assert d["value"] > 0 and abs(d["value"] - 2 * 1e3 / d["ms_per_step"]) < 0.02 * d["value"]        # whole-job volumes / max-over-ranks time
+    assert d["outputs_finite"] is True
+    if "--grad-wire" in extra:
+        assert d["config"]["grad_exchange"] == "bf16/rs_ag"
