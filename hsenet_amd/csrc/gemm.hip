@@ -428,7 +428,7 @@ __device__ __forceinline__ void lds_wait8g(u32x4& a, u32x4& b, u32x4& c, u32x4& 
 // of tile t (1.75 K-tiles before the barrier that needs it), B(t+2) in phase 3 of tile t (1.0 K-tile); the issue ORDER B(t+1) < A(t+2)
 // makes "everything but the newest 4 pieces" exactly the pieces barrier(t) needs (A(t+1), B(t+1)), so the wait is a counted vmcnt(4).
 //   LDS: A stages at 0 / 32 K / 64 K, B stages at 96 K / 128 K.
-template <bool F16 = false>
+template <bool F16 = false, bool PRO = true>      // PRO = false: the caller has issued the prologue pieces (gemm_nt16_persist_kernel)
 __device__ __forceinline__ void big_mainloop16(f32x4 (&acc)[8][4], char* smem, int row0, int col0, int wave, int lane,
                                                   __amdgpu_buffer_rsrc_t rsA, __amdgpu_buffer_rsrc_t rsB, const unsigned (&va)[4],
                                                   const unsigned (&vb)[4], unsigned ka, unsigned kb, int kt0, int kt1) {
@@ -471,11 +471,17 @@ __device__ __forceinline__ void big_mainloop16(f32x4 (&acc)[8][4], char* smem, i
     typedef std::integral_constant<int, 0> I0;
     typedef std::integral_constant<int, 1> I1;
     // prologue, in the order the counted waits rely on: A(0), B(0), A(1), B(1)
-    dmaA(kt0, 0u);
-    dmaB(kt0, 0u);
+    if (PRO) {
+        dmaA(kt0, 0u);
+        dmaB(kt0, 0u);
+    }
     if (kt0 + 1 < kt1) {
-        dmaA(kt0 + 1, AST);
-        dmaB(kt0 + 1, AST);
+        if (PRO) {
+            dmaA(kt0 + 1, AST);
+            dmaB(kt0 + 1, AST);
+        }
+        // (!PRO: the pieces were issued in front of the previous tile's epilogue, whose stores are YOUNGER: "at most 8 operations
+        // outstanding" then still implies A(0), B(0) landed -- loads retire in issue order -- it only also waits for most stores)
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1046,6 +1052,77 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmP p) {
     gemm_bf16_body<ATR, BTR, BIG, EF, M16, F16>(p, blockIdx.x, gridDim.x);
 }
 
+// Persistent form of the 16x16x32 NT kernel (round 4; the default whenever a launch has more tiles than CUs): ONE block per CU walks the
+// tiles b, b + gridDim, ... (gridDim a multiple of 8, so b % 8 -- the XCD -- and the tile order are what the one-tile-per-block launch
+// gives).  A block that owns all 160 KiB of LDS cannot overlap its successor's launch (3.6k cycles from a block's last instruction to the
+// next block's first, of a 46k-cycle K = 768 tile), and the first K-tiles of every output tile are compulsory L2 misses: here the next
+// tile's first two K-tiles are issued IN FRONT OF the current tile's epilogue (all five LDS stages are free after the main loop's last
+// barrier, the 16x16x32 epilogue goes from the accumulators straight to memory).  No extra synchronisation between tiles: a wave issues
+// that LDS-DMA only after the last barrier of the main loop, which every wave reaches after its last LDS read; the counted vmcnt waits
+// stay safe with the epilogue's stores in flight (loads retire in issue order, younger stores can only make a wait longer).  Measured
+// same box at 53 volumes (tools/r4_gemm2.sh): qkv 863 -> 826 us, fc1 1113 -> 1067, proj 311 -> 300, fc2 947 -> 925, fc1 + GELU 1455 ->
+// 1418-1434, x gelu' 1280 -> 1266-1274; in the engine plain 600 -> 586 us, x gelu' 1388 -> 1352, + residual 671 -> 659, + GELU 1218 -> 1205:
+// +0.34 % on the step.  What it cannot hide is the drain of the epilogue's stores: vmcnt is ONE counter for loads and stores, so the next
+// tile's first barrier is released only when (nearly) all of them have retired.
+// the first two K-tiles of an output tile, in big_mainloop16's order A(0), B(0), A(1), B(1): issued by the persistent kernel in front of the
+// PREVIOUS tile's epilogue, so that the tile's first (compulsory) L2 misses elapse under that epilogue
+__device__ __forceinline__ void prologue16(char* smem, int wave, __amdgpu_buffer_rsrc_t rsA, __amdgpu_buffer_rsrc_t rsB,
+                                           const unsigned (&va)[4], const unsigned (&vb)[4], int ktiles) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        if (t < ktiles) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dma_piece(rsA, smem + t * 32768, q, wave, va[q], (unsigned)t * 128u);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dma_piece(rsB, smem + 98304 + t * 32768, q, wave, vb[q], (unsigned)t * 128u);
+        }
+    }
+}
+template <int EF, bool F16>
+__global__ __launch_bounds__(512) void gemm_nt16_persist_kernel(GemmP p) {
+    __shared__ __attribute__((aligned(16))) char smem[163840];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int row0 = (wave >> 2) * 128, col0 = (wave & 3) * 64;
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.A, (size_t)p.M * p.lda * 2);        // (batch == 1, split_k == 1: checked by hs_gemm)
+    const __amdgpu_buffer_rsrc_t rsB = make_rsrc(p.B, (size_t)p.N * p.ldb * 2);
+    const int kt1 = p.K >> 6;                                                             // (K % 64 == 0: the 256x256 tile's condition)
+    int b = blockIdx.x, tm, tn, z;
+    tile_order(b, p.nblocks, p.tiles_m, p.tiles_n, tm, tn, z, p.gm, p.np);
+    int m0 = tm * 256, n0 = tn * 256;
+    unsigned va[4], vb[4];
+    auto offsets = [&](int m0_, int n0_) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) va[j] = dma_voff<false, true>(j, m0_, p.M, 0, 64, p.lda, wave, lane);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) vb[j] = dma_voff<false, true, true>(j, n0_, p.N, 0, 64, p.ldb, wave, lane);
+    };
+    offsets(m0, n0);
+    prologue16(smem, wave, rsA, rsB, va, vb, kt1);
+    for (;;) {
+        f32x4 acc16[8][4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc16[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        big_mainloop16<F16, false>(acc16, smem, row0, col0, wave, lane, rsA, rsB, va, vb, 128u, 128u, 0, kt1);
+        // every LDS read of this tile retired before the main loop's last barrier: all five stages are free
+        const int bn = b + (int)gridDim.x;
+        const bool more = bn < p.nblocks;
+        int m0n = 0, n0n = 0;
+        if (more) {
+            tile_order(bn, p.nblocks, p.tiles_m, p.tiles_n, tm, tn, z, p.gm, p.np);
+            m0n = tm * 256; n0n = tn * 256;
+            offsets(m0n, n0n);
+            prologue16(smem, wave, rsA, rsB, va, vb, kt1);
+        }
+        epilogue16<EF, 4, 0, F16>(p, acc16, m0 + row0, n0 + col0, 0l, lane);
+        if (!more) break;
+        b = bn; m0 = m0n; n0 = n0n;
+        offsets(m0, n0);            // recomputed (a few VALU operations) rather than kept live across the epilogue: that spilled
+    }
+}
+
 // Grouped launch: up to HS_GEMM_GROUP_MAX problems of one kernel variant in ONE grid (hs_gemm_group: the four weight-gradient
 // GEMMs of a transformer layer).  Problem i owns blocks [first[i], first[i+1]); every range starts at a multiple of 8 so that
 // (local block index) % 8 is still the XCD the block runs on, which is what tile_order builds on.
@@ -1176,11 +1253,13 @@ struct GemmEnv {
     char tile;      // 0, 'b' (big) or 's' (small)
     int gm;         // 0, or the tile order's group height
     int np;         // 0, or the tile order's panel width (column tiles)
+    int persist;    // 16x16x32 NT kernels as persistent blocks (0 / 1), HS_GEMM_PERSIST
     GemmEnv() : no_nt(getenv("HS_GEMM_NO_NT") != nullptr), no_m16(getenv("HS_GEMM_NO_M16") != nullptr), tile(0) {
         const char* t = getenv("HS_GEMM_TILE");
         if (t && (t[0] == 'b' || t[0] == 's')) tile = t[0];
         gm = getenv("HS_GEMM_GM") ? atoi(getenv("HS_GEMM_GM")) : 0;
         np = getenv("HS_GEMM_NP") ? atoi(getenv("HS_GEMM_NP")) : 0;
+        persist = getenv("HS_GEMM_PERSIST") ? atoi(getenv("HS_GEMM_PERSIST")) : 1;      // default on (round 4); 0 = one tile per block, for A/B runs
     }
 };
 const GemmEnv kEnv;
@@ -1302,10 +1381,13 @@ extern "C" int hs_gemm(const hs_gemm_args* a, int prec, void* stream) {
         const bool m16 = big && a->layout == HS_GEMM_NT && (!a->colsum_out || a->flags == (HS_EPI_GELU_BWD | HS_EPI_SAVE_DGELU)) && !kEnv.no_m16;
 #define HS_LAUNCH_M16(EF)                                                                                            \
     do {                                                                                                             \
-        if (h16) hipLaunchKernelGGL((gemm_bf16_kernel<false, false, true, EF, true, true>), grid, dim3(512), 0, s, p); \
+        if (persist && !h16) hipLaunchKernelGGL((gemm_nt16_persist_kernel<EF, false>), dim3(pgrid), dim3(512), 0, s, p); \
+        else if (h16) hipLaunchKernelGGL((gemm_bf16_kernel<false, false, true, EF, true, true>), grid, dim3(512), 0, s, p); \
         else hipLaunchKernelGGL((gemm_bf16_kernel<false, false, true, EF, true>), grid, dim3(512), 0, s, p);          \
     } while (0)
         p.nblocks = (int)grid.x;
+        const bool persist = kEnv.persist && zdim == 1 && (int)grid.x > ncu;
+        const int pgrid = ncu & ~7;
         const bool m16_ok = m16 && col8 && (f == 0 || f == HS_EPI_BIAS || f == (HS_EPI_BIAS | HS_EPI_RESID) || f == (HS_EPI_BIAS | HS_EPI_GELU | HS_EPI_SAVE_DGELU) ||
                                             (f == (HS_EPI_GELU_BWD | HS_EPI_SAVE_DGELU) && !(((uintptr_t)a->aux) & 15)));
         // profiling class = the kernel function: the four 16x16x32 instantiations are the encoder layer's hot GEMMs
@@ -1319,7 +1401,10 @@ extern "C" int hs_gemm(const hs_gemm_args* a, int prec, void* stream) {
             if (f == 0) HS_LAUNCH_M16(0);
             else if (f == HS_EPI_BIAS) HS_LAUNCH_M16(HS_EPI_BIAS);        // patch embedding, scorer / packer projections (fp32 out)
             else if (f == (HS_EPI_BIAS | HS_EPI_RESID)) HS_LAUNCH_M16(HS_EPI_BIAS | HS_EPI_RESID);
-            else if (f == (HS_EPI_GELU_BWD | HS_EPI_SAVE_DGELU)) hipLaunchKernelGGL((gemm_bf16_kernel<false, false, true, HS_EPI_GELU_BWD | HS_EPI_SAVE_DGELU, true>), grid, dim3(512), 0, s, p);
+            else if (f == (HS_EPI_GELU_BWD | HS_EPI_SAVE_DGELU)) {        // (backward only: no fp16 form)
+                if (persist) hipLaunchKernelGGL((gemm_nt16_persist_kernel<HS_EPI_GELU_BWD | HS_EPI_SAVE_DGELU, false>), dim3(pgrid), dim3(512), 0, s, p);
+                else hipLaunchKernelGGL((gemm_bf16_kernel<false, false, true, HS_EPI_GELU_BWD | HS_EPI_SAVE_DGELU, true>), grid, dim3(512), 0, s, p);
+            }
             else HS_LAUNCH_M16(HS_EPI_BIAS | HS_EPI_GELU | HS_EPI_SAVE_DGELU);
         } else if (a->layout == HS_GEMM_NT) {
             if (col8 && f == 0) HS_LAUNCH_E_NT(0);
