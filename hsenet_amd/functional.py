@@ -131,6 +131,8 @@ def cast16(x: torch.Tensor, prec: int) -> torch.Tensor:
     """fp32 -> the 16-bit operand format of `prec` (bf16 / fp16), round to nearest even."""
     if prec == L.PREC_BF16:
         return cast_bf16(x)
+    if prec != L.PREC_F16:
+        raise L.HsError("cast16: the precision has no 16-bit operand format")
     _need(x)
     y = torch.empty(x.shape, dtype=torch.float16, device=x.device)
     L.call("hs_cast_f16", x.data_ptr(), y.data_ptr(), x.numel(), _s())
