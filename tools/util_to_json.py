@@ -22,6 +22,8 @@ workload = sys.argv[3] if len(sys.argv) > 3 else "dual256"
 tag = sys.argv[4] if len(sys.argv) > 4 else "r04"
 # kernel-name substring -> class (= hs_prof_name() of the library's per-kernel timers); first match wins
 CLASS = [("attn_fwd_fast_kernel", "attn_fwd"), ("attn_bwd_dkdv16_w4_kernel", "attn_bwd_dkdv"), ("attn_bwd_dq2_kernel", "attn_bwd_dq"),
+         ("gemm_nt16_persist_kernel<0,", "gemm_nt16_plain"), ("gemm_nt16_persist_kernel<9,", "gemm_nt16_bias_resid"), ("gemm_nt16_persist_kernel<1,", "gemm_nt16_bias"),
+         ("gemm_nt16_persist_kernel<67,", "gemm_nt16_bias_gelu"), ("gemm_nt16_persist_kernel<68,", "gemm_nt16_dgelu"),
          ("gemm_bf16_kernel<false, false, true, 0, true", "gemm_nt16_plain"), ("gemm_bf16_kernel<false, false, true, 9, true", "gemm_nt16_bias_resid"),
          ("gemm_bf16_kernel<false, false, true, 1, true", "gemm_nt16_bias"),
          ("gemm_bf16_kernel<false, false, true, 67, true", "gemm_nt16_bias_gelu"), ("gemm_bf16_kernel<false, false, true, 68, true", "gemm_nt16_dgelu"),
@@ -33,7 +35,7 @@ CLASS = [("attn_fwd_fast_kernel", "attn_fwd"), ("attn_bwd_dkdv16_w4_kernel", "at
 def mfma_flops(name):
     """FLOPs of one MFMA instruction of this kernel: v_mfma_f32_32x32x16_bf16 = 32768; the kernels built on 16x16x32 (the dK/dV
     sweep; the NT GEMM's 256x256 tile = gemm_bf16_kernel<..., true> with M16 as the LAST template argument) = 16384."""
-    if "dkdv16" in name:
+    if "dkdv16" in name or "gemm_nt16_persist_kernel" in name:
         return 2 * 16 * 16 * 32
     if "gemm_bf16_kernel<" in name:           # template arguments <ATR, BTR, BIG, EF, M16[, F16]>
         targs = [t.strip() for t in name.split("gemm_bf16_kernel<")[1].split(">")[0].split(",")]
