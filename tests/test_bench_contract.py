@@ -82,3 +82,25 @@ def test_bench_cli_has_the_round4_flags():
         assert f'"{flag}"' in src, flag
     for key in ('"attention"', '"optimizer_excluded"', '"peaky_attention"', '"f32_mode"', '"eval_forward"'):
         assert key in src, key
+
+
+def test_attn_logit_std_scaling_gives_the_requested_logit_spread():
+    """--attn-logit-std / the peaky_attention leg: after scaling the q rows, logits q.k / 8 of unit-variance token rows have the requested
+    standard deviation (checked empirically on the CPU with a stand-in block list: the function only touches blk.attn.qkv.weight)."""
+    import types
+
+    import torch
+
+    import bench
+    torch.manual_seed(0)
+    d = 768
+    blocks = [types.SimpleNamespace(attn=types.SimpleNamespace(qkv=types.SimpleNamespace(weight=torch.randn(3 * d, d) * 0.02))) for _ in range(2)]
+    model = types.SimpleNamespace(blocks=blocks)
+    f = bench.set_attn_logit_std([model], 1.5)
+    assert f > 1.0
+    x = torch.randn(4096, d)                                     # LayerNorm outputs: unit variance per feature
+    for blk in blocks:
+        w = blk.attn.qkv.weight
+        q, k = x @ w[:d].t(), x @ w[d:2 * d].t()
+        logits = (q[:512, :64] @ k[:, :64].t()) / 8.0              # one 64-wide head
+        assert abs(float(logits.std()) - 1.5) < 0.15, float(logits.std())
