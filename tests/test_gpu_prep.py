@@ -78,7 +78,7 @@ def test_draws_follow_the_reference_probabilities():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("prec,tol", [("f32", 2e-5), ("bf16", 2e-2)])
+@pytest.mark.parametrize("prec,tol", [("f32", 2e-5), ("bf16", 2e-2), ("f16", 3e-3)])     # (fp16: the biased qkv projection and ln_eps options of the block driver at HS_PREC_F16)
 def test_trunk2d_and_slice_features(dev, prec, tol):
     """N4: the 2-D branch (resize to 32x224x224 + frozen BiomedCLIP-shaped ViT trunk) against its CPU restatement."""
     import hsenet_amd as H
