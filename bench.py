@@ -348,7 +348,8 @@ def build_engine(workload, geom, batch, dev, group=None):
         p1 = H.VisualPacker_3d_phi_v3(img, patch, 768, OUT_DIM, "mlp", 2, **pk).to(dev)
         p2 = H.VisualPacker_3d_phi_v3(img, patch, 768, OUT_DIM, "mlp", 2, **pk).to(dev)
         ts = os.environ.get("HS_DUAL_STREAMS")                     # (env: A/B runs only; default = the engine's batch rule)
-        eng = DualEngine(tower, p1, p2, batch, lr=1e-4, weight_decay=0.1, group=group, two_streams=None if ts is None else ts != "0", **dp)
+        eng = DualEngine(tower, p1, p2, batch, lr=1e-4, weight_decay=0.1, group=group, two_streams=None if ts is None else ts != "0",
+                         recompute_mlp=bool(os.environ.get("HS_RECOMPUTE_MLP")), **dp)
         pe = tower.vision_tower_stage1.patch_embedding
         return eng, pe, True
     if workload == "clip_s1":
@@ -442,6 +443,8 @@ def main():
     ap.add_argument("--workload", default="dual256", choices=list(GEOM))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--recompute-mlp", action="store_true", help="dual256 / native_dual: do not keep the MLP activations (46 %% of the saved "
+                    "activation bytes), re-run fc1 + GELU per layer in the backward; config.recompute says so (NOT the default headline)")
     ap.add_argument("--no-batch1", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the optimizer_excluded / peaky_attention / f32_mode / eval_forward legs")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
@@ -453,6 +456,8 @@ def main():
     ap.add_argument("--attn-logit-std", type=float, default=None, help="scale the q rows of the qkv weights so that the scaled attention "
                     "logits have this standard deviation (random init: 0.31)")
     a = ap.parse_args()
+    if a.recompute_mlp:
+        os.environ["HS_RECOMPUTE_MLP"] = "1"
     if a.grad_wire:
         os.environ["HS_GRAD_WIRE"] = a.grad_wire
     if a.grad_algo:
@@ -660,6 +665,8 @@ def main():
     }
     if batch_defaulted and a.workload == "dual256" and a.batch == DEFAULT_BATCH:
         out["config"]["batch_changed_from"] = 20          # rounds 1-2 quoted this metric at 20 volumes per GPU (same code: --batch 20)
+    if os.environ.get("HS_RECOMPUTE_MLP") and a.workload in ("dual256", "native_dual"):
+        out["config"]["recompute"] = "mlp activations re-made in the backward (one more fc1 + GELU GEMM per layer)"
     if a.attn_logit_std:
         out["config"]["attn_logit_std"] = a.attn_logit_std
         out["config"]["q_weight_factor"] = round(logit_factor, 3) if logit_factor else None

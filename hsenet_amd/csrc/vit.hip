@@ -37,6 +37,9 @@ Layout make_layout(const hs_vit_desc& c) {
     Layout L;
     const size_t M = (size_t)c.B * c.N, d = c.d, mlp = c.mlp;
     const size_t Ls = c.save_for_bwd ? c.L : 1;
+    // save_for_bwd == 2 (bf16 only): the two [rows][mlp] activations of the MLP (gelu(z) and gelu'(z): 46 % of what a layer saves) are NOT
+    // kept per layer; the backward re-runs fc1 with its GELU epilogue from the saved LN2 output (same kernel, same operands: identical bits)
+    const size_t Lm = c.save_for_bwd == 1 ? c.L : 1;
     const size_t es = c.prec == HS_PREC_F32 ? 4 : 2;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += al256(bytes); return o; };
@@ -50,8 +53,8 @@ Layout make_layout(const hs_vit_desc& c) {
     L.qkv = take(Ls * M * 3 * d * es);
     L.o = take(Ls * M * d * es);
     L.lse = take(Ls * (size_t)c.B * c.H * c.N * 4);
-    L.z = take(Ls * M * mlp * es);
-    L.a = take(Ls * M * mlp * es);
+    L.z = take(Lm * M * mlp * es);
+    L.a = take(Lm * M * mlp * es);
     L.stats = take(Ls * 4 * M * 4);
     L.fstats = take(2 * M * 4);
     const bool bwd = c.save_for_bwd != 0;
@@ -76,6 +79,8 @@ int check_desc(const hs_vit_desc* c) {
     if (c->d != c->H * 64) return HS_ERR_SHAPE;  // attention kernels are specialised for head_dim 64
     if ((c->d & 7) || (c->mlp & 7) || c->d > 1024) return HS_ERR_SHAPE;
     if (c->prec != HS_PREC_BF16 && c->prec != HS_PREC_F32 && c->prec != HS_PREC_F16) return HS_ERR_ARG;
+    if (c->save_for_bwd < 0 || c->save_for_bwd > 2) return HS_ERR_ARG;
+    if (c->save_for_bwd == 2 && c->prec != HS_PREC_BF16) return HS_ERR_ARG;   // MLP recompute: the bf16 path's option
     if (c->prec == HS_PREC_F16 && c->save_for_bwd) return HS_ERR_ARG;    // fp16 operands: forward only
     if (c->ln_eps < 0.f) return HS_ERR_ARG;
     if (c->qkv_bias && c->save_for_bwd) return HS_ERR_ARG;          // the biased projection is forward-only
@@ -134,8 +139,9 @@ extern "C" int hs_vit_blocks_fwd(const hs_vit_desc* desc, const float* x0, const
         char* qkv = w + L.qkv + ls * Md * 3 * es;
         char* o = w + L.o + ls * Md * es;
         float* lse = (float*)(w + L.lse) + ls * (size_t)c.B * c.H * c.N;
-        char* z = w + L.z + ls * (size_t)M * mlp * es;
-        char* a = w + L.a + ls * (size_t)M * mlp * es;
+        const size_t lm = c.save_for_bwd == 1 ? l : 0;
+        char* z = w + L.z + lm * (size_t)M * mlp * es;
+        char* a = w + L.a + lm * (size_t)M * mlp * es;
         float* st = (float*)(w + L.stats) + ls * 4 * (size_t)M;
         const void *wqkv, *wo, *w1, *w2;
         if (bf) {
@@ -163,7 +169,7 @@ extern "C" int hs_vit_blocks_fwd(const hs_vit_desc* desc, const float* x0, const
         RC(gemm(c.prec, HS_GEMM_NT, o, wo, M, d, d, d, d, xmid, nullptr, d, p[P_BO], xin, nullptr, nullptr, HS_EPI_BIAS | HS_EPI_RESID, 1, stream));
         RC(hs_layernorm_fwd16(xmid, nullptr, p[P_N2W], p[P_N2B], bf ? nullptr : (float*)h2, bf ? h2 : nullptr, st + 2 * M, st + 3 * M, M, d, eps, f16, stream));
         RC(gemm(c.prec, HS_GEMM_NT, h2, w1, M, mlp, d, d, d, bf ? nullptr : (float*)a, bf ? a : nullptr, mlp, p[P_B1], nullptr, nullptr,
-                c.save_for_bwd ? z : nullptr, HS_EPI_BIAS | HS_EPI_GELU | HS_EPI_SAVE_DGELU, 1, stream));
+                c.save_for_bwd == 1 ? z : nullptr, HS_EPI_BIAS | HS_EPI_GELU | HS_EPI_SAVE_DGELU, 1, stream));   // (2: gelu' is made again in the backward)
         RC(gemm(c.prec, HS_GEMM_NT, a, w2, M, d, mlp, mlp, mlp, xout, nullptr, d, p[P_B2], xmid, nullptr, nullptr, HS_EPI_BIAS | HS_EPI_RESID, 1, stream));
     }
     float* fs = (float*)(w + L.fstats);
@@ -230,8 +236,9 @@ extern "C" int hs_vit_blocks_bwd(const hs_vit_desc* desc, const float* x0, const
         const char* qkv = w + L.qkv + (size_t)l * Md * 3 * es;
         const char* o = w + L.o + (size_t)l * Md * es;
         const float* lse = (const float*)(w + L.lse) + (size_t)l * c.B * c.H * c.N;
-        const char* z = w + L.z + (size_t)l * M * mlp * es;
-        const char* a = w + L.a + (size_t)l * M * mlp * es;
+        const size_t lm = c.save_for_bwd == 1 ? l : 0;
+        char* z = w + L.z + lm * (size_t)M * mlp * es;
+        char* a = w + L.a + lm * (size_t)M * mlp * es;
         const float* st = (const float*)(w + L.stats) + (size_t)l * 4 * M;
         const void *wqkv, *wo, *w1, *w2;
         if (bf) {
@@ -250,6 +257,9 @@ extern "C" int hs_vit_blocks_bwd(const hs_vit_desc* desc, const float* x0, const
             const bf16_t* dx_in = (const bf16_t*)(w + L.dxb + (size_t)(j % 3) * dxs);
             bf16_t* dx_mid = (bf16_t*)(w + L.dxb + (size_t)((j + 1) % 3) * dxs);
             bf16_t* dx_out = (bf16_t*)(w + L.dxb + (size_t)((j + 2) % 3) * dxs);
+            if (c.save_for_bwd == 2)    // MLP recompute: gelu(z) and gelu'(z) of THIS layer again, exactly as the forward made them
+                RC(gemm(P, HS_GEMM_NT, h2, w1, M, mlp, d, d, d, nullptr, a, mlp, p[P_B1], nullptr, nullptr, z,
+                        HS_EPI_BIAS | HS_EPI_GELU | HS_EPI_SAVE_DGELU, 1, stream));
             // ---- MLP branch: x' = xm + W2 gelu(W1 h2 + b1) + b2        (db2 came with the dx that entered this layer)
             if (nt) RC(gemm(P, HS_GEMM_NT, dx_in, w2t, M, mlp, d, d, d, nullptr, dz, mlp, nullptr, nullptr, z, nullptr,
                             HS_EPI_GELU_BWD | HS_EPI_SAVE_DGELU, 1, stream, g[P_B1]));       // db1 = colsum(dz), fused in the epilogue

@@ -159,7 +159,9 @@ def encoder_flat_order(m) -> List[Tuple[str, nn.Parameter]]:
 class EncoderUnit:
     """One encoder (P4 ViT_stage1 / P6 ViT_stage2) on the fused drivers: hs_embed_* + hs_vit_blocks_*, own workspaces."""
 
-    def __init__(self, model, batch: int, trainable: bool = True):
+    def __init__(self, model, batch: int, trainable: bool = True, recompute_mlp: bool = False):
+        """recompute_mlp: do not keep the MLP's two [rows][mlp] activations per layer (46 % of the saved activation bytes: 0.6 of 1.3 GB
+        per 256^3 volume and encoder); the backward re-runs fc1 + GELU per layer (hs_vit_desc.save_for_bwd = 2; gradients bit-identical)."""
         if not isinstance(model, (ViT_stage1, ViT_stage2)):
             raise TypeError("EncoderUnit drives ViT_stage1 / ViT_stage2")
         p0 = next(model.parameters())
@@ -172,9 +174,9 @@ class EncoderUnit:
         self.has_cls = hasattr(model, "cls_token")
         self.N = self.Np + (1 if self.has_cls else 0)
         self.Ln = len(model.blocks)
-        sv = 1 if trainable else 0
+        sv = (2 if recompute_mlp else 1) if trainable else 0
         self.desc = L.VitDesc(batch, self.N, self.d, model.num_heads, model.mlp_dim, self.Ln, L.PREC_BF16, sv, 0.0, None)
-        self.edesc = L.EmbedDesc(batch, self.Np, self.Pd, self.d, int(self.has_cls), int(self.scorer), 32, sv, 0.0)
+        self.edesc = L.EmbedDesc(batch, self.Np, self.Pd, self.d, int(self.has_cls), int(self.scorer), 32, int(trainable), 0.0)
         lib = L.load()
         self.ws_bytes = lib.hs_vit_workspace_bytes(C.byref(self.desc))
         if self.ws_bytes == 0:
@@ -379,8 +381,8 @@ class FlatEncoder(_Engine):
     """One encoder with flat parameter / gradient / moment buffers and an explicit fused train step (BASELINE configs[1])."""
 
     def __init__(self, model, batch: int, *, lr=1e-4, weight_decay=0.1, max_grad_norm: Optional[float] = 1.0, n_buckets=4, group=None,
-                 grad_wire="fp32", grad_algo="allreduce"):
-        self.unit = EncoderUnit(model, batch, trainable=True)
+                 grad_wire="fp32", grad_algo="allreduce", recompute_mlp: bool = False):
+        self.unit = EncoderUnit(model, batch, trainable=True, recompute_mlp=recompute_mlp)
         self.model, self.dev, self.B = model, self.unit.dev, batch
         entries = _encoder_entries(self.unit, "")
         probe_names = [n for n, _, _ in entries]
@@ -425,12 +427,13 @@ class DualEngine(_Engine):
 
     def __init__(self, tower: ViT3DTower_dual_encoders, packer1: VisualPacker_3d_phi_v3, packer2: VisualPacker_3d_phi_v3, batch: int, *,
                  lr=1e-4, weight_decay=0.1, max_grad_norm: Optional[float] = 1.0, n_buckets=4, group=None,
-                 two_streams: Optional[bool] = None, grad_wire="fp32", grad_algo="allreduce"):
+                 two_streams: Optional[bool] = None, grad_wire="fp32", grad_algo="allreduce", recompute_mlp: bool = False):
+        """recompute_mlp: see EncoderUnit (activation memory 3.7 -> 2.5 GB per 256^3 volume for one more GEMM per layer in the backward)."""
         if tower.select_feature != "patch" or tower.remain_2d3d_ViT_type != "dual_vits":
             raise L.HsError("DualEngine drives the shipped configuration: select_feature='patch', remain_2d3d_ViT_type='dual_vits'")
         self.tower, self.B = tower, batch
-        self.u1 = EncoderUnit(tower.vision_tower_stage1, batch, True)
-        self.u2 = EncoderUnit(tower.vision_tower_stage2, batch, True)
+        self.u1 = EncoderUnit(tower.vision_tower_stage1, batch, True, recompute_mlp)
+        self.u2 = EncoderUnit(tower.vision_tower_stage2, batch, True, recompute_mlp)
         self.dev = self.u1.dev
         off1 = 1 if self.u1.has_cls else 0
         self.p1 = PackerUnit(packer1, batch, self.u1.N, off1, 2, 0, True)

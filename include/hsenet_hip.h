@@ -247,7 +247,8 @@ int hs_prof_count(void);
 typedef struct hs_vit_desc {
     int B, N, d, H, mlp, L;
     int prec;            /* HS_PREC_* */
-    int save_for_bwd;    /* 1: keep per-layer activations in ws for hs_vit_blocks_bwd */
+    int save_for_bwd;    /* 1: keep per-layer activations in ws for hs_vit_blocks_bwd; 2 (HS_PREC_BF16): the same WITHOUT the MLP's two
+                          * [rows][mlp] activations (46 % of the saved bytes): the backward re-runs fc1 + GELU per layer (+1 GEMM of 12) */
     float ln_eps;        /* LayerNorm epsilon; 0 = 1e-5 (MONAI / nn.LayerNorm default).  timm's ViT (the 2-D branch) uses 1e-6 */
     const float* const* qkv_bias;   /* NULL (MONAI SABlock, qkv_bias=False), or L device pointers to the [3d] bias of each
                                        layer's qkv Linear (timm ViT, forward only: hs_vit_blocks_bwd rejects it) */

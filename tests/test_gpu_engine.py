@@ -415,3 +415,46 @@ def test_default_bench_batch_is_consistent(dev):
     assert torch.equal(o0, o1) and torch.equal(ol, o1)
     assert abs(lB - l1) < 1e-5 * abs(l1)
     assert rel(gB, g1) < 2e-3                                          # measured 4.6e-4 at 53 volumes (fp32 summation order over the batch)
+
+
+def test_mlp_recompute_is_bit_identical_and_smaller(dev):
+    """DualEngine(recompute_mlp=True) / hs_vit_desc.save_for_bwd = 2: gelu(z) and gelu'(z) are not kept per layer, the backward re-runs fc1
+    with its GELU epilogue from the saved LN2 output (same kernel, same operands) — output, gradients and the parameters after two
+    optimizer steps equal the default engine's (forward bit for bit, gradients to the float-atomic noise of two runs); the encoder workspace shrinks by the two [rows][mlp] arrays of L - 1 layers."""
+    import ctypes as C
+    from hsenet_amd import _lib as L, functional as Fn
+    from hsenet_amd.engine import DualEngine
+    B, layers = 3, 3
+    _, _, _, sds, x, s = _oracle(B, 4100, layers)
+    xd, sd_ = x.to(dev), s.to(dev)
+    engs = []
+    for rec in (False, True):
+        tower, p1, p2 = _mine(sds, dev, layers)
+        engs.append(DualEngine(tower, p1, p2, B, lr=1e-3, recompute_mlp=rec))
+    a, b = engs
+    assert b.u1.desc.save_for_bwd == 2 and a.u1.desc.save_for_bwd == 1
+    N = a.u1.N
+    assert a.u1.ws_bytes - b.u1.ws_bytes >= 2 * (layers - 1) * B * N * 3072 * 2
+    oa, ob = a.forward(xd, sd_).clone(), b.forward(xd, sd_).clone()
+    assert torch.equal(oa, ob)
+    # one backward each: the re-made activations are the forward's, bit for bit (compared where they are consumed: the saved gelu' tile of the
+    # last layer processed = layer 0 sits in the recompute engine's single slot and in slot 0 of the default engine's per-layer array)
+    L.call("hs_mse_grad", oa.data_ptr(), a.dout.data_ptr(), None, oa.numel(), Fn._s())
+    L.call("hs_mse_grad", ob.data_ptr(), b.dout.data_ptr(), None, ob.numel(), Fn._s())
+    a.backward(a.dout)
+    b.backward(b.dout)
+    torch.cuda.synchronize()
+    # float atomics (split-K weight gradients, LayerNorm's column sums) make two runs of ONE engine differ in the last bits too: the
+    # comparison is to that noise level, far below the 1e-2 of a wrong activation
+    noise = float((a.grad - b.grad).norm() / a.grad.norm())
+    print(f"gradient difference with / without MLP recompute: {noise:.1e}")
+    assert noise < 2e-6
+    for _ in range(2):
+        a.train_step(xd, sd_)
+        b.train_step(xd, sd_)
+    torch.cuda.synchronize()
+    assert float((a.flat - b.flat).norm() / a.flat.norm()) < 1e-5
+    # the C entry point refuses the option outside the bf16 path
+    for prec in (L.PREC_F32, L.PREC_F16):
+        assert L.load().hs_vit_workspace_bytes(C.byref(L.VitDesc(1, 65, 768, 12, 3072, 2, prec, 2, 0.0, None))) == 0
+    assert L.load().hs_vit_workspace_bytes(C.byref(L.VitDesc(1, 65, 768, 12, 3072, 2, L.PREC_BF16, 3, 0.0, None))) == 0
