@@ -8,7 +8,7 @@ fwd + bwd of all four modules + DP gradient all-reduce (RCCL) + clipped AdamW; b
 residual stream; `--batch` volumes per GPU (default 53: see DEFAULT_BATCH), synthetic U[0,1) volumes and N(0,1) slice features already resident in HBM,
 random-init weights.  A "step" = one such train step over one batch.
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without WORLD_SIZE: starts the N ranks itself, one per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -434,6 +434,28 @@ def timed_run(eng, needs_2d, vols, slices, steps, warmup, sync, optimizer=True):
     return time.perf_counter() - t0, step
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment: start the N ranks here, as the reference's launcher does
+    (script/train_clip_stage1.sh:4 `accelerate launch`, README.md:78-105: 8 processes), and exit with their status.  Called BEFORE anything
+    in this process touches the GPU (torch.cuda.device_count() does not initialise it on this image); the ranks are fresh children of
+    `python -m torch.distributed.run`, never a re-exec of this process.  Refuses (exit 2) when fewer than N devices are visible -- unless
+    HS_BENCH_BACKEND=gloo asks for the one-GPU rehearsal of the N-rank control flow."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n and os.environ.get("HS_BENCH_BACKEND", "nccl") == "nccl":
+        sys.stderr.write(f"bench.py: --gpus {n} but only {have} GPU(s) are visible; not printing a line for a different world size\n")
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    print(f"[bench] starting {n} ranks: {' '.join(cmd[1:8])} bench.py ...", file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -456,6 +478,10 @@ def main():
     ap.add_argument("--attn-logit-std", type=float, default=None, help="scale the q rows of the qkv weights so that the scaled attention "
                     "logits have this standard deviation (random init: 0.31)")
     a = ap.parse_args()
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(launch_ranks(a.gpus, sys.argv[1:]))
+    if int(os.environ.get("WORLD_SIZE", "1")) != a.gpus:
+        sys.exit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE', '1')}: the line's n_gpus must be the --gpus that was asked for")
     if a.recompute_mlp:
         os.environ["HS_RECOMPUTE_MLP"] = "1"
     if a.grad_wire:
@@ -492,8 +518,6 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
-    if a.gpus != world and rank == 0:
-        print(f"[bench] note: --gpus {a.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
 
     from hsenet_amd import _lib as L
     from hsenet_amd.engine import profile_classes

@@ -154,7 +154,24 @@ def load() -> C.CDLL:
             fn.argtypes = args
             fn.restype = _RESTYPE.get(name, C.c_int)
         _lib = lib
+        _warn_if_stale(lib)
     return _lib
+
+
+def _warn_if_stale(lib) -> None:
+    """every consumer (tests, bench.py, the modules) comes through load(): say so ONCE when the shared object was not built from the
+    sources in this tree (an edited .hip file without a rebuild).  build() / smoke() raise instead (check_fresh); an HS_LIB_PATH
+    ablation build and a tree without its csrc/ sources are exempt."""
+    if os.environ.get("HS_LIB_PATH"):
+        return
+    try:
+        from .build import source_id
+        have, want = lib.hs_build_id().decode(), source_id()
+    except Exception:       # noqa: BLE001 - no sources / no hipcc to hash: nothing to compare against
+        return
+    if have != want:
+        import warnings
+        warnings.warn(f"{LIB_PATH} is STALE: built from sources {have}, the tree is {want} (run `python -m hsenet_amd.build`)", RuntimeWarning, stacklevel=3)
 
 
 def build_id() -> str:

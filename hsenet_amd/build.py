@@ -48,7 +48,20 @@ def source_id(src: str = None) -> str:
         h.update(" ".join(FLAGS + EXTRA.get(n, [])).encode())
     for f in _hdrs():
         h.update(open(f, "rb").read())
+    h.update(_toolchain_id().encode())
     return h.hexdigest()[:16]
+
+
+def _toolchain_id() -> str:
+    """the compiler's identity without running it (this is hashed on every library load): the ROCm release stamp of the toolchain
+    hipcc belongs to; an object built by another ROCm release is stale."""
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    root = os.path.dirname(os.path.dirname(os.path.realpath(exe)))
+    for cand in (os.path.join(root, ".info", "version"), "/opt/rocm/.info/version"):
+        v = _read(cand)
+        if v:
+            return "rocm " + v
+    return "rocm ?"
 
 
 def _read(path: str) -> str:

@@ -1352,7 +1352,13 @@ extern "C" int hs_gemm(const hs_gemm_args* a, int prec, void* stream) {
         // (more than ncu/2 big tiles), and loses by 30-37 % below that (one round of half-size tiles)
         p.tiles_m = (a->M + 255) / 256;
         const long big_blocks = (long)p.tiles_m * ((a->N + 255) / 256) * zdim;
-        static const int ncu = [] { int dev = 0, n = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+        // CU count of the CURRENT device, cached per device ordinal (a process may drive several)
+        static int ncu_of[64] = {0};
+        int dev_ = 0;
+        (void)hipGetDevice(&dev_);
+        dev_ &= 63;
+        if (!ncu_of[dev_]) { int n = 0; (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev_); ncu_of[dev_] = n > 0 ? n : 256; }
+        const int ncu = ncu_of[dev_];
         // (kEnv.tile: 'b' / 's' force the NT / NN tile for A/B runs; the TN kernel only exists with the 256x128 tile)
         const bool big = !(a->K & 63) && a->layout != HS_GEMM_TN && (kEnv.tile ? kEnv.tile == 'b' : 2 * big_blocks > ncu);
         p.tiles_n = (a->N + (big ? 255 : 127)) / (big ? 256 : 128);
@@ -1386,7 +1392,8 @@ extern "C" int hs_gemm(const hs_gemm_args* a, int prec, void* stream) {
         else hipLaunchKernelGGL((gemm_bf16_kernel<false, false, true, EF, true>), grid, dim3(512), 0, s, p);          \
     } while (0)
         p.nblocks = (int)grid.x;
-        const bool persist = kEnv.persist && zdim == 1 && (int)grid.x > ncu;
+        // (the persistent kernel carries no debug stamps: a hook build's HS_DBG modes select the one-tile kernel they instrument)
+        const bool persist = kEnv.persist && zdim == 1 && (int)grid.x > ncu && !HS_DBG(p.dbg_);
         const int pgrid = ncu & ~7;
         const bool m16_ok = m16 && col8 && (f == 0 || f == HS_EPI_BIAS || f == (HS_EPI_BIAS | HS_EPI_RESID) || f == (HS_EPI_BIAS | HS_EPI_GELU | HS_EPI_SAVE_DGELU) ||
                                             (f == (HS_EPI_GELU_BWD | HS_EPI_SAVE_DGELU) && !(((uintptr_t)a->aux) & 15)));

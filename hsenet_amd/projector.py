@@ -13,6 +13,7 @@ import torch
 import torch.nn as nn
 
 from . import functional as Fn
+from ._lib import HsError
 from .encoder import _prec
 
 
@@ -145,6 +146,8 @@ class LamedMetaForCausalLM:
                 ori = model.mm_projector(ori.contiguous())
                 try:
                     sec = model.mm_projector2(sec.contiguous())
+                except HsError:            # a HIP launch / shape / dtype failure is an error, not "no second projector"
+                    raise
                 except Exception:          # (the reference's bare except, :130: no second projector -> the shared one)
                     sec = model.mm_projector(sec.contiguous())
                 image_features = torch.cat([ori, sec], dim=1)

@@ -6,10 +6,15 @@ size 1 (gather_features is then the identity, utils/dist_utils.py:280-306), with
 (out of scope; BASELINE configs[3] trains against frozen text embeddings), plus the embedding splice of
 prepare_inputs_for_multimodal (lamed_arch.py:151-154).
 
-Pinning: CLIP_stage2.py cannot be imported here (BertModel.from_pretrained weights, the LaMed package path and open_clip at module
-scope — ordinary import errors, nothing was denied), so these ~40 lines are restated from the source text and are **parity
-unpinned** against the reference class itself; the encoders they call are the pinned oracle classes of ref_cpu.py, and the loss
-pieces are checked against torch.nn.functional identities in tests/test_oracle.py.
+Pinning (round 5): pinned against the reference classes RUN here.  oracle/make_goldens.py --only clip imports
+LaMed.src.model.CLIP_stage1 / CLIP_stage2 as the reference's own package (sys.modules stand-ins for the absent third-party monai /
+open_clip exactly as for vit.py; BertModel.from_pretrained -> a random-init one-layer BertModel of the same width because no BERT
+weights exist offline; AutoModel.from_pretrained -> the stage-1 instance), feeds the reference's own encode_text outputs to the
+classes below with identical seeded vision weights, and asserts loss / both logits / every vision gradient equal (<= 1e-6 / 2e-5)
+for stage 1 and for stage 2 at global_step in {0, 1000, 5000, 6000, None}, local_loss in {False, True}, gather_loss in {True,
+False}, at world size 1 and -- two gloo processes running the reference -- at world size 2.  The reference's outputs are committed as
+tests/golden/clip_ref.npz (tiny geometry) and tests/golden/clip_c4a_256.npz (BASELINE configs[3] at full size: the reference's own
+forward + autograd); tests/test_oracle.py re-checks this file against both without the reference present.
 """
 from __future__ import annotations
 
@@ -33,12 +38,18 @@ def relation_loss_weight(global_step, max_weighted_step=5000):
 
 
 def image_text_contrastive_learning(image_features, text_features, logit_scale, local_loss=False, world=1, rank=0,
-                                    all_image_features=None, all_text_features=None):
-    """CLIP_stage2.py:170-185.  At world 1 the gathered features are the inputs; for the local_loss branch the caller may pass
-    the features of every rank to restate what rank `rank` computes."""
+                                    all_image_features=None, all_text_features=None, gather_loss=True):
+    """CLIP_stage1.py:141-155 / CLIP_stage2.py:170-185.  At world 1 the gathered features are the inputs; at world > 1 the caller
+    passes the features of every rank (rank order) to restate what rank `rank` computes.  Labels are the collator's
+    (train/train_CLIP_stage1.py:146-151): arange(global batch) with gather_loss, arange(local batch) without; with local_loss a
+    rank's rows carry rank * B_local + arange(B_local)."""
     ai = image_features if all_image_features is None else all_image_features
     at = text_features if all_text_features is None else all_text_features
-    if local_loss:
+    if not gather_loss:                                                                                            # :150-152 / :180-182
+        lpi = logit_scale * image_features @ text_features.T
+        lpt = logit_scale * text_features @ image_features.T
+        labels = torch.arange(image_features.shape[0])
+    elif local_loss:
         lpi = logit_scale * image_features @ at.T
         lpt = logit_scale * text_features @ ai.T
         labels = rank * image_features.shape[0] + torch.arange(image_features.shape[0])
@@ -58,27 +69,36 @@ def image_text_relation_regulation(lpi, lpt, lpi_masked, lpt_masked):
 class M3DCLIPVision_stage1(nn.Module):
     """CLIP_stage1.py:56-102 minus the text tower."""
 
-    def __init__(self, img_size, patch_size, num_layers=12):
+    def __init__(self, img_size, patch_size, num_layers=12, gather_loss=True, local_loss=False):
         super().__init__()
         self.vision_encoder = R.ViT_stage1(in_channels=1, img_size=img_size, patch_size=patch_size, num_layers=num_layers,
                                            pos_embed="perceptron", classification=True)
         self.mm_vision_proj = nn.Linear(768, 768)
         self.logit_scale = nn.Parameter(torch.ones([]) * math.log(1 / 0.07))
+        self.gather_loss, self.local_loss = gather_loss, local_loss
 
     def encode_image(self, image):
         return R.clip_encode_image(self.vision_encoder, self.mm_vision_proj, image)
 
-    def forward(self, images, text_features, global_step=None):
-        """CLIP_stage1.py:111-139 with the text tower's cls features given."""
+    def forward(self, images, text_features, global_step=None, world=1, rank=0):
+        """CLIP_stage1.py:111-139 with the text tower's cls features given.  world > 1: `images` / `text_features` hold the GLOBAL
+        batch in rank order and the result is what rank `rank` computes (its own slice as the local features)."""
         img = self.encode_image(images)[:, 0]
-        loss, lpi, lpt = image_text_contrastive_learning(img, text_features, self.logit_scale)                   # :121
+        loss, lpi, lpt = _rank_view(self, img, text_features, self.logit_scale, world, rank)                     # :120
         return {"loss": loss, "logits": (lpi + lpt) / 2.0}
+
+
+def _rank_view(m, img_all, txt_all, logit_scale, world, rank):
+    b = img_all.shape[0] // world
+    sl = slice(rank * b, (rank + 1) * b)
+    return image_text_contrastive_learning(img_all[sl], txt_all[sl], logit_scale, m.local_loss, world, rank, img_all, txt_all,
+                                           m.gather_loss)
 
 
 class M3DCLIPVision_stage2(nn.Module):
     """CLIP_stage2.py:58-169 minus the text towers: text features are inputs."""
 
-    def __init__(self, img_size, patch_size, num_layers=12):
+    def __init__(self, img_size, patch_size, num_layers=12, gather_loss=True, local_loss=False):
         super().__init__()
         self.vision_encoder = R.ViT_stage2(in_channels=1, img_size=img_size, patch_size=patch_size, num_layers=num_layers,
                                            pos_embed="perceptron", classification=True)
@@ -86,16 +106,18 @@ class M3DCLIPVision_stage2(nn.Module):
         self.stage1_pretrained_CLIP = M3DCLIPVision_stage1(img_size, patch_size, num_layers)
         self.stage1_pretrained_CLIP.requires_grad_(False)
         self.logit_scale = nn.Parameter(torch.ones([]) * math.log(1 / 0.07))
+        self.gather_loss, self.local_loss = gather_loss, local_loss
 
     def encode_image(self, image, images_2d):
         return R.clip_encode_image(self.vision_encoder, self.mm_vision_proj, image, images_2d)
 
-    def forward(self, images, text_features_stage1, text_features, images_2d, global_step=None):
+    def forward(self, images, text_features_stage1, text_features, images_2d, global_step=None, world=1, rank=0):
+        """CLIP_stage2.py:119-169.  world > 1: every input holds the GLOBAL batch in rank order; returns rank `rank`'s results."""
         with torch.no_grad():       # the reference uses inference_mode (:124); no_grad keeps the tensors usable below
             img1 = self.stage1_pretrained_CLIP.encode_image(images)[:, 0]
-        _, lpi1, lpt1 = image_text_contrastive_learning(img1, text_features_stage1, self.logit_scale)            # :128
+        _, lpi1, lpt1 = _rank_view(self, img1, text_features_stage1, self.logit_scale, world, rank)              # :128 (THIS module's scale and flags)
         img2 = self.encode_image(images, images_2d)[:, 0]
-        loss_cl, lpi2, lpt2 = image_text_contrastive_learning(img2, text_features, self.logit_scale)            # :137
+        loss_cl, lpi2, lpt2 = _rank_view(self, img2, text_features, self.logit_scale, world, rank)               # :137
         loss_rel = image_text_relation_regulation(lpi1.detach(), lpt1.detach(), lpi2, lpt2)                     # :139
         w = relation_loss_weight(global_step)
         return {"loss": loss_cl + w * loss_rel, "logits": (lpi2 + lpt2) / 2.0, "loss_CL_stage2": loss_cl, "loss_relation": loss_rel}

@@ -322,30 +322,384 @@ def grads(vit, spp):
     print(f"grad_vit256_stage1 ok (restatement vs reference gradients: worst {worst:.1e})")
 
 
-def clip_c4a():
-    """BASELINE configs[3] at full geometry (256^3 / 16^3, L = 12), 2 volumes, global step 1000: loss pieces, logits and the gradient
-    fixture of every trainable tensor of the stage-2 CLIP step, from the ORACLE's restatement (oracle/clip_cpu.py — CLIP_stage2.py
-    itself cannot be imported, see that file's header: this fixture pins the HIP step to the oracle at full size, it does not pin
-    the oracle's ~40 lines of loss glue to the reference; the encoders inside are the classes the fixtures above validate)."""
+# --------------------------------------------------------------------------------------
+# the CLIP wrappers (round 5): M3DCLIP_stage1 / M3DCLIP_stage2 themselves, run here
+# --------------------------------------------------------------------------------------
+PREPRINT = "/root/reference/Preprint"
+BERT_KW = dict(hidden_size=768, num_hidden_layers=1, num_attention_heads=12, intermediate_size=1536, vocab_size=30522)
+
+
+def load_reference_clip():
+    """Import LaMed.src.model.CLIP_stage1 / CLIP_stage2 as the reference's own package (its absolute imports need Preprint/ on the
+    path).  Absent third-party pieces get stand-ins, as for vit.py: monai's two blocks = the oracle's restatement, open_clip = an
+    empty module (only touched when config.use_mask and config.use_2D_Encoder), BertModel.from_pretrained = a random-init ONE-layer
+    BertModel of the same width (no BERT weights exist offline; the text towers are out of scope and only their OUTPUTS are used:
+    the reference's own encode_text results are what the oracle is fed)."""
+    load_reference()
+    if PREPRINT not in sys.path:
+        sys.path.insert(0, PREPRINT)
+    import transformers
+    from transformers import BertConfig, BertModel
+
+    def _bert(path, *a, **k):
+        return BertModel(BertConfig(**BERT_KW))
+    BertModel.from_pretrained = staticmethod(_bert)
+    import LaMed.src.model.CLIP_stage1 as c1
+    import LaMed.src.model.CLIP_stage2 as c2
+    assert c1.BertModel is transformers.BertModel
+    return c1, c2
+
+
+def _ref_clip_models(c1, c2, img, patch, L, gather_loss, local_loss, seed_w, torch_seed=5):
+    """(reference M3DCLIP_stage2 holding a reference M3DCLIP_stage1, oracle M3DCLIPVision_stage2) with identical seeded vision
+    weights; BERT / mm_language_proj keep their torch.manual_seed init (they only produce the text features)."""
     from oracle import clip_cpu as RC
-    img, patch, B, step = (256, 256, 256), (16, 16, 16), 2, 1000
-    m = RC.M3DCLIPVision_stage2(img, patch).eval()
-    sd = R.seeded_state_dict(m, 91)
+    torch.manual_seed(torch_seed)
+    kw = dict(language_model_name_or_path="none", img_size=img, patch_size=patch, num_layers=L, gather_loss=gather_loss, local_loss=local_loss)
+    s1 = c1.M3DCLIP_stage1(c1.M3DCLIPConfig_stage1(**kw)).eval()
+    c2.AutoModel.from_pretrained = staticmethod(lambda path, **k: s1)                         # CLIP_stage2.py:87
+    s2 = c2.M3DCLIP_stage2(c2.M3DCLIPConfig_stage2(pretrained_model="none", use_mask=False, use_2D_Encoder=False, **kw)).eval()
+    ora = RC.M3DCLIPVision_stage2(img, patch, L, gather_loss=gather_loss, local_loss=local_loss).eval()
+    sd = R.seeded_state_dict(ora, seed_w)
     sd["logit_scale"] = torch.tensor(float(np.log(1 / 0.07)))
-    sd["stage1_pretrained_CLIP.logit_scale"] = torch.tensor(float(np.log(1 / 0.07)))
-    m.load_state_dict(sd)
+    sd["stage1_pretrained_CLIP.logit_scale"] = torch.tensor(float(np.log(1 / 0.05)))          # differs: :128 must use the OUTER scale
+    ora.load_state_dict(sd)
+    missing, unexpected = s2.load_state_dict(sd, strict=False)
+    assert not unexpected and all("language" in k for k in missing), (missing[:4], unexpected[:4])
+    assert all(not p.requires_grad for p in s2.stage1_pretrained_CLIP.parameters())
+    return s2, ora
+
+
+def _tokens(B, seed):
+    g = np.random.default_rng(seed)
+    ids = torch.from_numpy(g.integers(1000, 30000, size=(B, 12)))
+    mask = torch.ones(B, 12, dtype=torch.long)
+    mask[:, 9:] = 0
+    return ids, mask
+
+
+def _clip_world_worker(rank, world, port, cases, q):
+    """one rank of the reference at world size `world` (gloo): per case, this rank's loss / logits and its local vision gradients."""
+    import torch.distributed as dist
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    c1, c2 = load_reference_clip()
+    out = {}
+    for tag, (stage, img, patch, L, B, step, gather_loss, local_loss, seeds) in cases.items():
+        s2, _ = _ref_clip_models(c1, c2, img, patch, L, gather_loss, local_loss, seeds[0])
+        x, s = R.synthetic_volume((B * world, 1) + img, seeds[1]), R.synthetic_slices(B * world, seeds[2])
+        ids, mask = _tokens(B * world, seeds[3])
+        sl = slice(rank * B, (rank + 1) * B)
+        if not gather_loss:
+            labels = torch.arange(B)
+        elif local_loss:
+            labels = rank * B + torch.arange(B)
+        else:
+            labels = torch.arange(B * world)
+        if stage == 1:
+            s2 = s2.stage1_pretrained_CLIP
+            s2.requires_grad_(True)
+            r = s2(x[sl], ids[sl], mask[sl], labels, global_step=step)
+        else:
+            r = s2(x[sl], ids[sl], mask[sl], labels, s[sl], global_step=step)
+        r["loss"].backward()
+        grads = {n: p.grad.numpy().copy() for n, p in s2.named_parameters() if p.requires_grad and p.grad is not None and "language" not in n}
+        out[tag] = dict(loss=float(r["loss"].detach()), logits=r["logits"].detach().numpy().copy(), grads=grads)     # numpy: pickled by value
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def clip_ref():
+    """tests/golden/clip_ref.npz: the reference's M3DCLIP_stage1.forward (CLIP_stage1.py:111-155) and M3DCLIP_stage2.forward
+    (CLIP_stage2.py:119-190) at a small geometry, every branch; oracle/clip_cpu.py is asserted equal to each before it is written."""
+    import torch.distributed as dist
+    import torch.multiprocessing as mp
+    from oracle import clip_cpu as RC
+    c1, c2 = load_reference_clip()
+    if not dist.is_initialized():
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:29541", rank=0, world_size=1)   # gather_features needs a group (train_CLIP_stage1.py:31-38)
+    img, patch, L, B = (8, 64, 64), (4, 16, 16), 2, 4
+    seeds = dict(seed_w=101, seed_x=102, seed_s=103, seed_tok=104)
+    x, s = R.synthetic_volume((B, 1) + img, 102), R.synthetic_slices(B, 103)
+    ids, mask = _tokens(B, 104)
+    labels = torch.arange(B)
+    fx = dict(img=np.array(img), patch=np.array(patch), layers=L, batch=B, **seeds, scale_outer=float(np.log(1 / 0.07)),
+              scale_inner=float(np.log(1 / 0.05)))
+    worst = 0.0
+    for gather_loss, local_loss, ftag in ((True, False, "g"), (True, True, "l"), (False, False, "n")):
+        s2, ora = _ref_clip_models(c1, c2, img, patch, L, gather_loss, local_loss, 101)
+        with torch.no_grad():
+            t1 = s2.stage1_pretrained_CLIP.encode_text(ids, mask)[0][:, 0].clone()
+            t2 = s2.encode_text(ids, mask)[0][:, 0].clone()
+        if ftag == "g":
+            fx.update(text1=t1.numpy(), text2=t2.numpy(), stage2_keys=np.array(list(s2.state_dict().keys())),
+                      stage1_keys=np.array(list(s2.stage1_pretrained_CLIP.state_dict().keys())),
+                      stage2_shapes=np.array([str(tuple(v.shape)) for v in s2.state_dict().values()]))
+        # ---- stage 1, all three branches (its own logit_scale and flags; CLIP_stage1.py:111-155)
+        s1, o1 = s2.stage1_pretrained_CLIP, ora.stage1_pretrained_CLIP
+        s1.local_loss, s1.gather_loss, o1.local_loss, o1.gather_loss = local_loss, gather_loss, local_loss, gather_loss
+        s1.requires_grad_(True), o1.requires_grad_(True)
+        rr = s1(x, ids, mask, labels, global_step=500)
+        ro = o1(x, t1, global_step=500)
+        worst = max(worst, _eq(ro["loss"].detach(), rr["loss"].detach(), f"stage-1 loss {ftag}"),
+                    _eq(ro["logits"].detach(), rr["logits"].detach(), f"stage-1 logits {ftag}"))
+        rr["loss"].backward(), ro["loss"].backward()
+        named_r = [(n, p) for n, p in s1.named_parameters() if "language" not in n]
+        worst = max(worst, _grads_equal(list(o1.named_parameters()), named_r, f"stage-1 CLIP step {ftag}"))
+        fx.update(_grad_fixture(named_r, f"s1{ftag}grad"))
+        fx[f"s1_{ftag}_loss"], fx[f"s1_{ftag}_logits"] = float(rr["loss"].detach()), rr["logits"].detach().numpy()
+        s1.requires_grad_(False), o1.requires_grad_(False)
+        s1.zero_grad(), o1.zero_grad()
+        if ftag != "g":
+            # CLIP_stage2.py:124-128: the stage-1 features are INFERENCE tensors; only the gathered non-local branch routes them
+            # through all_gather + cat before the product with logit_scale, the other two branches multiply them directly and
+            # autograd refuses ("Inference tensors cannot be saved for backward"): the reference's stage 2 runs in branch "g" only.
+            try:
+                s2(x, ids, mask, labels, s, global_step=0)
+                raise AssertionError(f"reference stage 2 was expected to raise in branch {ftag}")
+            except RuntimeError as e:
+                assert "Inference tensors" in str(e), e
+            fx[f"s2_{ftag}_reference_raises"] = "RuntimeError: Inference tensors cannot be saved for backward"
+            continue
+        # ---- stage 2, every schedule branch (CLIP_stage2.py:141-149: < 5000, >= 5000, the bare-except None)
+        for step in (0, 1000, 5000, 6000, None):
+            rr = s2(x, ids, mask, labels, s, global_step=step)
+            ro = ora(x, t1, t2, s, global_step=step)
+            worst = max(worst, _eq(ro["loss"].detach(), rr["loss"].detach(), f"stage-2 loss {ftag} {step}"),
+                        _eq(ro["logits"].detach(), rr["logits"].detach(), f"stage-2 logits {ftag} {step}"))
+            fx[f"s2_{ftag}_loss_{step}"] = float(rr["loss"].detach())
+            fx[f"s2_{ftag}_logits_{step}"] = rr["logits"].detach().numpy()
+            if step == 1000:
+                s2.zero_grad(), ora.zero_grad()
+                rr["loss"].backward(), ro["loss"].backward()
+                named_r = [(n, p) for n, p in s2.named_parameters() if p.requires_grad and "language" not in n]
+                named_o = [(n, p) for n, p in ora.named_parameters() if p.requires_grad]
+                worst = max(worst, _grads_equal(named_o, named_r, f"stage-2 CLIP step {ftag}"))
+                fx.update(_grad_fixture(named_r, f"s2{ftag}grad"))
+                fx[f"s2_{ftag}_loss_cl"], fx[f"s2_{ftag}_loss_relation"] = float(ro["loss_CL_stage2"]), float(ro["loss_relation"])
+    dist.destroy_process_group()
+    # ---- world size 2: two gloo processes run the reference; the oracle restates each rank's view from the global batch
+    world, Bl = 2, 2
+    sd_ = (111, 112, 113, 114)
+    cases = {"s2g": (2, img, patch, L, Bl, 1000, True, False, sd_), "s1g": (1, img, patch, L, Bl, 1000, True, False, sd_),
+             "s1l": (1, img, patch, L, Bl, 1000, True, True, sd_), "s1n": (1, img, patch, L, Bl, 1000, False, False, sd_)}
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_clip_world_worker, args=(r, world, 29547, cases, q)) for r in range(world)]
+    [p.start() for p in procs]
+    got = dict(q.get(timeout=600) for _ in range(world))
+    [p.join() for p in procs]
+    for tag, (stage, img_, patch_, L_, B_, step, gl, ll, _) in cases.items():
+        s2, ora = _ref_clip_models(c1, c2, img_, patch_, L_, gl, ll, sd_[0])
+        xg, sg = R.synthetic_volume((B_ * world, 1) + img_, sd_[1]), R.synthetic_slices(B_ * world, sd_[2])
+        idg, mg = _tokens(B_ * world, sd_[3])
+        with torch.no_grad():
+            t1 = s2.stage1_pretrained_CLIP.encode_text(idg, mg)[0][:, 0].clone()
+            t2 = s2.encode_text(idg, mg)[0][:, 0].clone()
+        if stage == 1:
+            ora = ora.stage1_pretrained_CLIP
+            ora.requires_grad_(True)
+            ora.local_loss, ora.gather_loss = ll, gl
+        ora.zero_grad()
+        total = 0
+        for r in range(world):
+            ro = ora(xg, t1, global_step=step, world=world, rank=r) if stage == 1 else ora(xg, t1, t2, sg, global_step=step, world=world, rank=r)
+            worst = max(worst, _eq(ro["loss"].detach(), torch.tensor(got[r][tag]["loss"]), f"world-2 {tag} rank {r} loss"),
+                        _eq(ro["logits"].detach(), torch.from_numpy(got[r][tag]["logits"]), f"world-2 {tag} rank {r} logits"))
+            total = total + ro["loss"] / world
+            fx[f"w2_{tag}_loss_r{r}"], fx[f"w2_{tag}_logits_r{r}"] = got[r][tag]["loss"], got[r][tag]["logits"]
+        total.backward()                        # DDP: the mean over ranks of each rank's gradient (all_gather's backward sums the ranks' contributions)
+        ngrad = 0
+        for n, p in ora.named_parameters():
+            if p.requires_grad and p.grad is not None and n in got[0][tag]["grads"]:
+                avg = torch.from_numpy(np.asarray(sum(got[r][tag]["grads"][n] for r in range(world)) / world, dtype=np.float32))
+                den = float(avg.double().norm())
+                if den > 1e-9:
+                    e = float((p.grad.double() - avg.double()).norm()) / den
+                    assert e < 1e-4, (tag, n, e)      # a rank runs half the batch: other GEMM blocking than the oracle's global batch
+                    worst = max(worst, e)
+                    ngrad += 1
+                    if n.endswith("mm_vision_proj.weight") or n.endswith("cls_token"):
+                        a2 = avg.reshape(-1, avg.shape[-1])
+                        fx[f"w2_{tag}_g/{n}"] = a2[sorted({0, a2.shape[0] // 2, a2.shape[0] - 1})].numpy()     # rows [0, mid, last]
+        assert ngrad > 20, (tag, ngrad)
+        fx.update({"w2_text1": t1.numpy(), "w2_text2": t2.numpy()})
+    fx.update(w2_seeds=np.array([111, 112, 113, 114]), w2_batch_local=Bl, w2_step=1000)
+    np.savez_compressed(os.path.join(OUT, "clip_ref.npz"), **fx)
+    print(f"clip_ref ok: oracle == reference M3DCLIP_stage1 / M3DCLIP_stage2 in every branch (worst {worst:.1e}); "
+          f"{len(fx['stage2_keys'])} state-dict keys recorded")
+
+
+def clip_c4a():
+    """BASELINE configs[3] at full geometry (256^3 / 16^3, L = 12), 2 volumes, global step 1000: loss, logits and the gradient of every
+    trainable VISION tensor from the REFERENCE's own M3DCLIP_stage2.forward + autograd (round 5; rounds 2-4 wrote this file from the
+    restatement).  The text features the reference's two (random-init, one-layer) BERT towers produced are stored: they are the
+    inputs of the HIP step and of the oracle.  oracle/clip_cpu.py is asserted equal before anything is written."""
+    import torch.distributed as dist
+    c1, c2 = load_reference_clip()
+    if not dist.is_initialized():
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:29543", rank=0, world_size=1)
+    img, patch, B, step = (256, 256, 256), (16, 16, 16), 2, 1000
+    s2, ora = _ref_clip_models(c1, c2, img, patch, 12, True, False, 91)
+    for m in (s2, ora):                       # the committed fixture's convention: both scales log(1/0.07)
+        with torch.no_grad():
+            m.stage1_pretrained_CLIP.logit_scale.fill_(float(np.log(1 / 0.07)))
     x, s = R.synthetic_volume((B, 1) + img, 92), R.synthetic_slices(B, 93)
-    t1, t2 = RC.synthetic_text_features(B, 94), RC.synthetic_text_features(B, 95)
-    out = m(x, t1, t2, s, global_step=step)
-    out["loss"].backward()
-    named = [(n, p) for n, p in m.named_parameters() if p.requires_grad]
+    ids, mask = _tokens(B, 94)
+    with torch.no_grad():
+        t1 = s2.stage1_pretrained_CLIP.encode_text(ids, mask)[0][:, 0].clone()
+        t2 = s2.encode_text(ids, mask)[0][:, 0].clone()
+    rr = s2(x, ids, mask, torch.arange(B), s, global_step=step)
+    rr["loss"].backward()
+    ro = ora(x, t1, t2, s, global_step=step)
+    ro["loss"].backward()
+    _eq(ro["loss"].detach(), rr["loss"].detach(), "configs[3] loss"), _eq(ro["logits"].detach(), rr["logits"].detach(), "configs[3] logits")
+    named = [(n, p) for n, p in s2.named_parameters() if p.requires_grad and "language" not in n]
+    worst = _grads_equal([(n, p) for n, p in ora.named_parameters() if p.requires_grad], named, "configs[3] step")
     fx = _grad_fixture(named, "grad")
-    fx.update(img=np.array(img), patch=np.array(patch), batch=B, global_step=step, seed_w=91, seed_x=92, seed_s=93, seed_t1=94, seed_t2=95,
-              loss=float(out["loss"]), loss_cl=float(out["loss_CL_stage2"]), loss_relation=float(out["loss_relation"]),
-              logits=out["logits"].detach().numpy())
+    fx.update(img=np.array(img), patch=np.array(patch), batch=B, global_step=step, seed_w=91, seed_x=92, seed_s=93, seed_tok=94,
+              text1=t1.numpy(), text2=t2.numpy(), loss=float(rr["loss"].detach()), loss_cl=float(ro["loss_CL_stage2"]),
+              loss_relation=float(ro["loss_relation"]), logits=rr["logits"].detach().numpy(), source="reference M3DCLIP_stage2.forward + autograd")
     np.savez_compressed(os.path.join(OUT, "clip_c4a_256.npz"), **fx)
-    print(f"clip_c4a_256 ok: loss {float(out['loss']):.6f} (CL {float(out['loss_CL_stage2']):.6f}, relation {float(out['loss_relation']):.6f}), "
-          f"{len(named)} trainable tensors")
+    dist.destroy_process_group()
+    print(f"clip_c4a_256 ok (REFERENCE forward + autograd): loss {float(rr['loss']):.6f}; oracle gradients vs reference worst {worst:.1e}; "
+          f"{len(named)} trainable vision tensors")
+
+
+# --------------------------------------------------------------------------------------
+# the LamedMetaForCausalLM mixin (lamed_arch.py:114-155) and the CT script's own arithmetic (round 5)
+# --------------------------------------------------------------------------------------
+@torch.no_grad()
+def mixin_ref():
+    """tests/golden/mixin_ref.npz: the REFERENCE's LamedMetaForCausalLM.encode_images / prepare_inputs_for_multimodal
+    (lamed_arch.py:122-155) over the reference's build_vision_tower / build_mm_projector (multimodal_encoder/builder.py:4-11,
+    multimodal_projector/builder.py:81-106), native 32x256x256 geometry, towers cut to 2 blocks.  lamed_arch.py imports the
+    out-of-scope segmentation module (-> monai.networks.nets) at module scope: that one builder module gets an empty stand-in."""
+    from oracle import clip_cpu as RC
+    load_reference_clip()
+    name = "LaMed.src.model.segmentation_module.builder"
+    if name not in sys.modules:
+        st = types.ModuleType(name)
+        st.build_segmentation_module = lambda config, **k: None
+        sys.modules[name] = st
+    import LaMed.src.model.lamed_arch as la
+    img, patch, L, B, S = (32, 256, 256), (4, 16, 16), 2, 1, 300
+
+    class Cfg2:
+        vision_tower, vision_select_layer, vision_select_feature, image_channel = "vit_stage2_dual_encoders", -1, "patch", 1
+        remain_2d3d_ViT_type, image_size, patch_size = "dual_vits", img, patch
+        mm_projector_type, mm_hidden_size, hidden_size = "VisualPacker_3d_phi_v3", 768, 3072
+        proj_layer_type, proj_layer_num, proj_pooling_type, proj_pooling_size = "mlp", 2, "spatial", 2
+
+    def build(tower_fn, proj_fn, parallel):
+        tower = tower_fn(Cfg2()).eval()
+        for t in (tower.vision_tower_stage1, tower.vision_tower_stage2):
+            del t.blocks[L:]
+        p1, p2 = proj_fn(Cfg2()).eval(), proj_fn(Cfg2()).eval()
+        for m_, seed in ((tower, 201), (p1, 202), (p2, 203)):
+            m_.load_state_dict(R.seeded_state_dict(m_, seed))
+        emb = torch.nn.Embedding(64, 3072)
+        emb.load_state_dict(R.seeded_state_dict(emb, 204))
+
+        class Model:
+            mm_projector = p1
+            embed_tokens = emb
+
+            def get_vision_tower(self):
+                return tower
+        model = Model()
+        if parallel:
+            model.mm_projector2 = p2
+        return model, tower, p1, p2
+
+    x, s = R.synthetic_volume((B, 1) + img, 205), R.synthetic_slices(B, 206)
+    ids = torch.from_numpy(np.random.default_rng(207).integers(0, 64, size=(B, S)))
+    fx = dict(img=np.array(img), patch=np.array(patch), layers=L, batch=B, seq=S, seed_tower=201, seed_p1=202, seed_p2=203, seed_emb=204,
+              seed_x=205, seed_s=206, seed_ids=207)
+    rows = [0, 1, 127, 128, 255]
+    for parallel, tag in ((True, "par"), (False, "shared")):
+        model, _, _, _ = build(la.build_vision_tower, la.build_mm_projector, parallel)
+
+        class LM(la.LamedMetaForCausalLM):
+            def get_model(self):
+                return model
+        lm = LM()
+        feats = lm.encode_images(x, None, s)                                                     # :122-141
+        r = lm.prepare_inputs_for_multimodal(ids, "pos", "mask", "pkv", "labels", x, s)          # :143-155
+        assert r[0] is None and r[1:4] == ("pos", "mask", "pkv") and r[5] == "labels"
+        emb = r[4]
+        # the oracle's restatement of the same two steps
+        om, ot, op1, op2 = build(R.ViT3DTower_dual_encoders, lambda c: R.VisualPacker_3d_phi_v3(c.image_size, c.patch_size, c.mm_hidden_size, c.hidden_size,
+                                                                                             c.proj_layer_type, c.proj_layer_num), parallel)
+        of = R.encode_images(ot, op1, op2 if parallel else None, x, s)
+        oe = RC.splice_image_features(om.embed_tokens(ids), of)
+        _eq(of, feats, f"mixin encode_images ({tag})"), _eq(oe, emb, f"mixin splice ({tag})")
+        fx.update({f"{tag}_feat_rows": _sel(feats, rows), f"{tag}_feat_norms": feats.norm(dim=-1).numpy(),
+                   f"{tag}_emb_rows": _sel(emb, [0, 1, 2, 256, 257, S - 1]), f"{tag}_emb_norms": emb.norm(dim=-1).numpy()})
+        # pass-through cases (:148-149)
+        one = torch.zeros(B, 1, dtype=torch.long)
+        assert lm.prepare_inputs_for_multimodal(one, 1, 2, 3, 4, x, s) == (one, 1, 2, 3, None, 4)
+        assert lm.prepare_inputs_for_multimodal(ids, 1, 2, 3, 4, None, s)[0] is ids
+    fx.update(feat_rows_idx=np.array(rows), emb_rows_idx=np.array([0, 1, 2, 256, 257, S - 1]))
+    np.savez_compressed(os.path.join(OUT, "mixin_ref.npz"), **fx)
+    print("mixin_ref ok: oracle encode_images / splice == reference LamedMetaForCausalLM (parallel and shared projector)")
+
+
+def prep_ref():
+    """tests/golden/prep_ref.npz: the CT script's own `resize_array` and `nii_img_to_tensor`
+    (Data/data_processing/CT-RATE/CT-RATE_nii_to_3D_volume_npy_file.py:24-117) run here on a synthetic scan.  The script imports
+    monai.transforms / nibabel at module scope (absent: empty stand-ins; its module-level mtf.Compose is never called here because
+    `transform` is an ARGUMENT of nii_img_to_tensor: the oracle's crop + resize is passed in) and moves tensors through 'cuda'
+    (absent here: Tensor.to is wrapped for the duration of the call so that 'cuda' means this CPU; the arithmetic is device-neutral)."""
+    from oracle import prep_cpu as P
+    import pandas as pd
+    for n in ("monai.transforms", "nibabel"):
+        sys.modules.setdefault(n, types.ModuleType(n))
+    sys.modules.setdefault("monai", types.ModuleType("monai"))
+    mtf = sys.modules["monai.transforms"]
+    mtf.Compose = lambda ts: ts
+    mtf.CropForeground = lambda *a, **k: None
+    mtf.Resize = lambda *a, **k: None
+    path = "/root/reference/Data/data_processing/CT-RATE/CT-RATE_nii_to_3D_volume_npy_file.py"
+    ct = _load(path, "_ref_ct_script")
+    g = np.random.default_rng(301)
+    # (i) resize_array alone
+    arr = torch.from_numpy(g.standard_normal((1, 1, 11, 20, 24))).double()
+    a_ref, a_ora = ct.resize_array(arr, (3.0, 0.9, 0.9), (1.5, 0.75, 0.75)), P.resize_array(arr, (3.0, 0.9, 0.9), (1.5, 0.75, 0.75))
+    assert a_ref.shape == a_ora.shape == (1, 1, 22, 24, 28) and np.array_equal(a_ref, a_ora)
+    # (ii) the whole function on a synthetic scan (H, W, D) = (40, 48, 14): a body of tissue values inside air
+    raw = np.full((40, 48, 14), -1200.0)
+    raw[6:33, 9:41, 2:12] = g.uniform(-900, 700, size=(27, 32, 10))
+    slope, intercept, zsp, xysp = 1.0, -24.0, 3.0, 0.9
+
+    class _Nii:
+        def get_fdata(self):
+            return raw.copy()
+    sys.modules["nibabel"].load = lambda p: _Nii()
+    ct.nib.load = sys.modules["nibabel"].load
+    meta = pd.DataFrame([dict(VolumeName="scan.nii.gz", RescaleSlope=slope, RescaleIntercept=intercept, XYSpacing=f"[{xysp}, {xysp}]", ZSpacing=zsp)])
+    out_size = (8, 32, 32)
+    transform = lambda t: P.monai_resize(P.crop_foreground(t), out_size)
+    real_to, real_exists = torch.Tensor.to, os.path.exists
+
+    def to_cpu(self, *a, **k):
+        a = tuple("cpu" if (isinstance(v, str) and v.startswith("cuda")) else v for v in a)
+        return real_to(self, *a, **k)
+    try:
+        torch.Tensor.to = to_cpu
+        ct.os.path.exists = lambda p: True
+        y_ref = ct.nii_img_to_tensor("/nowhere/scan.nii.gz", transform, meta)
+    finally:
+        torch.Tensor.to = real_to
+        ct.os.path.exists = real_exists
+    assert y_ref is not None, "the reference function reported an error (printed above)"
+    y_ora = P.nii_img_to_tensor(raw, slope, intercept, zsp, xysp, out_size)
+    assert y_ref.shape == y_ora.shape == (1,) + out_size and torch.equal(y_ref, y_ora), float((y_ref - y_ora).abs().max())
+    np.savez_compressed(os.path.join(OUT, "prep_ref.npz"), seed=301, raw_shape=np.array(raw.shape), body=np.array([6, 33, 9, 41, 2, 12]),
+                        slope=slope, intercept=intercept, z_spacing=zsp, xy_spacing=xysp, out_size=np.array(out_size), out=y_ref.numpy(),
+                        resized=a_ref[0, 0, ::7, ::5, ::9])
+    print("prep_ref ok: oracle resize_array / nii_img_to_tensor == the reference script's (bit-equal)")
 
 
 @torch.no_grad()
@@ -367,7 +721,7 @@ def plumbing(vit):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-big", action="store_true")
-    ap.add_argument("--only", default=None, choices=["grads", "clip"], help="regenerate only this group of fixtures")
+    ap.add_argument("--only", default=None, choices=["grads", "clip", "mixin", "prep"], help="regenerate only this group of fixtures")
     a = ap.parse_args()
     if not os.path.isdir(REF):
         sys.exit("reference not present (this script only runs in the build container)")
@@ -377,8 +731,16 @@ def main():
     if a.only == "grads":
         grads(vit, spp)
         return
+    if a.only == "mixin":
+        mixin_ref()
+        return
+    if a.only == "prep":
+        prep_ref()
+        return
     if a.only == "clip":
-        clip_c4a()
+        clip_ref()
+        if not a.skip_big:
+            clip_c4a()
         return
     tiny_encoders(vit)
     packer(spp)
@@ -386,6 +748,10 @@ def main():
     if not a.skip_big:
         big(vit, spp)
         grads(vit, spp)
+    clip_ref()
+    mixin_ref()
+    prep_ref()
+    if not a.skip_big:
         clip_c4a()
 
 

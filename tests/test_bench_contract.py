@@ -104,3 +104,17 @@ def test_attn_logit_std_scaling_gives_the_requested_logit_spread():
         q, k = x @ w[:d].t(), x @ w[d:2 * d].t()
         logits = (q[:512, :64] @ k[:, :64].t()) / 8.0              # one 64-wide head
         assert abs(float(logits.std()) - 1.5) < 0.15, float(logits.std())
+
+
+def test_bench_gpus_n_is_the_world_size_or_an_error():
+    """round 5: `bench.py --gpus N` either runs N ranks (it starts them itself when WORLD_SIZE is unset) or exits non-zero -- it never
+    prints a line for another world size.  Without a GPU both refusals are observable here."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "HS_BENCH_BACKEND")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], env=env, capture_output=True, text=True, timeout=300)
+    if r.returncode == 0:
+        import pytest
+        pytest.skip("two GPUs are visible here: the launcher ran")
+    assert r.returncode == 2 and "GPU(s) are visible" in r.stderr and not any(ln.startswith("{") for ln in r.stdout.splitlines())
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"], env=dict(env, WORLD_SIZE="2"), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr and not r.stdout.strip()

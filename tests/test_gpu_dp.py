@@ -332,12 +332,17 @@ def test_dual_engine_rccl_world1_two_streams(dev, tmp_path):
     assert moved > 0 and diff < 2e-2 * moved
 
 
+@pytest.mark.parametrize("self_launch", [True, False])
 @pytest.mark.parametrize("workload,extra", [("dual256", ["--batch", "1"]), ("dual256", ["--scaling", "strong", "--global-batch", "2"]),
                                             ("clip_c4b", []), ("clip_s1", ["--grad-wire", "bf16", "--grad-algo", "rs_ag"])])
-def test_bench_two_rank_rehearsal(workload, extra):
-    """bench.py exactly as the driver launches it for N > 1 (python -m torch.distributed.run ... bench.py --gpus N), two ranks on the one
-    GPU of this box over gloo (HS_BENCH_BACKEND=gloo; on a multi-GPU node the same control flow runs over RCCL): per-rank collective-free
-    fit probe, the batch vote, barrier-bracketed timing with the max over ranks, ONE JSON line from rank 0, whole-job aggregate."""
+def test_bench_two_rank_rehearsal(workload, extra, self_launch):
+    """bench.py for N > 1, both ways it can be started: `python bench.py --gpus 2` (no WORLD_SIZE: bench.py starts its two ranks itself,
+    as the reference's `accelerate launch` does) and exactly as the driver launches it (python -m torch.distributed.run ... bench.py
+    --gpus N).  Two ranks on the one GPU of this box over gloo (HS_BENCH_BACKEND=gloo; on a multi-GPU node the same control flow runs
+    over RCCL): per-rank collective-free fit probe, the batch vote, barrier-bracketed timing with the max over ranks, ONE JSON line
+    from rank 0, whole-job aggregate."""
+    if self_launch and workload != "dual256":
+        pytest.skip("the self-launch form is covered on the dual256 cases")
     import json
     import subprocess
     import sys
@@ -347,9 +352,13 @@ def test_bench_two_rank_rehearsal(workload, extra):
     port = s.getsockname()[1]
     s.close()
     env = dict(os.environ, HS_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--workload", workload, "--no-cpu-baseline", "--no-roofline"] + extra
+    tail = ["--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", workload, "--no-cpu-baseline", "--no-roofline"] + extra
+    if self_launch:
+        env = {k: v for k, v in env.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+        cmd = [sys.executable, os.path.join(root, "bench.py")] + tail
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.join(root, "bench.py")] + tail
     r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

@@ -327,3 +327,142 @@ def test_restated_blocks_equal_real_monai_when_it_is_installed():
     pm.load_state_dict(pr.state_dict())
     v = torch.rand(2, 1, 8, 32, 32)
     assert torch.allclose(pr(v), pm(v), atol=1e-6, rtol=1e-5)
+
+
+# ---- round 5: the oracle against fixtures written by the REFERENCE's own wrapper classes run in the build container ----
+def _clip_ref_models(g, gather_loss=True, local_loss=False):
+    from oracle import clip_cpu as RC
+    img, patch, L = tuple(int(v) for v in g["img"]), tuple(int(v) for v in g["patch"]), int(g["layers"])
+    m = RC.M3DCLIPVision_stage2(img, patch, L, gather_loss=gather_loss, local_loss=local_loss).eval()
+    sd = R.seeded_state_dict(m, int(g["seed_w"]))
+    sd["logit_scale"] = torch.tensor(float(g["scale_outer"]))
+    sd["stage1_pretrained_CLIP.logit_scale"] = torch.tensor(float(g["scale_inner"]))
+    m.load_state_dict(sd)
+    return m, img
+
+
+def _check_grads(named, g, tag, tol=2e-5):
+    names = [str(n) for n in g[f"{tag}_names"]]
+    norms = dict(zip(names, g[f"{tag}_norms"]))
+    for n, p in named:
+        assert n in norms, n
+        assert abs(float(p.grad.double().norm()) - norms[n]) <= tol * norms[n] + 1e-12, n
+        key = f"{tag}_g/{n}"
+        if key in g.files:
+            want = torch.from_numpy(g[key])
+            got = p.grad.reshape(-1, p.grad.shape[-1])[g[f"{tag}_r/{n}"]] if f"{tag}_r/{n}" in g.files else p.grad
+            assert R.rel_err(got.reshape(want.shape), want) < tol, n
+
+
+def test_clip_oracle_equals_reference_wrapper_fixture(golden):
+    """tests/golden/clip_ref.npz = outputs of the reference's M3DCLIP_stage1.forward / M3DCLIP_stage2.forward (oracle/make_goldens.py::
+    clip_ref): every stage-1 branch (gathered, local_loss, no gather) with gradients, stage 2 over the schedule's branches with
+    gradients at step 1000, and the world-size-2 views of both."""
+    from oracle import clip_cpu as RC
+    g = golden("clip_ref.npz")
+    B = int(g["batch"])
+    t1, t2 = torch.from_numpy(g["text1"]), torch.from_numpy(g["text2"])
+    for gl, ll, tag in ((True, False, "g"), (True, True, "l"), (False, False, "n")):
+        m, img = _clip_ref_models(g, gl, ll)
+        x, s = R.synthetic_volume((B, 1) + img, int(g["seed_x"])), R.synthetic_slices(B, int(g["seed_s"]))
+        s1 = m.stage1_pretrained_CLIP
+        s1.local_loss, s1.gather_loss = ll, gl
+        s1.requires_grad_(True)
+        r = s1(x, t1, global_step=500)
+        assert abs(float(r["loss"]) - float(g[f"s1_{tag}_loss"])) < 1e-6 and R.rel_err(r["logits"].detach(), torch.from_numpy(g[f"s1_{tag}_logits"])) < 1e-6
+        r["loss"].backward()
+        _check_grads(list(s1.named_parameters()), g, f"s1{tag}grad")
+        s1.requires_grad_(False)
+        if tag != "g":
+            assert "Inference tensors" in str(g[f"s2_{tag}_reference_raises"])       # the reference's stage 2 cannot run this branch
+            continue
+        for step in (0, 1000, 5000, 6000, None):
+            r = m(x, t1, t2, s, global_step=step)
+            assert abs(float(r["loss"]) - float(g[f"s2_g_loss_{step}"])) < 1e-6, step
+            assert R.rel_err(r["logits"].detach(), torch.from_numpy(g[f"s2_g_logits_{step}"])) < 1e-6
+            if step == 1000:
+                r["loss"].backward()
+                _check_grads([(n, p) for n, p in m.named_parameters() if p.requires_grad], g, "s2ggrad")
+        assert float(g["s2_g_loss_5000"]) == float(g["s2_g_loss_6000"]) == float(g["s2_g_loss_None"]) != float(g["s2_g_loss_0"])
+    # world size 2 (two gloo processes ran the reference): each rank's loss / logits from the global batch
+    world, Bl, step = 2, int(g["w2_batch_local"]), int(g["w2_step"])
+    sw, sx, ss, _ = (int(v) for v in g["w2_seeds"])
+    t1, t2 = torch.from_numpy(g["w2_text1"]), torch.from_numpy(g["w2_text2"])
+    for tag, stage, gl, ll in (("s2g", 2, True, False), ("s1g", 1, True, False), ("s1l", 1, True, True), ("s1n", 1, False, False)):
+        m, img = _clip_ref_models(dict(g, seed_w=sw), gl, ll)
+        x, s = R.synthetic_volume((Bl * world, 1) + img, sx), R.synthetic_slices(Bl * world, ss)
+        if stage == 1:
+            m = m.stage1_pretrained_CLIP
+            m.local_loss, m.gather_loss = ll, gl
+        for r_ in range(world):
+            with torch.no_grad():
+                r = m(x, t1, global_step=step, world=world, rank=r_) if stage == 1 else m(x, t1, t2, s, global_step=step, world=world, rank=r_)
+            assert abs(float(r["loss"]) - float(g[f"w2_{tag}_loss_r{r_}"])) < 2e-6, (tag, r_)
+            assert R.rel_err(r["logits"], torch.from_numpy(g[f"w2_{tag}_logits_r{r_}"])) < 2e-6
+
+
+def test_reference_state_dict_layout_of_the_clip_checkpoint(golden):
+    """the reference's M3DCLIP_stage2.state_dict() key list (recorded from the class itself) against the counts the positional
+    hand-over of train/train_VLM.py:477-503 relies on, and against the product's vision halves."""
+    import hsenet_amd as H
+    from hsenet_amd import checkpoint as C
+    from hsenet_amd.clip import M3DCLIPVision_stage2
+    g = golden("clip_ref.npz")
+    keys = [str(k) for k in g["stage2_keys"]]
+    L = int(g["layers"])
+    vis = C.filter_visual_checkpoint({k: None for k in keys})
+    s1 = [k for k in vis if "stage1_pretrained_CLIP" in k]
+    s2 = [k for k in vis if "stage1_pretrained_CLIP" not in k]
+    assert len(s1) == 1 + 3 + 11 * L + 2 and len(s2) == len(s1) + 12
+    assert all(k.startswith("stage1_pretrained_CLIP.vision_encoder.") for k in s1) and all(k.startswith("vision_encoder.") for k in s2)
+    kw = dict(in_channels=1, img_size=tuple(int(v) for v in g["img"]), patch_size=tuple(int(v) for v in g["patch"]), num_layers=L,
+              pos_embed="perceptron", classification=True)
+    assert [k[len("stage1_pretrained_CLIP.vision_encoder."):] for k in s1] == list(H.ViT_stage1(**kw).state_dict().keys())
+    assert [k[len("vision_encoder."):] for k in s2] == list(H.ViT_stage2(**kw).state_dict().keys())
+    mine = list(M3DCLIPVision_stage2(kw["img_size"], kw["patch_size"], num_layers=L).state_dict().keys())
+    assert [k for k in keys if "language" not in k] == mine          # the vision half has the reference's keys in the reference's order
+
+
+def test_mixin_oracle_equals_reference_fixture(golden):
+    """tests/golden/mixin_ref.npz = the reference's LamedMetaForCausalLM.encode_images / prepare_inputs_for_multimodal over its own
+    builders (oracle/make_goldens.py::mixin_ref); the oracle's encode_images + splice reproduce it."""
+    from oracle import clip_cpu as RC
+    g = golden("mixin_ref.npz")
+    img, patch, L, B, S = tuple(int(v) for v in g["img"]), tuple(int(v) for v in g["patch"]), int(g["layers"]), int(g["batch"]), int(g["seq"])
+
+    class Cfg:
+        vision_select_layer, vision_select_feature, image_channel, remain_2d3d_ViT_type = -1, "patch", 1, "dual_vits"
+        image_size, patch_size = img, patch
+    tower = R.ViT3DTower_dual_encoders(Cfg()).eval()
+    for t in (tower.vision_tower_stage1, tower.vision_tower_stage2):
+        del t.blocks[L:]
+    p1, p2 = (R.VisualPacker_3d_phi_v3(img, patch, 768, 3072, "mlp", 2).eval() for _ in range(2))
+    emb = torch.nn.Embedding(64, 3072)
+    for m_, key in ((tower, "seed_tower"), (p1, "seed_p1"), (p2, "seed_p2"), (emb, "seed_emb")):
+        m_.load_state_dict(R.seeded_state_dict(m_, int(g[key])))
+    x, s = R.synthetic_volume((B, 1) + img, int(g["seed_x"])), R.synthetic_slices(B, int(g["seed_s"]))
+    ids = torch.from_numpy(np.random.default_rng(int(g["seed_ids"])).integers(0, 64, size=(B, S)))
+    with torch.no_grad():
+        for tag, second in (("par", p2), ("shared", None)):
+            f = R.encode_images(tower, p1, second, x, s)
+            e = RC.splice_image_features(emb(ids), f)
+            assert R.rel_err(f[:, g["feat_rows_idx"]], torch.from_numpy(g[f"{tag}_feat_rows"])) < 1e-6
+            assert R.rel_err(f.norm(dim=-1), torch.from_numpy(g[f"{tag}_feat_norms"])) < 1e-6
+            assert R.rel_err(e[:, g["emb_rows_idx"]], torch.from_numpy(g[f"{tag}_emb_rows"])) < 1e-6
+            assert R.rel_err(e.norm(dim=-1), torch.from_numpy(g[f"{tag}_emb_norms"])) < 1e-6
+
+
+def test_prep_oracle_equals_reference_script_fixture(golden):
+    """tests/golden/prep_ref.npz = the CT script's own nii_img_to_tensor / resize_array run on a synthetic scan."""
+    from oracle import prep_cpu as P
+    g = golden("prep_ref.npz")
+    rng = np.random.default_rng(int(g["seed"]))
+    arr = torch.from_numpy(rng.standard_normal((1, 1, 11, 20, 24))).double()
+    a = P.resize_array(arr, (3.0, 0.9, 0.9), (1.5, 0.75, 0.75))
+    assert np.array_equal(a[0, 0, ::7, ::5, ::9], g["resized"])
+    raw = np.full(tuple(int(v) for v in g["raw_shape"]), -1200.0)
+    b = [int(v) for v in g["body"]]
+    raw[b[0]:b[1], b[2]:b[3], b[4]:b[5]] = rng.uniform(-900, 700, size=(b[1] - b[0], b[3] - b[2], b[5] - b[4]))
+    y = P.nii_img_to_tensor(raw, float(g["slope"]), float(g["intercept"]), float(g["z_spacing"]), float(g["xy_spacing"]),
+                            tuple(int(v) for v in g["out_size"]))
+    assert np.array_equal(y.numpy(), g["out"])
