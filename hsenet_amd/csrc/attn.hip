@@ -712,11 +712,13 @@ __device__ __forceinline__ int offR16(int r, int c) { return r * 128 + ((c ^ swz
 // O and dO once more): a wave holds the dO rows of its 32 queries as MFMA operands anyway, so it loads the matching O rows (16 B per
 // lane and k-step), forms delta = sum_d dO*O in registers (8 products per k-step and lane, the two lanes of a row combined by one
 // shuffle), takes lse from the forward, and writes ws[0] = -delta, ws[1] = -lse*log2(e) for the dK/dV sweep launched after it.
-template <int NW>
-__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void attn_bwd_dq2_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
-                                                           const bf16_t* __restrict__ o, const float* __restrict__ lse,
-                                                           float* __restrict__ ws, bf16_t* __restrict__ dqkv, int B,
-                                                           int N, int H, float qmul, float out_mul) {
+// F16: the same sweep on IEEE fp16 operands (HS_ATTN_F16, round 5): P = exp2(S') <= 1 and dS = P * dP' are packed as fp16, the MFMAs are the
+// fp16 opcode; everything else (images, ring, waits) is format-blind.
+template <int NW, bool F16>
+__device__ __forceinline__ void attn_bwd_dq2_body(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
+                                                  const bf16_t* __restrict__ o, const float* __restrict__ lse,
+                                                  float* __restrict__ ws, bf16_t* __restrict__ dqkv, int B,
+                                                  int N, int H, float qmul, float out_mul) {
     __shared__ __attribute__((aligned(16))) char smem[3 * 16384];
     constexpr int QB = NW * 32, NP = 8 / NW;                 // queries per block; K (and V) DMA pieces per wave per tile
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31;
@@ -757,14 +759,14 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void attn_bwd_dq2_kernel(
     float dsum = 0.f;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-        qf[ks] = scale_frag(buf_load16(rs, (unsigned)(((long)qrow * D3 + head * 64 + ks * 16 + 8 * h) * 2)), qmul);
+        qf[ks] = scale_frag<F16>(buf_load16(rs, (unsigned)(((long)qrow * D3 + head * 64 + ks * 16 + 8 * h) * 2)), qmul);
         const unsigned off = (unsigned)(((long)qrow * Dm + head * 64 + ks * 16 + 8 * h) * 2);
         const u32x4 g = buf_load16(rsd, off), a = buf_load16(rso, off);
         dof[ks] = __builtin_bit_cast(bf16x8, g);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            dsum += __uint_as_float(a[i] << 16) * __uint_as_float(g[i] << 16);
-            dsum += __uint_as_float(a[i] & 0xffff0000u) * __uint_as_float(g[i] & 0xffff0000u);
+            dsum += unpack_lo<F16>(a[i]) * unpack_lo<F16>(g[i]);
+            dsum += unpack_hi<F16>(a[i]) * unpack_hi<F16>(g[i]);
         }
     }
     dsum += __shfl_xor(dsum, 32, 64);                        // lanes c and c + 32 hold the two halves of every 16-wide k-step of row qrow
@@ -816,8 +818,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void attn_bwd_dq2_kernel(
         auto sdp = [&](u32x4 (&r)[4], int kb, int half) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, r[2 * i]), qf[2 * half + i], st[kb], 0, 0, 0);
-                dpt[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, r[2 * i + 1]), dof[2 * half + i], dpt[kb], 0, 0, 0);
+                st[kb] = mfma32<F16>(__builtin_bit_cast(bf16x8, r[2 * i]), qf[2 * half + i], st[kb]);
+                dpt[kb] = mfma32<F16>(__builtin_bit_cast(bf16x8, r[2 * i + 1]), dof[2 * half + i], dpt[kb]);
             }
         };
         auto valu = [&](int kb) {
@@ -831,10 +833,10 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void attn_bwd_dq2_kernel(
         auto acc = [&](u32x4 (&f)[4], int kb) {
 #pragma unroll
             for (int sp = 0; sp < 2; ++sp) {
-                const bf16x8 dsf = pack8(dpt[kb], sp);
+                const bf16x8 dsf = pack8<F16>(dpt[kb], sp);
 #pragma unroll
                 for (int db = 0; db < 2; ++db)
-                    dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f[sp * 2 + db]), dsf, dq[db], 0, 0, 0);
+                    dq[db] = mfma32<F16>(__builtin_bit_cast(bf16x8, f[sp * 2 + db]), dsf, dq[db]);
             }
         };
         typedef std::integral_constant<int, 0> I0;
@@ -892,7 +894,20 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void attn_bwd_dq2_kernel(
     if (!active) return;
     tile(t, S0{}, std::true_type{}, rst);
     const int query = q0 + c;
-    if (query < N) store_dT(dqkv + ((long)b * N + query) * D3 + head * 64, dq, out_mul, h);
+    if (query < N) store_dT<F16>(dqkv + ((long)b * N + query) * D3 + head * 64, dq, out_mul, h);
+}
+// (thin non-template kernels: hipcc's host pass can drop the launch stub of a templated __global__ whose body holds constrained asm)
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq2_w4_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
+                                                                const bf16_t* __restrict__ o, const float* __restrict__ lse,
+                                                                float* __restrict__ ws, bf16_t* __restrict__ dqkv, int B, int N, int H,
+                                                                float qmul, float out_mul) {
+    attn_bwd_dq2_body<4, false>(qkv, d_o, o, lse, ws, dqkv, B, N, H, qmul, out_mul);
+}
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq2_w4_f16_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
+                                                                    const bf16_t* __restrict__ o, const float* __restrict__ lse,
+                                                                    float* __restrict__ ws, bf16_t* __restrict__ dqkv, int B, int N, int H,
+                                                                    float qmul, float out_mul) {
+    attn_bwd_dq2_body<4, true>(qkv, d_o, o, lse, ws, dqkv, B, N, H, qmul, out_mul);
 }
 
 // dK, dV: NW waves x 32 keys per block (K, V fragments and the dK^T, dV^T accumulators stay in registers), sweeping the queries in
@@ -913,7 +928,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void attn_bwd_dq2_kernel(
 //   A = dO^T / Q'^T tile di (16 d columns): two ds_read_b64_tr_b16 per fragment, 16-lane group g reading rows 4g..4g+3 and
 //                16+4g..16+4g+3 of the 32-query block at columns 16di..16di+15 -- the same k-slot order
 //   dV^T(di,ki), dK^T(di,ki): lane (key, g) holds d = 16di + 4g + r -> four consecutive d per 8-byte store.
-template <int NW>
+template <int NW, bool F16>
 __device__ __forceinline__ void attn_bwd_dkdv16_body(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
                                                      const float* __restrict__ ws, bf16_t* __restrict__ dqkv, int B,
                                                      int N, int H, float kmul, float dk_mul) {
@@ -965,7 +980,7 @@ __device__ __forceinline__ void attn_bwd_dkdv16_body(const bf16_t* __restrict__ 
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const unsigned off = key < N ? (unsigned)(((long)key * D3 + Dm + head * 64 + ks * 32 + 8 * g) * 2) : HS_OOB_OFF;
-            kf[ki][ks] = scale_frag(buf_load16(rs, off), kmul);
+            kf[ki][ks] = scale_frag<F16>(buf_load16(rs, off), kmul);
             vf[ki][ks] = __builtin_bit_cast(bf16x8, buf_load16(rs, key < N ? off + Dm * 2 : HS_OOB_OFF));
         }
     }
@@ -1028,13 +1043,13 @@ __device__ __forceinline__ void attn_bwd_dkdv16_body(const bf16_t* __restrict__ 
             const f32x4 cl = __builtin_bit_cast(f32x4, c1[qb][2 * qi]), cd = __builtin_bit_cast(f32x4, c1[qb][2 * qi + 1]);
 #pragma unroll
             for (int ki = 0; ki < 2; ++ki) {
-                s[qb][qi][ki] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, r[0]), kf[ki][0], cl, 0, 0, 0);
-                dp[qb][qi][ki] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, r[1]), vf[ki][0], cd, 0, 0, 0);
+                s[qb][qi][ki] = mfma16<F16>(__builtin_bit_cast(bf16x8, r[0]), kf[ki][0], cl);
+                dp[qb][qi][ki] = mfma16<F16>(__builtin_bit_cast(bf16x8, r[1]), vf[ki][0], cd);
             }
 #pragma unroll
             for (int ki = 0; ki < 2; ++ki) {
-                s[qb][qi][ki] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, r[2]), kf[ki][1], s[qb][qi][ki], 0, 0, 0);
-                dp[qb][qi][ki] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, r[3]), vf[ki][1], dp[qb][qi][ki], 0, 0, 0);
+                s[qb][qi][ki] = mfma16<F16>(__builtin_bit_cast(bf16x8, r[2]), kf[ki][1], s[qb][qi][ki]);
+                dp[qb][qi][ki] = mfma16<F16>(__builtin_bit_cast(bf16x8, r[3]), vf[ki][1], dp[qb][qi][ki]);
             }
         };
         auto valu = [&](int qb) {
@@ -1051,7 +1066,7 @@ __device__ __forceinline__ void attn_bwd_dkdv16_body(const bf16_t* __restrict__ 
         };
         auto pack = [&](const f32x4& lo, const f32x4& hi) {       // k-slots 0..3 <- tile qi = 0, 4..7 <- tile qi = 1
             u32x4 u;
-            u[0] = pack2bf(lo[0], lo[1]); u[1] = pack2bf(lo[2], lo[3]); u[2] = pack2bf(hi[0], hi[1]); u[3] = pack2bf(hi[2], hi[3]);
+            u[0] = pack2h<F16>(lo[0], lo[1]); u[1] = pack2h<F16>(lo[2], lo[3]); u[2] = pack2h<F16>(hi[0], hi[1]); u[3] = pack2h<F16>(hi[2], hi[3]);
             return __builtin_bit_cast(bf16x8, u);
         };
         auto dvdk = [&](u32x4 (&f)[4], int qb, int half) {         // 8 MFMAs: d tiles 2half, 2half+1 x both key tiles
@@ -1060,8 +1075,8 @@ __device__ __forceinline__ void attn_bwd_dkdv16_body(const bf16_t* __restrict__ 
                 const bf16x8 pf = pack(s[qb][0][ki], s[qb][1][ki]), dsf = pack(dp[qb][0][ki], dp[qb][1][ki]);
 #pragma unroll
                 for (int d2 = 0; d2 < 2; ++d2) {
-                    dv[2 * half + d2][ki] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, f[d2]), pf, dv[2 * half + d2][ki], 0, 0, 0);
-                    dk[2 * half + d2][ki] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, f[2 + d2]), dsf, dk[2 * half + d2][ki], 0, 0, 0);
+                    dv[2 * half + d2][ki] = mfma16<F16>(__builtin_bit_cast(bf16x8, f[d2]), pf, dv[2 * half + d2][ki]);
+                    dk[2 * half + d2][ki] = mfma16<F16>(__builtin_bit_cast(bf16x8, f[2 + d2]), dsf, dk[2 * half + d2][ki]);
                 }
             }
         };
@@ -1128,11 +1143,11 @@ __device__ __forceinline__ void attn_bwd_dkdv16_body(const bf16_t* __restrict__ 
 #pragma unroll
             for (int di = 0; di < 4; ++di) {
                 u32x2 v;
-                v[0] = pack2bf(dk[di][ki][0] * dk_mul, dk[di][ki][1] * dk_mul);
-                v[1] = pack2bf(dk[di][ki][2] * dk_mul, dk[di][ki][3] * dk_mul);
+                v[0] = pack2h<F16>(dk[di][ki][0] * dk_mul, dk[di][ki][1] * dk_mul);
+                v[1] = pack2h<F16>(dk[di][ki][2] * dk_mul, dk[di][ki][3] * dk_mul);
                 *(u32x2*)(row + Dm + 16 * di + 4 * g) = v;
-                v[0] = pack2bf(dv[di][ki][0], dv[di][ki][1]);
-                v[1] = pack2bf(dv[di][ki][2], dv[di][ki][3]);
+                v[0] = pack2h<F16>(dv[di][ki][0], dv[di][ki][1]);
+                v[1] = pack2h<F16>(dv[di][ki][2], dv[di][ki][3]);
                 *(u32x2*)(row + 2 * Dm + 16 * di + 4 * g) = v;
             }
         }
@@ -1143,7 +1158,12 @@ __device__ __forceinline__ void attn_bwd_dkdv16_body(const bf16_t* __restrict__ 
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv16_w4_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
                                                                    const float* __restrict__ ws, bf16_t* __restrict__ dqkv, int B,
                                                                    int N, int H, float kmul, float dk_mul) {
-    attn_bwd_dkdv16_body<4>(qkv, d_o, ws, dqkv, B, N, H, kmul, dk_mul);
+    attn_bwd_dkdv16_body<4, false>(qkv, d_o, ws, dqkv, B, N, H, kmul, dk_mul);
+}
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv16_w4_f16_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
+                                                                       const float* __restrict__ ws, bf16_t* __restrict__ dqkv, int B,
+                                                                       int N, int H, float kmul, float dk_mul) {
+    attn_bwd_dkdv16_body<4, true>(qkv, d_o, ws, dqkv, B, N, H, kmul, dk_mul);
 }
 
 extern "C" int hs_attn_fwd(const void* qkv, void* o, float* lse, int B, int N, int H, int dh, int prec, int flags, void* stream) {
@@ -1190,7 +1210,8 @@ extern "C" int hs_attn_bwd(const void* qkv, const void* o, const void* d_o, cons
                            int B, int N, int H, int dh, int flags, void* stream) {
     if (!qkv || !o || !d_o || !lse || !dqkv || !delta_ws) return HS_ERR_ARG;
     if (dh != 64 || B < 1 || N < 1 || H < 1) return HS_ERR_SHAPE;
-    if (flags & ~(HS_ATTN_Q_PRESCALED | HS_ATTN_F32)) return HS_ERR_ARG;
+    if (flags & ~(HS_ATTN_Q_PRESCALED | HS_ATTN_F32 | HS_ATTN_F16)) return HS_ERR_ARG;
+    if ((flags & HS_ATTN_F32) && (flags & HS_ATTN_F16)) return HS_ERR_ARG;
     if (((uintptr_t)qkv | (uintptr_t)o | (uintptr_t)d_o | (uintptr_t)dqkv) & 15) return HS_ERR_SHAPE;
     const float scale = 0.125f, LOG2E = 1.44269504088896341f;
     if (flags & HS_ATTN_F32) {           // parity mode: every tensor fp32, raw (unscaled) q
@@ -1209,7 +1230,7 @@ extern "C" int hs_attn_bwd(const void* qkv, const void* o, const void* d_o, cons
         return HS_OK;
     }
     if ((size_t)N * 3 * H * 64 * 2 >= HS_MAX_RECORDS) return HS_ERR_SHAPE;
-    const bool pre = (flags & HS_ATTN_Q_PRESCALED) != 0;
+    const bool pre = (flags & HS_ATTN_Q_PRESCALED) != 0, h16 = (flags & HS_ATTN_F16) != 0;
     const float c2 = pre ? 1.0f : scale * LOG2E;
     const float dk_mul = pre ? 1.0f / LOG2E : scale;        // dK = dh^-0.5 dS^T q = dS^T q' / log2(e)
     hipStream_t s = (hipStream_t)stream;
@@ -1222,13 +1243,13 @@ extern "C" int hs_attn_bwd(const void* qkv, const void* o, const void* d_o, cons
     dim3 grid((unsigned)(((N + 127) / 128) * H * B));
     {   // the dQ sweep first: it also writes the row constants the dK/dV sweep preloads (no separate statistics pass)
         ProfScope prof(HS_PROF_ATTN_DQ, stream, 2.0 * nn, 6 * io);
-        hipLaunchKernelGGL(attn_bwd_dq2_kernel<4>, grid, dim3(256), 0, s, (const bf16_t*)qkv, (const bf16_t*)d_o, (const bf16_t*)o, lse,
-                           nstat, (bf16_t*)dqkv, B, N, H, c2, scale);
+        hipLaunchKernelGGL(h16 ? attn_bwd_dq2_w4_f16_kernel : attn_bwd_dq2_w4_kernel, grid, dim3(256), 0, s, (const bf16_t*)qkv,
+                           (const bf16_t*)d_o, (const bf16_t*)o, lse, nstat, (bf16_t*)dqkv, B, N, H, c2, scale);
     }
     {
         ProfScope prof(HS_PROF_ATTN_DKDV, stream, 6.0 * nn, 6 * io);
-        hipLaunchKernelGGL(attn_bwd_dkdv16_w4_kernel, grid, dim3(256), 0, s, (const bf16_t*)qkv, (const bf16_t*)d_o, nstat,
-                           (bf16_t*)dqkv, B, N, H, c2, dk_mul);
+        hipLaunchKernelGGL(h16 ? attn_bwd_dkdv16_w4_f16_kernel : attn_bwd_dkdv16_w4_kernel, grid, dim3(256), 0, s, (const bf16_t*)qkv,
+                           (const bf16_t*)d_o, nstat, (bf16_t*)dqkv, B, N, H, c2, dk_mul);
     }
     HS_CHECK_LAUNCH();
     return HS_OK;

@@ -59,11 +59,12 @@ __device__ __forceinline__ void trR_issue(u32x4& f, unsigned b0, unsigned b1) {
     f[0] = lo[0]; f[1] = lo[1]; f[2] = hi[0]; f[3] = hi[1];
 }
 __device__ __forceinline__ void lds_settle2(u32x4& a, u32x4& b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b)::"memory"); }
+template <bool F16 = false>
 __device__ __forceinline__ bf16x8 scale_frag(u32x4 raw, float mul) {
     u32x4 r;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-        r[i] = pack2bf(__uint_as_float(raw[i] << 16) * mul, __uint_as_float(raw[i] & 0xffff0000u) * mul);
+        r[i] = pack2h<F16>(unpack_lo<F16>(raw[i]) * mul, unpack_hi<F16>(raw[i]) * mul);
     return __builtin_bit_cast(bf16x8, r);
 }
 

@@ -2,11 +2,13 @@
 #pragma once
 #include "common.h"
 
+int hs_gemm_group_prec(const hs_gemm_args* args, int count, int prec, void* stream);      // gemm.hip (declared in hsenet_hip.h too)
+
 int hs_cast_bf16_multi(const float* const* src, void* const* dst, const int64_t* n, int count, void* stream, int f16 = 0);   // small.hip (f16: fp16 instead of bf16)
 int hs_layernorm_fwd16(const float* x, const float* resid, const float* gamma, const float* beta, float* y_f32, void* y_16, float* mean,
                        float* rstd, int rows, int d, float eps, int f16, void* stream);                                        // norm.hip
 // fp32 [R][C] -> bf16 [C][R] for up to `count` matrices in one launch per 64 (R, C multiples of 64)               // small.hip
-int hs_cast_bf16_transpose_multi(const float* const* src, void* const* dst, const int* R, const int* C, int count, void* stream);
+int hs_cast_bf16_transpose_multi(const float* const* src, void* const* dst, const int* R, const int* C, int count, void* stream, int f16 = 0);
 
 namespace hsdrv {
 
@@ -66,8 +68,8 @@ inline int wgrad_group_split(const int (*mn)[2], int count, int K) {
 }
 
 // dW[No_rows = n_out][n_in] += dY^T X   (dY bf16 [rows][ldy] columns [0, n_out), X bf16 [rows][ldx]); dW zeroed by the caller
-inline int wgrad(const void* dy, long ldy, const void* x, long ldx, float* dw, int n_out, int n_in, int rows, void* s) {
-    return gemm(HS_PREC_BF16, HS_GEMM_TN, dy, x, n_out, n_in, rows, ldy, ldx, dw, nullptr, n_in, nullptr, nullptr, nullptr, nullptr,
+inline int wgrad(const void* dy, long ldy, const void* x, long ldx, float* dw, int n_out, int n_in, int rows, void* s, int prec = HS_PREC_BF16) {
+    return gemm(prec, HS_GEMM_TN, dy, x, n_out, n_in, rows, ldy, ldx, dw, nullptr, n_in, nullptr, nullptr, nullptr, nullptr,
                 HS_EPI_ATOMIC, wgrad_split(n_out, n_in, rows), s);
 }
 

@@ -1131,13 +1131,13 @@ struct GemmGroup {
     int first[HS_GEMM_GROUP_MAX + 1];
     int count;
 };
-template <bool ATR, bool BTR, bool BIG, int EF>
+template <bool ATR, bool BTR, bool BIG, int EF, bool F16 = false>
 __global__ __launch_bounds__(512) void gemm_bf16_group_kernel(GemmGroup g) {
     int i = 0;
     while (i + 1 < g.count && (int)blockIdx.x >= g.first[i + 1]) ++i;
     const int b = (int)blockIdx.x - g.first[i];
     if (b >= g.p[i].nblocks) return;                                    // padding up to the next multiple of 8
-    gemm_bf16_body<ATR, BTR, BIG, EF>(g.p[i], b, g.p[i].nblocks);
+    gemm_bf16_body<ATR, BTR, BIG, EF, false, F16>(g.p[i], b, g.p[i].nblocks);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1265,6 +1265,46 @@ struct GemmEnv {
 const GemmEnv kEnv;
 }  // namespace
 
+// kernel selection of the 16-bit GEMMs, once per operand format (H = false: bf16, the training policy; H = true: IEEE fp16 -- since round 5
+// every layout and epilogue, i.e. forward AND backward: same kernels, fp16 packs and the fp16 MFMA opcode)
+struct Launch16 { int layout, f; bool big, col8, m16_ok, persist; int pgrid; };
+template <bool H>
+static void launch16(const GemmP& p, const Launch16& c, dim3 grid, hipStream_t s) {
+    const int f = c.f;
+#define HS_LAUNCH_E(ATR, BTR, EF)                                                                                    \
+    do {                                                                                                             \
+        if (c.big) hipLaunchKernelGGL((gemm_bf16_kernel<ATR, BTR, true, EF, false, H>), grid, dim3(512), 0, s, p);    \
+        else hipLaunchKernelGGL((gemm_bf16_kernel<ATR, BTR, false, EF, false, H>), grid, dim3(512), 0, s, p);         \
+    } while (0)
+#define HS_LAUNCH_M16(EF)                                                                                            \
+    do {                                                                                                             \
+        if (c.persist) hipLaunchKernelGGL((gemm_nt16_persist_kernel<EF, H>), dim3(c.pgrid), dim3(512), 0, s, p);      \
+        else hipLaunchKernelGGL((gemm_bf16_kernel<false, false, true, EF, true, H>), grid, dim3(512), 0, s, p);       \
+    } while (0)
+    if (c.m16_ok) {
+        if (f == 0) HS_LAUNCH_M16(0);
+        else if (f == HS_EPI_BIAS) HS_LAUNCH_M16(HS_EPI_BIAS);        // patch embedding, scorer / packer projections (fp32 out)
+        else if (f == (HS_EPI_BIAS | HS_EPI_RESID)) HS_LAUNCH_M16(HS_EPI_BIAS | HS_EPI_RESID);
+        else if (f == (HS_EPI_GELU_BWD | HS_EPI_SAVE_DGELU)) HS_LAUNCH_M16(HS_EPI_GELU_BWD | HS_EPI_SAVE_DGELU);
+        else HS_LAUNCH_M16(HS_EPI_BIAS | HS_EPI_GELU | HS_EPI_SAVE_DGELU);
+    } else if (c.layout == HS_GEMM_NT) {
+        if (c.col8 && f == 0) HS_LAUNCH_E(false, false, 0);
+        else if (c.col8 && f == (HS_EPI_BIAS | HS_EPI_RESID)) HS_LAUNCH_E(false, false, HS_EPI_BIAS | HS_EPI_RESID);
+        else if (c.col8 && f == (HS_EPI_BIAS | HS_EPI_GELU | HS_EPI_SAVE_DGELU)) HS_LAUNCH_E(false, false, HS_EPI_BIAS | HS_EPI_GELU | HS_EPI_SAVE_DGELU);
+        else if (c.col8 && f == (HS_EPI_GELU_BWD | HS_EPI_SAVE_DGELU)) HS_LAUNCH_E(false, false, HS_EPI_GELU_BWD | HS_EPI_SAVE_DGELU);   // fc2's dgrad against W2^T at shapes too small for the 256x256 tile
+        else HS_LAUNCH_E(false, false, -1);
+    } else if (c.layout == HS_GEMM_NN) {
+        if (c.col8 && f == 0) HS_LAUNCH_E(false, true, 0);
+        else if (c.col8 && f == (HS_EPI_GELU_BWD | HS_EPI_SAVE_DGELU)) HS_LAUNCH_E(false, true, HS_EPI_GELU_BWD | HS_EPI_SAVE_DGELU);
+        else HS_LAUNCH_E(false, true, -1);
+    } else {
+        if (f == HS_EPI_ATOMIC) hipLaunchKernelGGL((gemm_bf16_kernel<true, true, false, HS_EPI_ATOMIC, false, H>), grid, dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((gemm_bf16_kernel<true, true, false, -1, false, H>), grid, dim3(512), 0, s, p);
+    }
+#undef HS_LAUNCH_E
+#undef HS_LAUNCH_M16
+}
+
 extern "C" int hs_gemm_group(const hs_gemm_args* args, int count, void* stream) {
     if (!args || count < 1 || count > HS_GEMM_GROUP_MAX) return HS_ERR_ARG;
     GemmGroup g = {};
@@ -1311,11 +1351,9 @@ extern "C" int hs_gemm(const hs_gemm_args* a, int prec, void* stream) {
     if ((a->flags & HS_EPI_GELU_BWD) && !a->aux) return HS_ERR_ARG;
     if (a->split_k > 1 && (!(a->flags & HS_EPI_ATOMIC) || a->batch != 1 || !a->out_f32 || a->out_bf16)) return HS_ERR_SHAPE;
     if (prec != HS_PREC_BF16 && prec != HS_PREC_F32 && prec != HS_PREC_F16) return HS_ERR_ARG;
-    // fp16 operands: the forward GEMMs only (NT, no gradient epilogues, nothing saved for a backward pass)
-    const bool h16 = prec == HS_PREC_F16;
-    if (h16 && (a->layout != HS_GEMM_NT || (a->flags & (HS_EPI_GELU_BWD | HS_EPI_ATOMIC)) || a->colsum_out || a->aux_out || a->split_k != 1)) return HS_ERR_ARG;
+    const bool h16 = prec == HS_PREC_F16;          // fp16 operands: every layout and epilogue the bf16 path has (round 5)
     if (a->scale_cols < 0 || (a->scale_cols & 3) || (a->scale_cols && (a->flags & HS_EPI_ATOMIC))) return HS_ERR_SHAPE;
-    if (a->colsum_out && (prec != HS_PREC_BF16 || (a->N & 3) || (a->ldc & 3) || a->batch != 1 || (a->flags & HS_EPI_ATOMIC))) return HS_ERR_SHAPE;
+    if (a->colsum_out && (prec == HS_PREC_F32 || (a->N & 3) || (a->ldc & 3) || a->batch != 1 || (a->flags & HS_EPI_ATOMIC))) return HS_ERR_SHAPE;
     const int esz = prec == HS_PREC_F32 ? 4 : 2;
     const int vec = 16 / esz;  // elements per 16-B chunk
     const bool atr = a->layout == HS_GEMM_TN, btr = a->layout != HS_GEMM_NT;
@@ -1372,25 +1410,7 @@ extern "C" int hs_gemm(const hs_gemm_args* a, int prec, void* stream) {
         // epilogue specialisations (compile-time flags); anything else runs the generic kernel (EF = -1)
         const bool col8 = !(a->N & 7) && !(a->ldc & 7) && !(a->scale_cols & 7);
         const int f = a->flags;
-#define HS_LAUNCH_E(ATR, BTR, EF)                                                                                    \
-    do {                                                                                                             \
-        if (big) hipLaunchKernelGGL((gemm_bf16_kernel<ATR, BTR, true, EF>), grid, dim3(512), 0, s, p);                \
-        else hipLaunchKernelGGL((gemm_bf16_kernel<ATR, BTR, false, EF>), grid, dim3(512), 0, s, p);                   \
-    } while (0)
-        // the NT kernels again with fp16 operand packs and the fp16 MFMA opcode (HS_PREC_F16)
-#define HS_LAUNCH_E_NT(EF)                                                                                           \
-    do {                                                                                                             \
-        if (!h16) HS_LAUNCH_E(false, false, EF);                                                                     \
-        else if (big) hipLaunchKernelGGL((gemm_bf16_kernel<false, false, true, EF, false, true>), grid, dim3(512), 0, s, p);   \
-        else hipLaunchKernelGGL((gemm_bf16_kernel<false, false, false, EF, false, true>), grid, dim3(512), 0, s, p); \
-    } while (0)
         const bool m16 = big && a->layout == HS_GEMM_NT && (!a->colsum_out || a->flags == (HS_EPI_GELU_BWD | HS_EPI_SAVE_DGELU)) && !kEnv.no_m16;
-#define HS_LAUNCH_M16(EF)                                                                                            \
-    do {                                                                                                             \
-        if (persist && !h16) hipLaunchKernelGGL((gemm_nt16_persist_kernel<EF, false>), dim3(pgrid), dim3(512), 0, s, p); \
-        else if (h16) hipLaunchKernelGGL((gemm_bf16_kernel<false, false, true, EF, true, true>), grid, dim3(512), 0, s, p); \
-        else hipLaunchKernelGGL((gemm_bf16_kernel<false, false, true, EF, true>), grid, dim3(512), 0, s, p);          \
-    } while (0)
         p.nblocks = (int)grid.x;
         // (the persistent kernel carries no debug stamps: a hook build's HS_DBG modes select the one-tile kernel they instrument)
         const bool persist = kEnv.persist && zdim == 1 && (int)grid.x > ncu && !HS_DBG(p.dbg_);
@@ -1404,32 +1424,9 @@ extern "C" int hs_gemm(const hs_gemm_args* a, int prec, void* stream) {
                          : f == (HS_EPI_BIAS | HS_EPI_RESID) ? HS_PROF_GEMM_NT16_RESID
                          : f == (HS_EPI_GELU_BWD | HS_EPI_SAVE_DGELU) ? HS_PROF_GEMM_NT16_DGELU : HS_PROF_GEMM_NT16_GELU;
         ProfScope prof(pclass, stream, 2.0 * mnk, prof_bytes);
-        if (m16_ok) {
-            if (f == 0) HS_LAUNCH_M16(0);
-            else if (f == HS_EPI_BIAS) HS_LAUNCH_M16(HS_EPI_BIAS);        // patch embedding, scorer / packer projections (fp32 out)
-            else if (f == (HS_EPI_BIAS | HS_EPI_RESID)) HS_LAUNCH_M16(HS_EPI_BIAS | HS_EPI_RESID);
-            else if (f == (HS_EPI_GELU_BWD | HS_EPI_SAVE_DGELU)) {        // (backward only: no fp16 form)
-                if (persist) hipLaunchKernelGGL((gemm_nt16_persist_kernel<HS_EPI_GELU_BWD | HS_EPI_SAVE_DGELU, false>), dim3(pgrid), dim3(512), 0, s, p);
-                else hipLaunchKernelGGL((gemm_bf16_kernel<false, false, true, HS_EPI_GELU_BWD | HS_EPI_SAVE_DGELU, true>), grid, dim3(512), 0, s, p);
-            }
-            else HS_LAUNCH_M16(HS_EPI_BIAS | HS_EPI_GELU | HS_EPI_SAVE_DGELU);
-        } else if (a->layout == HS_GEMM_NT) {
-            if (col8 && f == 0) HS_LAUNCH_E_NT(0);
-            else if (col8 && f == (HS_EPI_BIAS | HS_EPI_RESID)) HS_LAUNCH_E_NT(HS_EPI_BIAS | HS_EPI_RESID);
-            else if (col8 && f == (HS_EPI_BIAS | HS_EPI_GELU | HS_EPI_SAVE_DGELU)) HS_LAUNCH_E_NT(HS_EPI_BIAS | HS_EPI_GELU | HS_EPI_SAVE_DGELU);
-            else if (col8 && f == (HS_EPI_GELU_BWD | HS_EPI_SAVE_DGELU)) HS_LAUNCH_E(false, false, HS_EPI_GELU_BWD | HS_EPI_SAVE_DGELU);   // fc2's dgrad against W2^T at shapes too small for the 256x256 tile
-            else HS_LAUNCH_E_NT(-1);
-        } else if (a->layout == HS_GEMM_NN) {
-            if (col8 && f == 0) HS_LAUNCH_E(false, true, 0);
-            else if (col8 && f == (HS_EPI_GELU_BWD | HS_EPI_SAVE_DGELU)) HS_LAUNCH_E(false, true, HS_EPI_GELU_BWD | HS_EPI_SAVE_DGELU);
-            else HS_LAUNCH_E(false, true, -1);
-        } else {
-            if (f == HS_EPI_ATOMIC) hipLaunchKernelGGL((gemm_bf16_kernel<true, true, false, HS_EPI_ATOMIC>), grid, dim3(512), 0, s, p);
-            else hipLaunchKernelGGL((gemm_bf16_kernel<true, true, false, -1>), grid, dim3(512), 0, s, p);
-        }
-#undef HS_LAUNCH_E
-#undef HS_LAUNCH_E_NT
-#undef HS_LAUNCH_M16
+        const Launch16 ln = {a->layout, f, big, col8, m16_ok, persist, pgrid};
+        if (h16) launch16<true>(p, ln, grid, s);
+        else launch16<false>(p, ln, grid, s);
     } else {
         ProfScope prof(HS_PROF_GEMM_NT + a->layout, stream, 2.0 * mnk, prof_bytes);
         p.tiles_m = (a->M + 63) / 64;

@@ -97,7 +97,8 @@ __device__ __forceinline__ float ln_bwd_out(float gy, float xh, float c1, float 
 // buffer, which set the occupancy of this HBM-bound kernel (NCH=4 for every d cost 200 VGPRs / 48 KiB: 2 waves/SIMD).
 // WPB = waves per block: 4, or 8 for small row counts (one volume per GPU: 4097 rows) where a wave's rows are a serial chain of
 // load latencies -- 16 rows per block then take 2 steps per wave instead of 4 while the block's 3 x d reduction atomics stay the same.
-template <bool DYBF, int NCH, int WPB = 4>
+// DYF: format of dy (0 fp32, 1 bf16, 2 IEEE fp16); OF16: the 16-bit copy of dx leaves as fp16 instead of bf16 (HS_PREC_F16 training)
+template <int DYF, int NCH, int WPB = 4, bool OF16 = false>
 __global__ __launch_bounds__(WPB * 64, (NCH >= 4 && WPB == 4) ? 3 : 16 / WPB) void layernorm_bwd_kernel(const void* __restrict__ dy_, const float* __restrict__ x,
                                                             const float* __restrict__ resid, const float* __restrict__ gamma,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -130,10 +131,10 @@ __global__ __launch_bounds__(WPB * 64, (NCH >= 4 && WPB == 4) ? 3 : 16 / WPB) vo
                 f32x4 xv = *(const f32x4*)(x + (long)row * d + ch * 4);
                 if (resid) xv += *(const f32x4*)(resid + (long)row * d + ch * 4);
                 f32x4 dv;
-                if (DYBF) {
+                if (DYF) {
                     const u32x2 pk = *(const u32x2*)((const bf16_t*)dy_ + (long)row * d + ch * 4);
-                    dv[0] = __uint_as_float(pk[0] << 16); dv[1] = __uint_as_float(pk[0] & 0xffff0000u);
-                    dv[2] = __uint_as_float(pk[1] << 16); dv[3] = __uint_as_float(pk[1] & 0xffff0000u);
+                    dv[0] = unpack_lo<DYF == 2>(pk[0]); dv[1] = unpack_hi<DYF == 2>(pk[0]);
+                    dv[2] = unpack_lo<DYF == 2>(pk[1]); dv[3] = unpack_hi<DYF == 2>(pk[1]);
                 } else {
                     dv = *(const f32x4*)((const float*)dy_ + (long)row * d + ch * 4);
                 }
@@ -159,8 +160,8 @@ __global__ __launch_bounds__(WPB * 64, (NCH >= 4 && WPB == 4) ? 3 : 16 / WPB) vo
                 if (dx) *(f32x4*)(dx + (long)row * d + ch * 4) = o;
                 if (dxb) {
                     u32x2 pk;
-                    pk[0] = pack2bf(o[0], o[1]);
-                    pk[1] = pack2bf(o[2], o[3]);
+                    pk[0] = pack2h<OF16>(o[0], o[1]);
+                    pk[1] = pack2h<OF16>(o[2], o[3]);
                     *(u32x2*)(dxb + (long)row * d + ch * 4) = pk;
                 }
             }
@@ -189,10 +190,10 @@ __global__ __launch_bounds__(WPB * 64, (NCH >= 4 && WPB == 4) ? 3 : 16 / WPB) vo
                     f32x4 xv = *(const f32x4*)(x + (long)row * d + ch * 4);
                     if (resid) xv += *(const f32x4*)(resid + (long)row * d + ch * 4);
                     f32x4 dv;
-                    if (DYBF) {
+                    if (DYF) {
                         const u32x2 pk = *(const u32x2*)((const bf16_t*)dy_ + (long)row * d + ch * 4);
-                        dv[0] = __uint_as_float(pk[0] << 16); dv[1] = __uint_as_float(pk[0] & 0xffff0000u);
-                        dv[2] = __uint_as_float(pk[1] << 16); dv[3] = __uint_as_float(pk[1] & 0xffff0000u);
+                        dv[0] = unpack_lo<DYF == 2>(pk[0]); dv[1] = unpack_hi<DYF == 2>(pk[0]);
+                        dv[2] = unpack_lo<DYF == 2>(pk[1]); dv[3] = unpack_hi<DYF == 2>(pk[1]);
                     } else {
                         dv = *(const f32x4*)((const float*)dy_ + (long)row * d + ch * 4);
                     }
@@ -216,8 +217,8 @@ __global__ __launch_bounds__(WPB * 64, (NCH >= 4 && WPB == 4) ? 3 : 16 / WPB) vo
                     if (dx) *(f32x4*)(dx + (long)row * d + ch * 4) = o;
                     if (dxb) {
                         u32x2 pk;
-                        pk[0] = pack2bf(o[0], o[1]);
-                        pk[1] = pack2bf(o[2], o[3]);
+                        pk[0] = pack2h<OF16>(o[0], o[1]);
+                        pk[1] = pack2h<OF16>(o[2], o[3]);
                         *(u32x2*)(dxb + (long)row * d + ch * 4) = pk;
                     }
                 }
@@ -268,6 +269,11 @@ extern "C" int hs_layernorm_bwd(const void* dy, int dy_is_bf16, const float* x, 
                                 float* dgamma, float* dbeta, float* dxsum, int rows, int d, void* stream) {
     if (!dy || !x || !gamma || !mean || !rstd || (!dx && !dx_bf16)) return HS_ERR_ARG;
     if (rows < 1 || d < 4 || (d & 3) || d > LN_MAXCH * 256) return HS_ERR_SHAPE;
+    // dy_is_bf16: HS_LN_DY_F32 (0) / HS_LN_DY_BF16 (1) / HS_LN_DY_F16 (2: dy fp16 and the 16-bit dx copy fp16), or
+    // HS_LN_DY_F32 | HS_LN_OUT_F16 (4: fp32 dy, the 16-bit dx copy as fp16 -- the top of an fp16 backward pass)
+    const int dyf = dy_is_bf16 & 3;
+    const bool of16 = dyf == 2 || (dy_is_bf16 & 4);
+    if (dyf == 3 || (dy_is_bf16 & ~7) || ((dy_is_bf16 & 4) && dyf == 1)) return HS_ERR_ARG;
     // every block ends with 3 x d float atomics (dgamma, dbeta, dxsum): at one row per wave they outweigh the rows' own traffic
     // (4097 rows x 768: 45.5 us with 4 rows per block, 28.3 us with 16), so a block takes 16 rows while that still leaves >= 256 blocks
     int blocks = (rows + 3) / 4;
@@ -281,22 +287,27 @@ extern "C" int hs_layernorm_bwd(const void* dy, int dy_is_bf16, const float* x, 
     if (HS_DBG(g_hs_dbg[5]) == 1) wide = false;                            // (hook builds: A/B of the two variants, tools/ln_bwd_ab.py)
     if (HS_DBG(g_hs_dbg[5]) == 2) wide = rows / 32 >= 1 && d <= 768;
     if (wide) blocks = (rows + 31) / 32;
-    ProfScope prof(HS_PROF_LN_BWD, stream, 0, (double)rows * d * (4 + (dy_is_bf16 ? 2 : 4) + (resid ? 4 : 0) + (dx_in ? 4 : 0) + (dx ? 4 : 0) + (dx_bf16 ? 2 : 0)));
+    ProfScope prof(HS_PROF_LN_BWD, stream, 0, (double)rows * d * (4 + (dyf ? 2 : 4) + (resid ? 4 : 0) + (dx_in ? 4 : 0) + (dx ? 4 : 0) + (dx_bf16 ? 2 : 0)));
     const int nchunks = (d + 255) / 256;
-#define HS_LN_BWD(DYBF, NCH)                                                                                              \
+#define HS_LN_BWD(DYF, OF16, NCH)                                                                                         \
     do {                                                                                                                  \
         if (wide && NCH <= 3)                                                                                             \
-            hipLaunchKernelGGL((layernorm_bwd_kernel<DYBF, (NCH <= 3 ? NCH : 1), 8>), dim3(blocks), dim3(512), 0, (hipStream_t)stream, dy, x, \
+            hipLaunchKernelGGL((layernorm_bwd_kernel<DYF, (NCH <= 3 ? NCH : 1), 8, OF16>), dim3(blocks), dim3(512), 0, (hipStream_t)stream, dy, x, \
                                resid, gamma, mean, rstd, dx_in, dx, (bf16_t*)dx_bf16, dgamma, dbeta, dxsum, rows, d);      \
         else                                                                                                              \
-            hipLaunchKernelGGL((layernorm_bwd_kernel<DYBF, NCH>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, x, resid, gamma, \
+            hipLaunchKernelGGL((layernorm_bwd_kernel<DYF, NCH, 4, OF16>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, x, resid, gamma, \
                                mean, rstd, dx_in, dx, (bf16_t*)dx_bf16, dgamma, dbeta, dxsum, rows, d);                    \
     } while (0)
-    if (dy_is_bf16) {
-        if (nchunks == 1) HS_LN_BWD(true, 1); else if (nchunks == 2) HS_LN_BWD(true, 2); else if (nchunks == 3) HS_LN_BWD(true, 3); else HS_LN_BWD(true, 4);
-    } else {
-        if (nchunks == 1) HS_LN_BWD(false, 1); else if (nchunks == 2) HS_LN_BWD(false, 2); else if (nchunks == 3) HS_LN_BWD(false, 3); else HS_LN_BWD(false, 4);
-    }
+#define HS_LN_BWD_N(DYF, OF16)                                                                                            \
+    do {                                                                                                                  \
+        if (nchunks == 1) HS_LN_BWD(DYF, OF16, 1); else if (nchunks == 2) HS_LN_BWD(DYF, OF16, 2);                         \
+        else if (nchunks == 3) HS_LN_BWD(DYF, OF16, 3); else HS_LN_BWD(DYF, OF16, 4);                                      \
+    } while (0)
+    if (dyf == 1) HS_LN_BWD_N(1, false);
+    else if (dyf == 2) HS_LN_BWD_N(2, true);
+    else if (of16) HS_LN_BWD_N(0, true);
+    else HS_LN_BWD_N(0, false);
+#undef HS_LN_BWD_N
 #undef HS_LN_BWD
     HS_CHECK_LAUNCH();
     return HS_OK;

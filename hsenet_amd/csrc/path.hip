@@ -20,6 +20,7 @@ using namespace hsdrv;
 // ---------------------------------------------------------------------------------------------------------------------
 // dst[b*dst_bstride + r*d + :] = src[b*src_bstride + r*d + :] for r < R  (fp32 and/or bf16 copies): strided row blocks, e.g. the
 // packer reading rows 1.. of [B][N][d]
+template <bool F16>
 __global__ __launch_bounds__(256) void rows_gather_kernel(const float* __restrict__ src, float* __restrict__ dst,
                                                           bf16_t* __restrict__ dstb, long src_bstride, long dst_bstride, int R, int d,
                                                           long total) {
@@ -35,7 +36,7 @@ __global__ __launch_bounds__(256) void rows_gather_kernel(const float* __restric
     if (dst) *(f32x4*)(dst + o) = v;
     if (dstb) {
         u32x2 pk;
-        pk[0] = pack2bf(v[0], v[1]); pk[1] = pack2bf(v[2], v[3]);
+        pk[0] = pack2h<F16>(v[0], v[1]); pk[1] = pack2h<F16>(v[2], v[3]);
         *(u32x2*)(dstb + o) = pk;
     }
 }
@@ -55,6 +56,7 @@ __global__ __launch_bounds__(256) void rows_scatter_kernel(const float* __restri
     *(f32x4*)(dst + row * d + ch * 4) = v;
 }
 // out = a (+ b) as fp32 and/or bf16
+template <bool F16>
 __global__ __launch_bounds__(256) void add_cast_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ of,
                                                        bf16_t* __restrict__ ob, long n4) {
     const long g = (long)blockIdx.x * 256 + threadIdx.x;
@@ -64,23 +66,26 @@ __global__ __launch_bounds__(256) void add_cast_kernel(const float* __restrict__
     if (of) *(f32x4*)(of + g * 4) = v;
     if (ob) {
         u32x2 pk;
-        pk[0] = pack2bf(v[0], v[1]); pk[1] = pack2bf(v[2], v[3]);
+        pk[0] = pack2h<F16>(v[0], v[1]); pk[1] = pack2h<F16>(v[2], v[3]);
         *(u32x2*)(ob + g * 4) = pk;
     }
 }
-static int add_cast(const float* a, const float* b, float* of, void* ob, long n, void* stream) {
+static int add_cast(const float* a, const float* b, float* of, void* ob, long n, void* stream, int f16 = 0) {
     if (n & 3) return HS_ERR_SHAPE;
     ProfScope prof(HS_PROF_OTHER, stream, 0, (double)n * (4 + (b ? 4 : 0) + (of ? 4 : 0) + (ob ? 2 : 0)));
-    hipLaunchKernelGGL(add_cast_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, b, of, (bf16_t*)ob,
-                       n / 4);
+    if (f16) hipLaunchKernelGGL(add_cast_kernel<true>, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, b, of, (bf16_t*)ob, n / 4);
+    else hipLaunchKernelGGL(add_cast_kernel<false>, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, b, of, (bf16_t*)ob, n / 4);
     HS_CHECK_LAUNCH();
     return HS_OK;
 }
-static int rows_gather(const float* src, float* dst, void* dstb, long src_bstride, int B, int R, int d, void* stream, long dst_bstride = -1) {
+static int rows_gather(const float* src, float* dst, void* dstb, long src_bstride, int B, int R, int d, void* stream, long dst_bstride = -1,
+                       int f16 = 0) {
     const long total = (long)B * R * (d / 4);
     ProfScope prof(HS_PROF_OTHER, stream, 0, (double)B * R * d * (4 + (dst ? 4 : 0) + (dstb ? 2 : 0)));
-    hipLaunchKernelGGL(rows_gather_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, dst,
-                       (bf16_t*)dstb, src_bstride, dst_bstride < 0 ? (long)R * d : dst_bstride, R, d, total);
+    if (f16) hipLaunchKernelGGL(rows_gather_kernel<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, dst,
+                                (bf16_t*)dstb, src_bstride, dst_bstride < 0 ? (long)R * d : dst_bstride, R, d, total);
+    else hipLaunchKernelGGL(rows_gather_kernel<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, dst,
+                            (bf16_t*)dstb, src_bstride, dst_bstride < 0 ? (long)R * d : dst_bstride, R, d, total);
     HS_CHECK_LAUNCH();
     return HS_OK;
 }
@@ -104,6 +109,10 @@ extern "C" int hs_rows_scatter(const float* src, float* dst, int B, int r0, int 
     if (B < 1 || R < 1 || r0 < 0 || r0 + R > Rt || d < 4 || (d & 3) || (((uintptr_t)src | (uintptr_t)dst) & 15)) return HS_ERR_SHAPE;
     return rows_scatter(src, dst, B, r0, R, Rt, d, stream);
 }
+
+// fp32 -> the driver's 16-bit operand format (bf16, or IEEE fp16 for a descriptor with prec = HS_PREC_F16)
+static int cast16(const float* x, void* y, int64_t n, void* stream, int f16) { return f16 ? hs_cast_f16(x, y, n, stream) : hs_cast_bf16(x, y, n, stream); }
+static int prec_check(int prec) { return prec == HS_PREC_BF16 || prec == HS_PREC_F16 ? HS_OK : HS_ERR_ARG; }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // embedding driver
@@ -152,6 +161,7 @@ int embed_check(const hs_embed_desc* c) {
     if (!c) return HS_ERR_ARG;
     if (c->B < 1 || c->Np < 1 || c->Pd < 8 || (c->Pd & 7) || c->d < 8 || (c->d & 7) || c->d > 1024) return HS_ERR_SHAPE;
     if (!(c->drop_p >= 0.f && c->drop_p < 1.f)) return HS_ERR_ARG;
+    RC(prec_check(c->prec));
     if (c->scorer) {
         if (c->ns < 4 || c->ns > 64 || (c->ns & 3) || (c->Np & 3)) return HS_ERR_SHAPE;     // hs_cross_attn_* limits
     }
@@ -176,7 +186,7 @@ extern "C" int hs_embed_fwd(const hs_embed_desc* desc, const void* patches, cons
     char* w = (char*)ws;
     const int M = c.B * c.Np, d = c.d, Ms = c.B * c.ns;
     const size_t Md = (size_t)M * d;
-    const int P = HS_PREC_BF16;
+    const int P = c.prec, f16 = P == HS_PREC_F16;       // 16-bit operand format of every GEMM / cast of this call
     {
         std::vector<const float*> src = {ep[E_WPE]};
         std::vector<void*> dst = {w + L.w_pe};
@@ -190,7 +200,7 @@ extern "C" int hs_embed_fwd(const hs_embed_desc* desc, const void* patches, cons
             }
             if (!ep[E_WS] || !ep[E_BS] || !ep[E_NW] || !ep[E_NB]) return HS_ERR_ARG;
         }
-        RC(hs_cast_bf16_multi(src.data(), dst.data(), cnt.data(), (int)src.size(), stream));
+        RC(hs_cast_bf16_multi(src.data(), dst.data(), cnt.data(), (int)src.size(), stream, f16));
     }
     float* pe = (float*)(w + L.pe);
     RC(gemm(P, HS_GEMM_NT, patches, w + L.w_pe, M, d, c.Pd, c.Pd, c.Pd, pe, nullptr, d, ep[E_BPE], nullptr, nullptr, nullptr, HS_EPI_BIAS, 1,
@@ -203,13 +213,13 @@ extern "C" int hs_embed_fwd(const hs_embed_desc* desc, const void* patches, cons
     float *ao = (float*)(w + L.ao), *xo = (float*)(w + L.xo), *ln = (float*)(w + L.ln), *st = (float*)(w + L.stats);
     float* score = (float*)(w + L.score);
     RC(hs_assemble_tokens(pe, ep[E_POS], nullptr, nullptr, xe, nullptr, c.B, c.Np, d, stream));          // x = embedding + pos (vit.py:325)
-    RC(hs_cast_bf16(xe, w + L.xe_b, (int64_t)Md, stream));
+    RC(cast16(xe, w + L.xe_b, (int64_t)Md, stream, f16));
     RC(gemm(P, HS_GEMM_NT, w + L.xe_b, w + L.w_q, M, d, d, d, d, q, nullptr, d, ep[E_BQ], nullptr, nullptr, nullptr, HS_EPI_BIAS, 1, stream));
-    RC(hs_cast_bf16(image_2d, w + L.sem_b, (int64_t)Ms * d, stream));                                    // image_2d.view(B, 32, -1) (:332)
+    RC(cast16(image_2d, w + L.sem_b, (int64_t)Ms * d, stream, f16));                                    // image_2d.view(B, 32, -1) (:332)
     RC(gemm(P, HS_GEMM_NT, w + L.sem_b, w + L.w_k, Ms, d, d, d, d, k, nullptr, d, ep[E_BK], nullptr, nullptr, nullptr, HS_EPI_BIAS, 1, stream));
     RC(gemm(P, HS_GEMM_NT, w + L.sem_b, w + L.w_v, Ms, d, d, d, d, v, nullptr, d, ep[E_BV], nullptr, nullptr, nullptr, HS_EPI_BIAS, 1, stream));
     RC(hs_cross_attn_fwd(q, k, v, ao, p, pd, c.B, c.Np, c.ns, d, c.drop_p, c.seed[0], c.offset[0], stream));
-    RC(hs_cast_bf16(ao, w + L.ao_b, (int64_t)Md, stream));
+    RC(cast16(ao, w + L.ao_b, (int64_t)Md, stream, f16));
     RC(gemm(P, HS_GEMM_NT, w + L.ao_b, w + L.w_o, M, d, d, d, d, xo, nullptr, d, ep[E_BO], nullptr, nullptr, nullptr, HS_EPI_BIAS, 1, stream));
     if (c.drop_p > 0.f) RC(hs_dropout(xo, xo, (int64_t)Md, c.drop_p, c.seed[1], c.offset[1], stream));
     RC(hs_layernorm_fwd(q, xo, ep[E_NW], ep[E_NB], ln, nullptr, st, st + M, M, d, 1e-5f, stream));      // norm(query + dropout(x)) (:62)
@@ -229,7 +239,7 @@ extern "C" int hs_embed_bwd(const hs_embed_desc* desc, const void* patches, cons
     char* w = (char*)ws;
     const int M = c.B * c.Np, d = c.d, Ms = c.B * c.ns;
     const size_t Md = (size_t)M * d;
-    const int P = HS_PREC_BF16;
+    const int P = c.prec, f16 = P == HS_PREC_F16;       // 16-bit operand format of every GEMM / cast of this call
     float* dpe = (float*)(w + L.dpe);
     float* dcls = c.has_cls ? eg[E_CLS] : nullptr;
     const float* dpe_tot = dpe;
@@ -248,36 +258,36 @@ extern "C" int hs_embed_bwd(const hs_embed_desc* desc, const void* patches, cons
         RC(hs_assemble_tokens_bwd(dtokens, xe, score, dpe, nullptr, dcls, dscore, c.B, c.Np, d, stream));
         RC(hs_rowdot_sigmoid_bwd(ln, ep[E_WS], score, dscore, dln, eg[E_WS], eg[E_BS], M, d, stream));
         const bool drop = c.drop_p > 0.f;
-        RC(hs_layernorm_bwd(dln, 0, q, xo, ep[E_NW], st, st + M, nullptr, dsum, w + L.dsum_b, eg[E_NW], eg[E_NB], drop ? nullptr : eg[E_BO],
+        RC(hs_layernorm_bwd(dln, f16 ? HS_LN_OUT_F16 : 0, q, xo, ep[E_NW], st, st + M, nullptr, dsum, w + L.dsum_b, eg[E_NW], eg[E_NB], drop ? nullptr : eg[E_BO],
                             M, d, stream));
         const void* dxo_b = w + L.dsum_b;
         if (drop) {                         // d(dropout_2(x)) : same Philox mask as the forward
             float* dxo = (float*)(w + L.dxo);
             RC(hs_dropout(dsum, dxo, (int64_t)Md, c.drop_p, c.seed[1], c.offset[1], stream));
-            RC(hs_cast_bf16(dxo, w + L.dxo_b, (int64_t)Md, stream));
-            RC(hs_colsum(w + L.dxo_b, 1, eg[E_BO], M, d, d, stream));
+            RC(cast16(dxo, w + L.dxo_b, (int64_t)Md, stream, f16));
+            RC(hs_colsum(w + L.dxo_b, 1 + f16, eg[E_BO], M, d, d, stream));
             dxo_b = w + L.dxo_b;
         }
-        RC(wgrad(dxo_b, d, w + L.ao_b, d, eg[E_WO], d, d, M, stream));
+        RC(wgrad(dxo_b, d, w + L.ao_b, d, eg[E_WO], d, d, M, stream, P));
         RC(gemm(P, HS_GEMM_NN, dxo_b, w + L.w_o, M, d, d, d, d, dao, nullptr, d, nullptr, nullptr, nullptr, nullptr, 0, 1, stream));
         RC(hs_cross_attn_bwd(q, k, v, p, pd, dao, dq2, dk, dv, pws, c.B, c.Np, c.ns, d, c.drop_p, c.seed[0], c.offset[0], stream));
-        RC(add_cast(dsum, dq2, nullptr, w + L.dq_b, (long)Md, stream));                 // dq = residual branch + attention branch
-        RC(wgrad(w + L.dq_b, d, w + L.xe_b, d, eg[E_WQ], d, d, M, stream));
-        RC(hs_colsum(w + L.dq_b, 1, eg[E_BQ], M, d, d, stream));
+        RC(add_cast(dsum, dq2, nullptr, w + L.dq_b, (long)Md, stream, f16));                 // dq = residual branch + attention branch
+        RC(wgrad(w + L.dq_b, d, w + L.xe_b, d, eg[E_WQ], d, d, M, stream, P));
+        RC(hs_colsum(w + L.dq_b, 1 + f16, eg[E_BQ], M, d, d, stream));
         // dx total = token path + Query path
         RC(gemm(P, HS_GEMM_NN, w + L.dq_b, w + L.w_q, M, d, d, d, d, dpe2, nullptr, d, nullptr, dpe, nullptr, nullptr, HS_EPI_RESID, 1, stream));
         dpe_tot = dpe2;
         RC(hs_assemble_tokens_bwd(dpe2, nullptr, nullptr, nullptr, eg[E_POS], nullptr, nullptr, c.B, c.Np, d, stream));   // dpos += sum_b dx
-        RC(hs_cast_bf16(dk, w + L.dk_b, (int64_t)Ms * d, stream));
-        RC(hs_cast_bf16(dv, w + L.dv_b, (int64_t)Ms * d, stream));
-        RC(wgrad(w + L.dk_b, d, w + L.sem_b, d, eg[E_WK], d, d, Ms, stream));
-        RC(wgrad(w + L.dv_b, d, w + L.sem_b, d, eg[E_WV], d, d, Ms, stream));
-        RC(hs_colsum(w + L.dk_b, 1, eg[E_BK], Ms, d, d, stream));
-        RC(hs_colsum(w + L.dv_b, 1, eg[E_BV], Ms, d, d, stream));
+        RC(cast16(dk, w + L.dk_b, (int64_t)Ms * d, stream, f16));
+        RC(cast16(dv, w + L.dv_b, (int64_t)Ms * d, stream, f16));
+        RC(wgrad(w + L.dk_b, d, w + L.sem_b, d, eg[E_WK], d, d, Ms, stream, P));
+        RC(wgrad(w + L.dv_b, d, w + L.sem_b, d, eg[E_WV], d, d, Ms, stream, P));
+        RC(hs_colsum(w + L.dk_b, 1 + f16, eg[E_BK], Ms, d, d, stream));
+        RC(hs_colsum(w + L.dv_b, 1 + f16, eg[E_BV], Ms, d, d, stream));
     }
-    RC(hs_cast_bf16(dpe_tot, w + L.dpe_b, (int64_t)Md, stream));
-    RC(wgrad(w + L.dpe_b, d, patches, c.Pd, eg[E_WPE], d, c.Pd, M, stream));
-    return hs_colsum(w + L.dpe_b, 1, eg[E_BPE], M, d, d, stream);
+    RC(cast16(dpe_tot, w + L.dpe_b, (int64_t)Md, stream, f16));
+    RC(wgrad(w + L.dpe_b, d, patches, c.Pd, eg[E_WPE], d, c.Pd, M, stream, P));
+    return hs_colsum(w + L.dpe_b, 1 + f16, eg[E_BPE], M, d, d, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -327,6 +337,7 @@ int pack_check(const hs_packer_desc* c) {
     const int64_t cells = (int64_t)(c->gd / c->kd) * (c->gh / c->kh) * (c->gw / c->kw);
     if (c->out_batch_stride < cells * c->out_dim || (c->out_batch_stride & 7)) return HS_ERR_SHAPE;
     if (!(c->drop_p >= 0.f && c->drop_p < 1.f)) return HS_ERR_ARG;
+    RC(prec_check(c->prec));
     return HS_OK;
 }
 
@@ -349,12 +360,12 @@ extern "C" int hs_packer_fwd(const hs_packer_desc* desc, const float* feat, cons
     const int d = c.d, od = c.out_dim;
     const int T = c.gd * c.gh * c.gw, cells = (c.gd / c.kd) * (c.gh / c.kh) * (c.gw / c.kw);
     const int Mt = c.B * T, Mc = c.B * cells;
-    const int P = HS_PREC_BF16;
+    const int P = c.prec, f16 = P == HS_PREC_F16;       // 16-bit operand format of every GEMM / cast of this call
     {   // bf16 weight copies; [Wk; Wv] adjacent so that K and V of every HR token come out of ONE GEMM (59 % of the packer's FLOPs)
         const float* src[6] = {pp[K_W1], pp[K_W2], pp[K_WQ], pp[K_WK], pp[K_WV], pp[K_WO]};
         void* dst[6] = {w + L.w1, w + L.w2, w + L.wq, w + L.wkv, w + L.wkv + (size_t)d * d * 2, w + L.wo};
         const int64_t cnt[6] = {(int64_t)od * d, (int64_t)od * od, (int64_t)d * d, (int64_t)d * d, (int64_t)d * d, (int64_t)d * d};
-        RC(hs_cast_bf16_multi(src, dst, cnt, 6, stream));
+        RC(hs_cast_bf16_multi(src, dst, cnt, 6, stream, f16));
         float* bkv = (float*)(w + L.bkv);
         RC(hs_scale(pp[K_BK], bkv, 1.0f, d, stream));
         RC(hs_scale(pp[K_BV], bkv + d, 1.0f, d, stream));
@@ -362,17 +373,17 @@ extern "C" int hs_packer_fwd(const hs_packer_desc* desc, const float* feat, cons
     float *hr = (float*)(w + L.hr), *lr = (float*)(w + L.lr), *q = (float*)(w + L.q), *kv = (float*)(w + L.kv);
     float *xo = (float*)(w + L.xo), *xl = (float*)(w + L.xl), *st = (float*)(w + L.stats);
     // visual_inputs.view(B, gd, gh, gw, 768) (:140); the 'patch' feature selection (vit.py:934-936) = in_row_offset 1
-    RC(rows_gather(feat + (size_t)c.in_row_offset * d, hr, w + L.hr_b, (long)c.in_batch_stride, c.B, T, d, stream));
+    RC(rows_gather(feat + (size_t)c.in_row_offset * d, hr, w + L.hr_b, (long)c.in_batch_stride, c.B, T, d, stream, -1, f16));
     RC(hs_pool3d_fwd(hr, lr, c.B, c.gd, c.gh, c.gw, c.kd, c.kh, c.kw, d, stream));                          // :141 avg_pool3d
-    RC(hs_cast_bf16(lr, w + L.lr_b, (int64_t)Mc * d, stream));
+    RC(cast16(lr, w + L.lr_b, (int64_t)Mc * d, stream, f16));
     RC(gemm(P, HS_GEMM_NT, w + L.lr_b, w + L.wq, Mc, d, d, d, d, q, nullptr, d, pp[K_BQ], nullptr, nullptr, nullptr, HS_EPI_BIAS, 1, stream));
     RC(gemm(P, HS_GEMM_NT, w + L.hr_b, w + L.wkv, Mt, 2 * d, d, d, d, kv, nullptr, 2 * d, (const float*)(w + L.bkv), nullptr, nullptr, nullptr,
             HS_EPI_BIAS, 1, stream));
     RC(hs_window_attn_fwd(q, kv, xo, c.B, c.gd, c.gh, c.gw, c.kd, c.kh, c.kw, d, c.drop_p, c.seed[0], c.offset[0], stream));
-    RC(hs_cast_bf16(xo, w + L.xo_b, (int64_t)Mc * d, stream));
+    RC(cast16(xo, w + L.xo_b, (int64_t)Mc * d, stream, f16));
     RC(gemm(P, HS_GEMM_NT, w + L.xo_b, w + L.wo, Mc, d, d, d, d, xl, nullptr, d, pp[K_BO], nullptr, nullptr, nullptr, HS_EPI_BIAS, 1, stream));
     if (c.drop_p > 0.f) RC(hs_dropout(xl, xl, (int64_t)Mc * d, c.drop_p, c.seed[1], c.offset[1], stream));
-    RC(hs_layernorm_fwd(q, xl, pp[K_NW], pp[K_NB], nullptr, w + L.fe_b, st, st + Mc, Mc, d, 1e-5f, stream));   // :82
+    RC(hs_layernorm_fwd16(q, xl, pp[K_NW], pp[K_NB], nullptr, w + L.fe_b, st, st + Mc, Mc, d, 1e-5f, f16, stream));   // :82
     // proj_mpls: Linear -> GELU -> Linear (:127-131,144)
     RC(gemm(P, HS_GEMM_NT, w + L.fe_b, w + L.w1, Mc, od, d, d, d, nullptr, w + L.a, od, pp[K_B1], nullptr, nullptr,
             c.save_for_bwd ? w + L.gz : nullptr, HS_EPI_BIAS | HS_EPI_GELU | HS_EPI_SAVE_DGELU, 1, stream));
@@ -397,7 +408,7 @@ extern "C" int hs_packer_bwd(const hs_packer_desc* desc, const float* dout, cons
     const int d = c.d, od = c.out_dim;
     const int T = c.gd * c.gh * c.gw, cells = (c.gd / c.kd) * (c.gh / c.kh) * (c.gw / c.kw);
     const int Mt = c.B * T, Mc = c.B * cells;
-    const int P = HS_PREC_BF16;
+    const int P = c.prec, f16 = P == HS_PREC_F16;       // 16-bit operand format of every GEMM / cast of this call
     const bool drop = c.drop_p > 0.f;
     // dfeat is written as a DENSE [B][in_row_offset + T][d] tensor: a padded input stride would put every batch entry after the
     // first at the wrong offset, so it is refused (before anything is launched) rather than scattered silently
@@ -406,41 +417,41 @@ extern "C" int hs_packer_bwd(const hs_packer_desc* desc, const float* dout, cons
     float *dsum = (float*)(w + L.dsum), *dxo = (float*)(w + L.dxo), *dq2 = (float*)(w + L.dq2), *dkv = (float*)(w + L.dkv);
     float *dlr = (float*)(w + L.dlr), *dhr = (float*)(w + L.dhr);
     // ---- proj_mpls
-    RC(rows_gather(dout, nullptr, w + L.dout_b, (long)c.out_batch_stride, c.B, cells, od, stream));
-    RC(wgrad(w + L.dout_b, od, w + L.a, od, pg[K_W2], od, od, Mc, stream));
-    RC(hs_colsum(w + L.dout_b, 1, pg[K_B2], Mc, od, od, stream));
+    RC(rows_gather(dout, nullptr, w + L.dout_b, (long)c.out_batch_stride, c.B, cells, od, stream, -1, f16));
+    RC(wgrad(w + L.dout_b, od, w + L.a, od, pg[K_W2], od, od, Mc, stream, P));
+    RC(hs_colsum(w + L.dout_b, 1 + f16, pg[K_B2], Mc, od, od, stream));
     RC(gemm(P, HS_GEMM_NN, w + L.dout_b, w + L.w2, Mc, od, od, od, od, nullptr, w + L.dz, od, nullptr, nullptr, w + L.gz, nullptr,
             HS_EPI_GELU_BWD | HS_EPI_SAVE_DGELU, 1, stream, pg[K_B1]));
-    RC(wgrad(w + L.dz, od, w + L.fe_b, d, pg[K_W1], od, d, Mc, stream));
+    RC(wgrad(w + L.dz, od, w + L.fe_b, d, pg[K_W1], od, d, Mc, stream, P));
     RC(gemm(P, HS_GEMM_NN, w + L.dz, w + L.w1, Mc, d, od, od, d, nullptr, w + L.dfe, d, nullptr, nullptr, nullptr, nullptr, 0, 1, stream));
     // ---- LN(q + dropout(output_linear(attn)))
-    RC(hs_layernorm_bwd(w + L.dfe, 1, q, xl, pp[K_NW], st, st + Mc, nullptr, dsum, w + L.dsum_b, pg[K_NW], pg[K_NB], drop ? nullptr : pg[K_BO],
+    RC(hs_layernorm_bwd(w + L.dfe, f16 ? HS_LN_DY_F16 : HS_LN_DY_BF16, q, xl, pp[K_NW], st, st + Mc, nullptr, dsum, w + L.dsum_b, pg[K_NW], pg[K_NB], drop ? nullptr : pg[K_BO],
                         Mc, d, stream));
     const void* dxl_b = w + L.dsum_b;
     if (drop) {
         float* dxl = (float*)(w + L.dxl);
         RC(hs_dropout(dsum, dxl, (int64_t)Mc * d, c.drop_p, c.seed[1], c.offset[1], stream));
-        RC(hs_cast_bf16(dxl, w + L.dxl_b, (int64_t)Mc * d, stream));
-        RC(hs_colsum(w + L.dxl_b, 1, pg[K_BO], Mc, d, d, stream));
+        RC(cast16(dxl, w + L.dxl_b, (int64_t)Mc * d, stream, f16));
+        RC(hs_colsum(w + L.dxl_b, 1 + f16, pg[K_BO], Mc, d, d, stream));
         dxl_b = w + L.dxl_b;
     }
-    RC(wgrad(dxl_b, d, w + L.xo_b, d, pg[K_WO], d, d, Mc, stream));
+    RC(wgrad(dxl_b, d, w + L.xo_b, d, pg[K_WO], d, d, Mc, stream, P));
     RC(gemm(P, HS_GEMM_NN, dxl_b, w + L.wo, Mc, d, d, d, d, dxo, nullptr, d, nullptr, nullptr, nullptr, nullptr, 0, 1, stream));
     // ---- window attention: tokens outside every window (grid not divisible by the kernel) get no gradient
     if ((c.gd % c.kd) || (c.gh % c.kh) || (c.gw % c.kw)) {
         if (hipMemsetAsync(dkv, 0, (size_t)Mt * 2 * d * 4, (hipStream_t)stream) != hipSuccess) return HS_ERR_LAUNCH;
     }
     RC(hs_window_attn_bwd(q, kv, dxo, dq2, dkv, c.B, c.gd, c.gh, c.gw, c.kd, c.kh, c.kw, d, c.drop_p, c.seed[0], c.offset[0], stream));
-    RC(add_cast(dsum, dq2, nullptr, w + L.dq_b, (long)Mc * d, stream));
-    RC(wgrad(w + L.dq_b, d, w + L.lr_b, d, pg[K_WQ], d, d, Mc, stream));
-    RC(hs_colsum(w + L.dq_b, 1, pg[K_BQ], Mc, d, d, stream));
+    RC(add_cast(dsum, dq2, nullptr, w + L.dq_b, (long)Mc * d, stream, f16));
+    RC(wgrad(w + L.dq_b, d, w + L.lr_b, d, pg[K_WQ], d, d, Mc, stream, P));
+    RC(hs_colsum(w + L.dq_b, 1 + f16, pg[K_BQ], Mc, d, d, stream));
     RC(gemm(P, HS_GEMM_NN, w + L.dq_b, w + L.wq, Mc, d, d, d, d, dlr, nullptr, d, nullptr, nullptr, nullptr, nullptr, 0, 1, stream));
-    RC(hs_cast_bf16(dkv, w + L.dkv_b, (int64_t)Mt * 2 * d, stream));
+    RC(cast16(dkv, w + L.dkv_b, (int64_t)Mt * 2 * d, stream, f16));
     const char* dkv_b = w + L.dkv_b;
-    RC(wgrad(dkv_b, 2 * d, w + L.hr_b, d, pg[K_WK], d, d, Mt, stream));
-    RC(wgrad(dkv_b + (size_t)d * 2, 2 * d, w + L.hr_b, d, pg[K_WV], d, d, Mt, stream));
-    RC(hs_colsum(dkv_b, 1, pg[K_BK], Mt, d, 2 * d, stream));
-    RC(hs_colsum(dkv_b + (size_t)d * 2, 1, pg[K_BV], Mt, d, 2 * d, stream));
+    RC(wgrad(dkv_b, 2 * d, w + L.hr_b, d, pg[K_WK], d, d, Mt, stream, P));
+    RC(wgrad(dkv_b + (size_t)d * 2, 2 * d, w + L.hr_b, d, pg[K_WV], d, d, Mt, stream, P));
+    RC(hs_colsum(dkv_b, 1 + f16, pg[K_BK], Mt, d, 2 * d, stream));
+    RC(hs_colsum(dkv_b + (size_t)d * 2, 1 + f16, pg[K_BV], Mt, d, 2 * d, stream));
     if (!dfeat) return HS_OK;                 // input features not differentiated (frozen towers: lamed_arch.py:66)
     RC(gemm(P, HS_GEMM_NN, dkv_b, w + L.wkv, Mt, d, 2 * d, 2 * d, d, dhr, nullptr, d, nullptr, nullptr, nullptr, nullptr, 0, 1, stream));
     RC(hs_pool3d_bwd(dlr, dhr, c.B, c.gd, c.gh, c.gw, c.kd, c.kh, c.kw, d, 1, stream));

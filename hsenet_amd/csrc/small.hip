@@ -570,9 +570,10 @@ extern "C" int hs_window_attn_bwd(const float* q, const float* kv, const float* 
 // K7/K8
 // ------------------------------------------------------------------------------------------------------
 // out[n] += sum_m x[m][n].  Block: 32 column groups (16 B each) x 8 row lanes; grid (col strips, row chunks).
-template <bool BF16>
+template <int FMT>       // 0 fp32, 1 bf16, 2 IEEE fp16
 __global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ x, float* __restrict__ out, int M, int N, long ldx,
                                                      int rows_per_block) {
+    constexpr bool BF16 = FMT != 0;
     constexpr int V = BF16 ? 8 : 4;
     __shared__ float red[8][32 * V];
     const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;
@@ -588,8 +589,8 @@ __global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ x,
                 const u32x4 v = *(const u32x4*)((const bf16_t*)x + (long)r * ldx + col0);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    acc[2 * i] += __uint_as_float(v[i] << 16);
-                    acc[2 * i + 1] += __uint_as_float(v[i] & 0xffff0000u);
+                    acc[2 * i] += unpack_lo<FMT == 2>(v[i]);
+                    acc[2 * i + 1] += unpack_hi<FMT == 2>(v[i]);
                 }
             } else {
                 const f32x4 v = *(const f32x4*)((const float*)x + (long)r * ldx + col0);
@@ -613,13 +614,15 @@ __global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ x,
 }
 extern "C" int hs_colsum(const void* x, int is_bf16, float* out, int M, int N, int64_t ldx, void* stream) {
     if (!x || !out) return HS_ERR_ARG;
+    if (is_bf16 < 0 || is_bf16 > 2) return HS_ERR_ARG;        // 0 fp32, 1 bf16, 2 fp16
     const int V = is_bf16 ? 8 : 4;
     if (M < 1 || N < V || (N % V) || (ldx % V) || ((uintptr_t)x & 15)) return HS_ERR_SHAPE;
     const int rpb = 512;
     dim3 grid((N + 32 * V - 1) / (32 * V), (M + rpb - 1) / rpb);
     ProfScope prof(HS_PROF_COLSUM, stream, 0, (double)M * N * (is_bf16 ? 2 : 4));
-    if (is_bf16) hipLaunchKernelGGL(colsum_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, out, M, N, (long)ldx, rpb);
-    else hipLaunchKernelGGL(colsum_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, out, M, N, (long)ldx, rpb);
+    if (is_bf16 == 2) hipLaunchKernelGGL(colsum_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, x, out, M, N, (long)ldx, rpb);
+    else if (is_bf16) hipLaunchKernelGGL(colsum_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, x, out, M, N, (long)ldx, rpb);
+    else hipLaunchKernelGGL(colsum_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, x, out, M, N, (long)ldx, rpb);
     HS_CHECK_LAUNCH();
     return HS_OK;
 }
@@ -716,6 +719,7 @@ int hs_cast_bf16_multi(const float* const* src, void* const* dst, const int64_t*
 // GEMM kernel; against W^T [in][out] the same product is an NT GEMM and runs on the forward's kernel.  Up to 64 matrices per
 // launch, 64 x 64 tiles through LDS, R and C multiples of 64.  Internal to the library (vit.hip); rounding = hs_cast_bf16's.
 struct CastTSegs { const float* src[64]; bf16_t* dst[64]; int R[64], C[64]; int first[65]; };
+template <bool F16>
 __global__ __launch_bounds__(256) void cast_bf16_transpose_multi_kernel(CastTSegs g) {
     __shared__ __attribute__((aligned(16))) bf16_t t[64][64 + 8];          // 144-B rows: 16-B aligned reads
     int b = blockIdx.x, sgm = 0;
@@ -730,14 +734,14 @@ __global__ __launch_bounds__(256) void cast_bf16_transpose_multi_kernel(CastTSeg
     for (int k = 0; k < 4; ++k) {
         const f32x4 v = *(const f32x4*)(x + (long)(r0 + tr) * C + c0 + tb + 4 * k);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) t[tb + 4 * k + e][tr] = f2bf(v[e]);
+        for (int e = 0; e < 4; ++e) t[tb + 4 * k + e][tr] = f2h<F16>(v[e]);
     }
     __syncthreads();
     const u32x4 lo = *(const u32x4*)&t[tr][tb], hi = *(const u32x4*)&t[tr][tb + 8];
     *(u32x4*)(y + (long)(c0 + tr) * R + r0 + tb) = lo;
     *(u32x4*)(y + (long)(c0 + tr) * R + r0 + tb + 8) = hi;
 }
-int hs_cast_bf16_transpose_multi(const float* const* src, void* const* dst, const int* R, const int* C, int count, void* stream) {
+int hs_cast_bf16_transpose_multi(const float* const* src, void* const* dst, const int* R, const int* C, int count, void* stream, int f16) {
     if (!src || !dst || !R || !C || count < 1) return HS_ERR_ARG;
     for (int c0 = 0; c0 < count; c0 += 64) {
         CastTSegs g;
@@ -754,7 +758,8 @@ int hs_cast_bf16_transpose_multi(const float* const* src, void* const* dst, cons
         }
         for (int i = cnt; i < 64; ++i) { g.src[i] = nullptr; g.dst[i] = nullptr; g.R[i] = 0; g.C[i] = 0; g.first[i + 1] = g.first[cnt]; }
         ProfScope prof(HS_PROF_CAST, stream, 0, bytes);
-        hipLaunchKernelGGL(cast_bf16_transpose_multi_kernel, dim3((unsigned)g.first[cnt]), dim3(256), 0, (hipStream_t)stream, g);
+        if (f16) hipLaunchKernelGGL(cast_bf16_transpose_multi_kernel<true>, dim3((unsigned)g.first[cnt]), dim3(256), 0, (hipStream_t)stream, g);
+        else hipLaunchKernelGGL(cast_bf16_transpose_multi_kernel<false>, dim3((unsigned)g.first[cnt]), dim3(256), 0, (hipStream_t)stream, g);
         HS_CHECK_LAUNCH();
     }
     return HS_OK;

@@ -112,9 +112,14 @@ int hs_assemble_tokens_bwd(const float* dtok, const float* pe_pos, const float* 
  * x fp32 [rows][d]; optional resid added first (y = LN(x + resid)); writes y as fp32 and/or bf16; mean/rstd optional. */
 int hs_layernorm_fwd(const float* x, const float* resid, const float* gamma, const float* beta, float* y_f32,
                      void* y_bf16, float* mean, float* rstd, int rows, int d, float eps, void* stream);
-/* dx = LNbwd(dy) (+ dx_in when given); dy fp32 or bf16 (dy_is_bf16); also emits a bf16 copy of the result;
+/* dx = LNbwd(dy) (+ dx_in when given); dy fp32, bf16 or fp16 (dy_is_bf16 = HS_LN_DY_*); also emits a 16-bit copy of the result (bf16; fp16
+ * with HS_LN_DY_F16, or with HS_LN_DY_F32 | HS_LN_OUT_F16 = fp32 dy at the top of an fp16 backward pass);
  * dgamma/dbeta accumulate atomically (caller zeroes).  x (and resid) are the forward inputs.  dxsum (optional, [d])
  * accumulates the column sums of the produced dx = the bias gradient of the Linear this dx is the output-gradient of. */
+#define HS_LN_DY_F32 0
+#define HS_LN_DY_BF16 1
+#define HS_LN_DY_F16 2
+#define HS_LN_OUT_F16 4
 int hs_layernorm_bwd(const void* dy, int dy_is_bf16, const float* x, const float* resid, const float* gamma,
                      const float* mean, const float* rstd, const float* dx_in, float* dx, void* dx_bf16, float* dgamma,
                      float* dbeta, float* dxsum, int rows, int d, void* stream);
@@ -128,9 +133,12 @@ int hs_layernorm_bwd(const void* dy, int dy_is_bf16, const float* x, const float
  * bf16 rounding of q).  o, lse and dqkv mean the same either way (dqkv is the gradient of the UNSCALED q, k, v). */
 #define HS_ATTN_Q_PRESCALED 1
 #define HS_ATTN_F32 2          /* hs_attn_bwd only: qkv, o, d_o, dqkv are fp32 (exact-f32 MFMA parity mode; raw q) */
+#define HS_ATTN_F16 16         /* hs_attn_bwd only: qkv, o, d_o, dqkv are IEEE fp16 (HS_PREC_F16 training: the two bf16 sweeps with fp16
+                                * packs and the fp16 MFMA opcode; P = exp2(S') <= 1 and dS = P dP' sit in fp16's range for a loss-scaled dO) */
 int hs_attn_fwd(const void* qkv, void* o, float* lse, int B, int N, int H, int dh, int prec, int flags, void* stream);
 /* dqkv from (qkv, o, do, lse); delta_ws: fp32 scratch 2 x [B][H][N] (row constants -sum(dO*O) and -lse*log2(e)).
- * bf16 tensors, or fp32 ones with HS_ATTN_F32 (parity mode: the same two sweeps on v_mfma_f32_32x32x2_f32, no rounding). */
+ * bf16 tensors, fp16 ones with HS_ATTN_F16, or fp32 ones with HS_ATTN_F32 (parity mode: the same two sweeps on
+ * v_mfma_f32_32x32x2_f32, no rounding). */
 int hs_attn_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv, float* delta_ws,
                 int B, int N, int H, int dh, int flags, void* stream);
 /* The same gradients with a caller-sized workspace (bytes from hs_attn_bwd_ws_bytes for the same flags, 256-B aligned, ZEROED before its

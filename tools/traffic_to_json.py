@@ -3,7 +3,7 @@ hbm_bytes_per_launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024   (FETCH_SIZE/WRITE_
 import csv, glob, json, sys, collections
 out, batch = sys.argv[1], int(sys.argv[2])
 workload = sys.argv[3] if len(sys.argv) > 3 else "dual256"
-CLASS = {"attn_fwd_fast_kernel": "attn_fwd", "attn_bwd_dkdv16_w4_kernel": "attn_bwd_dkdv", "attn_bwd_dq2_kernel": "attn_bwd_dq",
+CLASS = {"attn_fwd_fast_kernel": "attn_fwd", "attn_bwd_dkdv16_w4_kernel": "attn_bwd_dkdv", "attn_bwd_dq2_w4": "attn_bwd_dq",
          "gemm_bf16_kernel<false, false": "gemm_nt", "gemm_bf16_kernel<false, true": "gemm_nn", "gemm_bf16_kernel<true, true": "gemm_tn",
          "gemm_bf16_group_kernel<true, true": "gemm_tn_group",
          "layernorm_bwd_kernel": "layernorm_bwd", "layernorm_fwd_kernel": "layernorm_fwd"}

@@ -21,7 +21,7 @@ out, batch = sys.argv[1], int(sys.argv[2])
 workload = sys.argv[3] if len(sys.argv) > 3 else "dual256"
 tag = sys.argv[4] if len(sys.argv) > 4 else "r04"
 # kernel-name substring -> class (= hs_prof_name() of the library's per-kernel timers); first match wins
-CLASS = [("attn_fwd_fast_kernel", "attn_fwd"), ("attn_bwd_dkdv16_w4_kernel", "attn_bwd_dkdv"), ("attn_bwd_dq2_kernel", "attn_bwd_dq"),
+CLASS = [("attn_fwd_fast_kernel", "attn_fwd"), ("attn_bwd_dkdv16_w4_kernel", "attn_bwd_dkdv"), ("attn_bwd_dq2_w4", "attn_bwd_dq"),
          ("gemm_nt16_persist_kernel<0,", "gemm_nt16_plain"), ("gemm_nt16_persist_kernel<9,", "gemm_nt16_bias_resid"), ("gemm_nt16_persist_kernel<1,", "gemm_nt16_bias"),
          ("gemm_nt16_persist_kernel<67,", "gemm_nt16_bias_gelu"), ("gemm_nt16_persist_kernel<68,", "gemm_nt16_dgelu"),
          ("gemm_bf16_kernel<false, false, true, 0, true", "gemm_nt16_plain"), ("gemm_bf16_kernel<false, false, true, 9, true", "gemm_nt16_bias_resid"),
