@@ -16,7 +16,8 @@ HS_OK, HS_ERR_SHAPE, HS_ERR_ARCH, HS_ERR_LAUNCH, HS_ERR_ARG = 0, -1, -2, -3, -4
 PREC_BF16, PREC_F32, PREC_F16 = 0, 1, 2
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 EPI_BIAS, EPI_GELU, EPI_GELU_BWD, EPI_RESID, EPI_ATOMIC, EPI_BIAS_M, EPI_SAVE_DGELU = 1, 2, 4, 8, 16, 32, 64
-ATTN_Q_PRESCALED, ATTN_F32, ATTN_ONE_SWEEP, ATTN_ONE_SWEEP_TILES = 1, 2, 4, 8
+ATTN_Q_PRESCALED, ATTN_F32, ATTN_ONE_SWEEP, ATTN_ONE_SWEEP_TILES, ATTN_F16 = 1, 2, 4, 8, 16
+LN_DY_F32, LN_DY_BF16, LN_DY_F16, LN_OUT_F16 = 0, 1, 2, 4
 Q_PRESCALE = 0.125 * 1.44269504088896341   # dh^-0.5 * log2(e) for dh = 64 (hs_gemm scale_cols_alpha for the q third)
 
 _ERR = {HS_ERR_SHAPE: "unsupported shape/alignment", HS_ERR_ARCH: "no gfx950 device", HS_ERR_LAUNCH: "HIP launch error",
@@ -44,14 +45,15 @@ class VitDesc(C.Structure):
 
 class EmbedDesc(C.Structure):
     _fields_ = [("B", C.c_int), ("Np", C.c_int), ("Pd", C.c_int), ("d", C.c_int), ("has_cls", C.c_int), ("scorer", C.c_int),
-                ("ns", C.c_int), ("save_for_bwd", C.c_int), ("drop_p", C.c_float), ("seed", C.c_uint64 * 2), ("offset", C.c_uint64 * 2)]
+                ("ns", C.c_int), ("save_for_bwd", C.c_int), ("drop_p", C.c_float), ("seed", C.c_uint64 * 2), ("offset", C.c_uint64 * 2),
+                ("prec", C.c_int)]
 
 
 class PackerDesc(C.Structure):
     _fields_ = [("B", C.c_int), ("gd", C.c_int), ("gh", C.c_int), ("gw", C.c_int), ("kd", C.c_int), ("kh", C.c_int), ("kw", C.c_int),
                 ("d", C.c_int), ("out_dim", C.c_int), ("in_row_offset", C.c_int), ("in_batch_stride", C.c_int64),
                 ("out_batch_stride", C.c_int64), ("save_for_bwd", C.c_int), ("drop_p", C.c_float), ("seed", C.c_uint64 * 2),
-                ("offset", C.c_uint64 * 2)]
+                ("offset", C.c_uint64 * 2), ("prec", C.c_int)]
 
 
 _vp, _i, _f, _i64, _sz, _u64 = C.c_void_p, C.c_int, C.c_float, C.c_int64, C.c_size_t, C.c_uint64
@@ -63,6 +65,7 @@ SIGNATURES = {
     "hs_device_check": [_i],
     "hs_gemm": [C.POINTER(GemmArgs), _i, _vp],
     "hs_gemm_group": [C.POINTER(GemmArgs), _i, _vp],
+    "hs_gemm_group_prec": [C.POINTER(GemmArgs), _i, _i, _vp],
     "hs_patchify": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "hs_assemble_tokens": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "hs_assemble_tokens_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
@@ -112,6 +115,7 @@ SIGNATURES = {
     "hs_packer_fwd": [C.POINTER(PackerDesc), _vp, _vp, _vp, _vp, _sz, _vp],
     "hs_packer_bwd": [C.POINTER(PackerDesc), _vp, _vp, _vp, _vp, _vp, _sz, _vp],
     "hs_mse_grad": [_vp, _vp, _vp, _i64, _vp],
+    "hs_mse_grad_scaled": [_vp, _vp, _vp, _i64, _f, _vp],
     "hs_sumsq": [_vp, _vp, _vp, _i64, _vp],
     "hs_adamw_masked": [_vp, _vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _f, _vp, _f, _i, _vp],
     "hs_rows_copy": [_vp, _i64, _vp, _vp, _i64, _i, _i, _i, _vp],

@@ -16,6 +16,7 @@
 #include <type_traits>
 
 #define NEG_INF (-__builtin_inff())
+#define HS_F16_PSHIFT 6        // attention backward at fp16 operands: P, dS carried as P * 2^6, dS * 2^6 (see attn_bwd_dq2_body)
 #if HS_ABL & 1
 #define HS_BWD_EXP2(x) (x)
 #else
@@ -771,7 +772,9 @@ __device__ __forceinline__ void attn_bwd_dq2_body(const bf16_t* __restrict__ qkv
     }
     dsum += __shfl_xor(dsum, 32, 64);                        // lanes c and c + 32 hold the two halves of every 16-wide k-step of row qrow
     const long srow = ((long)b * H + head) * N + qrow;
-    const float nd = -dsum, nl = -lse[srow] * 1.44269504088896341f;
+    // fp16: P enters as P * 2^HS_F16_PSHIFT (the shift rides in the row constant, for free): dS = P dP' of a near-uniform row is ~|dP'| / N,
+    // which for N = 4097 sits at the bottom of fp16's normal range (6.1e-5); the factor is taken out again where dQ / dK / dV are stored
+    const float nd = -dsum, nl = -lse[srow] * 1.44269504088896341f + (F16 ? (float)HS_F16_PSHIFT : 0.0f);
     if (h == 0 && q0 + c < N) {                              // one writer per query row (rows past N are clamped duplicates)
         ws[srow] = nd;
         ws[(long)B * H * N + srow] = nl;
@@ -931,7 +934,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_w4_f16_kernel(const bf16_
 template <int NW, bool F16>
 __device__ __forceinline__ void attn_bwd_dkdv16_body(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
                                                      const float* __restrict__ ws, bf16_t* __restrict__ dqkv, int B,
-                                                     int N, int H, float kmul, float dk_mul) {
+                                                     int N, int H, float kmul, float dk_mul, float dv_mul) {
     constexpr int STG = 16896, KBK = NW * 32, NP = 8 / NW;
     __shared__ __attribute__((aligned(16))) char smem[3 * STG];
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
@@ -1146,8 +1149,8 @@ __device__ __forceinline__ void attn_bwd_dkdv16_body(const bf16_t* __restrict__ 
                 v[0] = pack2h<F16>(dk[di][ki][0] * dk_mul, dk[di][ki][1] * dk_mul);
                 v[1] = pack2h<F16>(dk[di][ki][2] * dk_mul, dk[di][ki][3] * dk_mul);
                 *(u32x2*)(row + Dm + 16 * di + 4 * g) = v;
-                v[0] = pack2h<F16>(dv[di][ki][0], dv[di][ki][1]);
-                v[1] = pack2h<F16>(dv[di][ki][2], dv[di][ki][3]);
+                v[0] = pack2h<F16>(dv[di][ki][0] * dv_mul, dv[di][ki][1] * dv_mul);
+                v[1] = pack2h<F16>(dv[di][ki][2] * dv_mul, dv[di][ki][3] * dv_mul);
                 *(u32x2*)(row + 2 * Dm + 16 * di + 4 * g) = v;
             }
         }
@@ -1157,13 +1160,13 @@ __device__ __forceinline__ void attn_bwd_dkdv16_body(const bf16_t* __restrict__ 
 // (thin non-template kernel: hipcc's host pass silently dropped the launch stub of the templated __global__ form)
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv16_w4_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
                                                                    const float* __restrict__ ws, bf16_t* __restrict__ dqkv, int B,
-                                                                   int N, int H, float kmul, float dk_mul) {
-    attn_bwd_dkdv16_body<4, false>(qkv, d_o, ws, dqkv, B, N, H, kmul, dk_mul);
+                                                                   int N, int H, float kmul, float dk_mul, float dv_mul) {
+    attn_bwd_dkdv16_body<4, false>(qkv, d_o, ws, dqkv, B, N, H, kmul, dk_mul, dv_mul);
 }
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv16_w4_f16_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
                                                                        const float* __restrict__ ws, bf16_t* __restrict__ dqkv, int B,
-                                                                       int N, int H, float kmul, float dk_mul) {
-    attn_bwd_dkdv16_body<4, true>(qkv, d_o, ws, dqkv, B, N, H, kmul, dk_mul);
+                                                                       int N, int H, float kmul, float dk_mul, float dv_mul) {
+    attn_bwd_dkdv16_body<4, true>(qkv, d_o, ws, dqkv, B, N, H, kmul, dk_mul, dv_mul);
 }
 
 extern "C" int hs_attn_fwd(const void* qkv, void* o, float* lse, int B, int N, int H, int dh, int prec, int flags, void* stream) {
@@ -1233,6 +1236,7 @@ extern "C" int hs_attn_bwd(const void* qkv, const void* o, const void* d_o, cons
     const bool pre = (flags & HS_ATTN_Q_PRESCALED) != 0, h16 = (flags & HS_ATTN_F16) != 0;
     const float c2 = pre ? 1.0f : scale * LOG2E;
     const float dk_mul = pre ? 1.0f / LOG2E : scale;        // dK = dh^-0.5 dS^T q = dS^T q' / log2(e)
+    const float unshift = h16 ? 1.0f / (float)(1 << HS_F16_PSHIFT) : 1.0f;     // (fp16: the kernels carry P and dS times 2^HS_F16_PSHIFT)
     hipStream_t s = (hipStream_t)stream;
     // FLOP credit follows SURVEY.md 8(d): the backward's ALGORITHMIC work is 2.0 x the forward's 4*nn (dV, dP, dQ, dK: four
     // products); the recomputation of S (both kernels) and of dP (dQ kernel) is executed but NOT counted.  dK/dV kernel: dV, dP, dK
@@ -1244,12 +1248,12 @@ extern "C" int hs_attn_bwd(const void* qkv, const void* o, const void* d_o, cons
     {   // the dQ sweep first: it also writes the row constants the dK/dV sweep preloads (no separate statistics pass)
         ProfScope prof(HS_PROF_ATTN_DQ, stream, 2.0 * nn, 6 * io);
         hipLaunchKernelGGL(h16 ? attn_bwd_dq2_w4_f16_kernel : attn_bwd_dq2_w4_kernel, grid, dim3(256), 0, s, (const bf16_t*)qkv,
-                           (const bf16_t*)d_o, (const bf16_t*)o, lse, nstat, (bf16_t*)dqkv, B, N, H, c2, scale);
+                           (const bf16_t*)d_o, (const bf16_t*)o, lse, nstat, (bf16_t*)dqkv, B, N, H, c2, scale * unshift);
     }
     {
         ProfScope prof(HS_PROF_ATTN_DKDV, stream, 6.0 * nn, 6 * io);
         hipLaunchKernelGGL(h16 ? attn_bwd_dkdv16_w4_f16_kernel : attn_bwd_dkdv16_w4_kernel, grid, dim3(256), 0, s, (const bf16_t*)qkv,
-                           (const bf16_t*)d_o, nstat, (bf16_t*)dqkv, B, N, H, c2, dk_mul);
+                           (const bf16_t*)d_o, nstat, (bf16_t*)dqkv, B, N, H, c2, dk_mul * unshift, unshift);
     }
     HS_CHECK_LAUNCH();
     return HS_OK;

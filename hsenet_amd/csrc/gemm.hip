@@ -1305,8 +1305,10 @@ static void launch16(const GemmP& p, const Launch16& c, dim3 grid, hipStream_t s
 #undef HS_LAUNCH_M16
 }
 
-extern "C" int hs_gemm_group(const hs_gemm_args* args, int count, void* stream) {
+extern "C" int hs_gemm_group(const hs_gemm_args* args, int count, void* stream) { return hs_gemm_group_prec(args, count, HS_PREC_BF16, stream); }
+extern "C" int hs_gemm_group_prec(const hs_gemm_args* args, int count, int prec, void* stream) {
     if (!args || count < 1 || count > HS_GEMM_GROUP_MAX) return HS_ERR_ARG;
+    if (prec != HS_PREC_BF16 && prec != HS_PREC_F16) return HS_ERR_ARG;
     GemmGroup g = {};
     double flops = 0, bytes = 0;
     int nblocks = 0;
@@ -1337,7 +1339,8 @@ extern "C" int hs_gemm_group(const hs_gemm_args* args, int count, void* stream) 
     g.first[count] = nblocks;
     g.count = count;
     ProfScope prof(HS_PROF_GEMM_TN_GROUP, stream, flops, bytes);
-    hipLaunchKernelGGL((gemm_bf16_group_kernel<true, true, false, HS_EPI_ATOMIC>), dim3(nblocks), dim3(512), 0, (hipStream_t)stream, g);
+    if (prec == HS_PREC_F16) hipLaunchKernelGGL((gemm_bf16_group_kernel<true, true, false, HS_EPI_ATOMIC, true>), dim3(nblocks), dim3(512), 0, (hipStream_t)stream, g);
+    else hipLaunchKernelGGL((gemm_bf16_group_kernel<true, true, false, HS_EPI_ATOMIC>), dim3(nblocks), dim3(512), 0, (hipStream_t)stream, g);
     HS_CHECK_LAUNCH();
     return HS_OK;
 }

@@ -463,27 +463,31 @@ extern "C" int hs_packer_bwd(const hs_packer_desc* desc, const float* dout, cons
 // ---------------------------------------------------------------------------------------------------------------------
 // L = mean(y^2):  dy = y * 2/n ;  loss[0] += sum(y^2)/n
 __global__ __launch_bounds__(256) void mse_grad_kernel(const float* __restrict__ y, float* __restrict__ dy, float* __restrict__ loss, long n,
-                                                       float inv_n) {
+                                                       float inv_n, float gscale) {
     float acc = 0.f;
+    const float k = 2.0f * inv_n * gscale;
     for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long)gridDim.x * 1024) {
         if (i + 4 <= n) {
             const f32x4 v = *(const f32x4*)(y + i);
-            *(f32x4*)(dy + i) = v * (2.0f * inv_n);
+            *(f32x4*)(dy + i) = v * k;
             acc += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
         } else {
-            for (long j = i; j < n; ++j) { dy[j] = y[j] * 2.0f * inv_n; acc += y[j] * y[j]; }
+            for (long j = i; j < n; ++j) { dy[j] = y[j] * k; acc += y[j] * y[j]; }
         }
     }
     acc = wave_sum(acc);
     if (loss && (threadIdx.x & 63) == 0) atomicAdd(loss, acc * inv_n);
 }
-extern "C" int hs_mse_grad(const float* y, float* dy, float* loss, int64_t n, void* stream) {
+extern "C" int hs_mse_grad(const float* y, float* dy, float* loss, int64_t n, void* stream) { return hs_mse_grad_scaled(y, dy, loss, n, 1.0f, stream); }
+// the same with dy multiplied by `grad_scale` (the loss scale of an fp16 backward pass; `loss` stays the unscaled mean square)
+extern "C" int hs_mse_grad_scaled(const float* y, float* dy, float* loss, int64_t n, float grad_scale, void* stream) {
     if (!y || !dy) return HS_ERR_ARG;
+    if (!(grad_scale > 0.f)) return HS_ERR_ARG;
     if (n < 1 || (((uintptr_t)y | (uintptr_t)dy) & 15)) return HS_ERR_SHAPE;
     long blocks = (n + 1023) / 1024;
     if (blocks > 2048) blocks = 2048;
     ProfScope prof(HS_PROF_OTHER, stream, 0, (double)n * 8);
-    hipLaunchKernelGGL(mse_grad_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, y, dy, loss, (long)n, 1.0f / (float)n);
+    hipLaunchKernelGGL(mse_grad_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, y, dy, loss, (long)n, 1.0f / (float)n, grad_scale);
     HS_CHECK_LAUNCH();
     return HS_OK;
 }
@@ -540,6 +544,9 @@ __global__ __launch_bounds__(256) void adamw_masked_kernel(float* __restrict__ p
     if (i >= n) return;
     float scale = gs;
     if (gsq) {     // clip_grad_norm_: coef = max_norm / (||g|| + 1e-6), applied when < 1
+        // a non-finite gradient norm (an fp16 backward pass that overflowed its loss scale) skips the update, moments included -- what
+        // torch.cuda.amp.GradScaler.step does; with finite gradients this branch is never taken
+        if (!(gsq[0] < 3.0e38f)) return;
         const float nrm = sqrtf(gsq[0]) * gs;
         const float coef = max_norm / (nrm + 1e-6f);
         if (coef < 1.0f) scale *= coef;

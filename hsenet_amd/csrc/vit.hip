@@ -46,7 +46,7 @@ Layout make_layout(const hs_vit_desc& c) {
     L.per_w = 3 * d * d + d * d + mlp * d + d * mlp;
     L.wbf = take(c.prec != HS_PREC_F32 ? (size_t)c.L * L.per_w * 2 : 0);      // 16-bit (bf16 / fp16) weight copies
     // TRANSPOSED bf16 weight copies for the backward pass' dgrads (see dgrad_nt below): same per-layer order [Wqkv^T | Wo^T | W1^T | W2^T]
-    L.wbft = take(c.prec == HS_PREC_BF16 && c.save_for_bwd && dgrad_nt(c) ? (size_t)c.L * L.per_w * 2 : 0);
+    L.wbft = take(c.prec != HS_PREC_F32 && c.save_for_bwd && dgrad_nt(c) ? (size_t)c.L * L.per_w * 2 : 0);
     L.xmid = take(Ls * M * d * 4);
     L.h1 = take(Ls * M * d * es);
     L.h2 = take(Ls * M * d * es);
@@ -63,7 +63,7 @@ Layout make_layout(const hs_vit_desc& c) {
     // bf16 copies of the residual-stream gradient (GEMM operand): THREE rotating buffers -- a layer's backward produces two new ones
     // (after LN2 and after LN1 backward) and its four weight-gradient GEMMs, launched as ONE group at the end of the layer, still
     // read the previous two.  Copy j (j = 0 entering the top layer, two per layer) lives in buffer j % 3, so chunked calls agree.
-    L.dxb = take(bwd && c.prec == HS_PREC_BF16 ? 3 * al256(M * d * 2) : 0);
+    L.dxb = take(bwd && c.prec != HS_PREC_F32 ? 3 * al256(M * d * 2) : 0);
     L.dob = take(bwd ? M * d * es : 0);
     L.dz = take(bwd ? M * mlp * es : 0);
     L.dqkv = take(bwd ? M * 3 * d * es : 0);
@@ -80,8 +80,7 @@ int check_desc(const hs_vit_desc* c) {
     if ((c->d & 7) || (c->mlp & 7) || c->d > 1024) return HS_ERR_SHAPE;
     if (c->prec != HS_PREC_BF16 && c->prec != HS_PREC_F32 && c->prec != HS_PREC_F16) return HS_ERR_ARG;
     if (c->save_for_bwd < 0 || c->save_for_bwd > 2) return HS_ERR_ARG;
-    if (c->save_for_bwd == 2 && c->prec != HS_PREC_BF16) return HS_ERR_ARG;   // MLP recompute: the bf16 path's option
-    if (c->prec == HS_PREC_F16 && c->save_for_bwd) return HS_ERR_ARG;    // fp16 operands: forward only
+    if (c->save_for_bwd == 2 && c->prec == HS_PREC_F32) return HS_ERR_ARG;   // MLP recompute: the 16-bit paths' option
     if (c->ln_eps < 0.f) return HS_ERR_ARG;
     if (c->qkv_bias && c->save_for_bwd) return HS_ERR_ARG;          // the biased projection is forward-only
     return HS_OK;
@@ -193,8 +192,11 @@ extern "C" int hs_vit_blocks_bwd(const hs_vit_desc* desc, const float* x0, const
     const int M = c.B * c.N, d = c.d, mlp = c.mlp;
     const size_t Md = (size_t)M * d;
     // bf16 (the reference's autocast policy): GEMM operands / dgrad outputs bf16, residual-stream gradient fp32 + bf16 copies.
+    // f16 (round 5): the same sequence and kernels with IEEE fp16 wherever bf16 stands (the caller's dy carries a power-of-two loss scale).
     // f32 (parity mode): everything fp32, exact-f32 MFMA GEMMs and attention.
-    const bool bf = c.prec == HS_PREC_BF16;
+    const bool bf = c.prec != HS_PREC_F32;
+    const int f16 = c.prec == HS_PREC_F16;
+    const int ln16 = f16 ? HS_LN_DY_F16 : HS_LN_DY_BF16;
     const size_t es = bf ? 2 : 4;
     const int P = c.prec;
     float* dx = (float*)(w + L.dx);
@@ -218,12 +220,12 @@ extern "C" int hs_vit_blocks_bwd(const hs_vit_desc* desc, const float* x0, const
             src.push_back(p[P_W1]); dst.push_back(wl + 4 * d * d); R.push_back(mlp); Cc.push_back(d);
             src.push_back(p[P_W2]); dst.push_back(wl + 4 * d * d + (size_t)mlp * d); R.push_back(d); Cc.push_back(mlp);
         }
-        RC(hs_cast_bf16_transpose_multi(src.data(), dst.data(), R.data(), Cc.data(), (int)src.size(), stream));
+        RC(hs_cast_bf16_transpose_multi(src.data(), dst.data(), R.data(), Cc.data(), (int)src.size(), stream, f16));
     }
     if (l_hi == c.L) {
         const float* fs = (const float*)(w + L.fstats);
         // (each LN backward also emits the column sums of the dx it produces = the bias gradient of the Linear below it)
-        RC(hs_layernorm_bwd(dy, 0, hidden + (size_t)(c.L - 1) * Md, nullptr, np[0], fs, fs + M, nullptr, dx, dxb, ng[0], ng[1],
+        RC(hs_layernorm_bwd(dy, f16 ? HS_LN_OUT_F16 : HS_LN_DY_F32, hidden + (size_t)(c.L - 1) * Md, nullptr, np[0], fs, fs + M, nullptr, dx, dxb, ng[0], ng[1],
                             lg[(size_t)(c.L - 1) * P_COUNT + P_B2], M, d, stream));
     }
     for (int l = l_hi - 1; l >= l_lo; --l) {
@@ -267,16 +269,16 @@ extern "C" int hs_vit_blocks_bwd(const hs_vit_desc* desc, const float* x0, const
                          HS_EPI_GELU_BWD | HS_EPI_SAVE_DGELU, 1, stream, g[P_B1]));
             if (nt) RC(gemm(P, HS_GEMM_NT, dz, w1t, M, d, mlp, mlp, mlp, nullptr, dh, d, nullptr, nullptr, nullptr, nullptr, 0, 1, stream));
             else RC(gemm(P, HS_GEMM_NN, dz, w1, M, d, mlp, mlp, d, nullptr, dh, d, nullptr, nullptr, nullptr, nullptr, 0, 1, stream));
-            RC(hs_layernorm_bwd(dh, 1, xmid, nullptr, p[P_N2W], st + 2 * M, st + 3 * M, dx, dx, dx_mid, g[P_N2W], g[P_N2B], g[P_BO], M, d, stream));
+            RC(hs_layernorm_bwd(dh, ln16, xmid, nullptr, p[P_N2W], st + 2 * M, st + 3 * M, dx, dx, dx_mid, g[P_N2W], g[P_N2B], g[P_BO], M, d, stream));
             // ---- attention branch: xm = x + Wo attn(LN1 x) + bo         (dbo came from the LN2 backward just above)
             if (nt) RC(gemm(P, HS_GEMM_NT, dx_mid, wot, M, d, d, d, d, nullptr, dob, d, nullptr, nullptr, nullptr, nullptr, 0, 1, stream));
             else RC(gemm(P, HS_GEMM_NN, dx_mid, wo, M, d, d, d, d, nullptr, dob, d, nullptr, nullptr, nullptr, nullptr, 0, 1, stream));
-            RC(hs_attn_bwd(qkv, o, dob, lse, dqkv, delta, c.B, c.N, c.H, 64, HS_ATTN_Q_PRESCALED, stream));
+            RC(hs_attn_bwd(qkv, o, dob, lse, dqkv, delta, c.B, c.N, c.H, 64, HS_ATTN_Q_PRESCALED | (f16 ? HS_ATTN_F16 : 0), stream));
             if (nt) RC(gemm(P, HS_GEMM_NT, dqkv, wqkvt, M, d, 3 * d, 3 * d, 3 * d, nullptr, dh, d, nullptr, nullptr, nullptr, nullptr, 0, 1, stream));
             else RC(gemm(P, HS_GEMM_NN, dqkv, wqkv, M, d, 3 * d, 3 * d, d, nullptr, dh, d, nullptr, nullptr, nullptr, nullptr, 0, 1, stream));
             float* dxo = (l == 0) ? dx0 : dx;
             float* b2_below = (l == 0) ? nullptr : lg[(size_t)(l - 1) * P_COUNT + P_B2];
-            RC(hs_layernorm_bwd(dh, 1, xin, nullptr, p[P_N1W], st, st + M, dx, dxo, l == 0 ? nullptr : dx_out, g[P_N1W], g[P_N1B], b2_below, M, d, stream));
+            RC(hs_layernorm_bwd(dh, ln16, xin, nullptr, p[P_N1W], st, st + M, dx, dxo, l == 0 ? nullptr : dx_out, g[P_N1W], g[P_N1B], b2_below, M, d, stream));
             // ---- dW2 = dx'^T a, dW1 = dz^T h2, dWqkv = dqkv^T h1, dWo = dxm^T o (largest first)
             const int mn[4][2] = {{d, mlp}, {mlp, d}, {3 * d, d}, {d, d}};
             static const int split_env = getenv("HS_WGRAD_GROUP_SPLIT") ? atoi(getenv("HS_WGRAD_GROUP_SPLIT")) : 0;   // (A/B runs)
@@ -290,7 +292,7 @@ extern "C" int hs_vit_blocks_bwd(const hs_vit_desc* desc, const float* x0, const
                 wg[i].lda = mn[i][0]; wg[i].ldb = mn[i][1]; wg[i].ldc = mn[i][1]; wg[i].batch = 1; wg[i].out_f32 = dws[i];
                 wg[i].alpha = 1.0f; wg[i].flags = HS_EPI_ATOMIC; wg[i].layout = HS_GEMM_TN; wg[i].split_k = split;
             }
-            RC(hs_gemm_group(wg, 4, stream));
+            RC(hs_gemm_group_prec(wg, 4, P, stream));
             continue;
         }
         // ---- f32 parity mode: the same sequence with exact-f32 kernels, every buffer fp32, weight gradients where their operands

@@ -159,9 +159,14 @@ def encoder_flat_order(m) -> List[Tuple[str, nn.Parameter]]:
 class EncoderUnit:
     """One encoder (P4 ViT_stage1 / P6 ViT_stage2) on the fused drivers: hs_embed_* + hs_vit_blocks_*, own workspaces."""
 
-    def __init__(self, model, batch: int, trainable: bool = True, recompute_mlp: bool = False):
+    def __init__(self, model, batch: int, trainable: bool = True, recompute_mlp: bool = False, prec: int = L.PREC_BF16):
         """recompute_mlp: do not keep the MLP's two [rows][mlp] activations per layer (46 % of the saved activation bytes: 0.6 of 1.3 GB
-        per 256^3 volume and encoder); the backward re-runs fc1 + GELU per layer (hs_vit_desc.save_for_bwd = 2; gradients bit-identical)."""
+        per 256^3 volume and encoder); the backward re-runs fc1 + GELU per layer (hs_vit_desc.save_for_bwd = 2; gradients bit-identical).
+        prec: L.PREC_BF16 (the reference's training policy) or L.PREC_F16 (fp16 operands, forward and backward; the patch matrix the
+        unit is given must be in the same format)."""
+        if prec not in (L.PREC_BF16, L.PREC_F16):
+            raise L.HsError("the engines run on 16-bit operands: precision 'bf16' or 'f16' (the exact-f32 mode is the module API's)")
+        self.prec = prec
         if not isinstance(model, (ViT_stage1, ViT_stage2)):
             raise TypeError("EncoderUnit drives ViT_stage1 / ViT_stage2")
         p0 = next(model.parameters())
@@ -175,8 +180,9 @@ class EncoderUnit:
         self.N = self.Np + (1 if self.has_cls else 0)
         self.Ln = len(model.blocks)
         sv = (2 if recompute_mlp else 1) if trainable else 0
-        self.desc = L.VitDesc(batch, self.N, self.d, model.num_heads, model.mlp_dim, self.Ln, L.PREC_BF16, sv, 0.0, None)
+        self.desc = L.VitDesc(batch, self.N, self.d, model.num_heads, model.mlp_dim, self.Ln, prec, sv, 0.0, None)
         self.edesc = L.EmbedDesc(batch, self.Np, self.Pd, self.d, int(self.has_cls), int(self.scorer), 32, int(trainable), 0.0)
+        self.edesc.prec = prec
         lib = L.load()
         self.ws_bytes = lib.hs_vit_workspace_bytes(C.byref(self.desc))
         if self.ws_bytes == 0:
@@ -271,7 +277,7 @@ class PackerUnit:
     concatenated (B, slots*cells, out_dim) tensor."""
 
     def __init__(self, packer: VisualPacker_3d_phi_v3, batch: int, in_tokens: int, in_row_offset: int, out_slots: int, slot: int,
-                 trainable: bool = True):
+                 trainable: bool = True, prec: int = L.PREC_BF16):
         p0 = next(packer.parameters())
         if not p0.is_cuda:
             raise L.HsError("the engine needs the module on an MI355X ('cuda') device")
@@ -285,6 +291,7 @@ class PackerUnit:
             raise L.HsError(f"packer grid {packer.grid} does not match {in_tokens - in_row_offset} patch tokens")
         self.desc = L.PackerDesc(batch, gd, gh, gw, kd, kh, kw, d, self.out_dim, in_row_offset, in_tokens * d,
                                  out_slots * self.cells * self.out_dim, 1 if trainable else 0, 0.0)
+        self.desc.prec = prec
         self._ws_key = None
 
     def flat_order(self) -> List[Tuple[str, nn.Parameter]]:
@@ -322,8 +329,33 @@ class PackerUnit:
         L.call("hs_packer_bwd", C.byref(self.desc), self._slot_ptr(dout), self._pp, self._pg, Fn._p(dfeat), ws, wb, Fn._s())
 
 
+_PRECS = {"bf16": L.PREC_BF16, "f16": L.PREC_F16}
+
+
+def _engine_prec(precision: str) -> int:
+    if precision not in _PRECS:
+        raise L.HsError("engine precision must be 'bf16' (the reference's autocast policy) or 'f16' (fp16 operands + loss scale)")
+    return _PRECS[precision]
+
+
+def default_loss_scale(numel: int) -> float:
+    """the power of two that makes d(mean(y^2))/dy = 2 y / numel about y itself: 2^floor(log2(numel)).  The fp16 backward pass then
+    carries activation gradients of the activations' own magnitude -- well inside fp16's 6e-5 .. 65504 -- whatever the batch."""
+    return float(2 ** (max(1, int(numel)).bit_length() - 1))
+
+
 class _Engine:
-    """shared: flat buffers, gradient buckets, optimizer."""
+    """shared: flat buffers, gradient buckets, optimizer.
+
+    precision 'f16' (round 5): every 16-bit tensor of the step is IEEE fp16 instead of bf16 (same kernels, same rate, 11 instead of 8
+    significant bits: forward within 1e-3 of the fp32 reference, gradients within ~2e-3).  fp16 has 5 exponent bits, so the loss
+    gradient is multiplied by ``loss_scale`` (a power of two; default: default_loss_scale of the loss' element count) before the
+    backward pass -- the flat gradient then holds loss_scale x the true gradient -- and the factor is taken out inside the AdamW pass
+    (``hs_adamw_masked``'s grad_scale), which also skips a step whose gradient norm is not finite (what torch.cuda.amp.GradScaler
+    does); ``unscaled_grad()`` returns the true gradient for inspection."""
+
+    loss_scale = 1.0
+    prec = L.PREC_BF16
 
     def _finish(self, entries, bounds, *, lr, weight_decay, max_grad_norm, group, grad_wire="fp32", grad_algo="allreduce"):
         self.params = FlatParams(entries, self.dev)
@@ -337,7 +369,16 @@ class _Engine:
         return self.params.step_no
 
     def optimizer_step(self) -> None:
-        self.params.step(lr=self.lr, weight_decay=self.wd, grad_scale=self.buckets.grad_scale, max_grad_norm=self.max_grad_norm)
+        self.params.step(lr=self.lr, weight_decay=self.wd, grad_scale=self.buckets.grad_scale / self.loss_scale,
+                         max_grad_norm=self.max_grad_norm)
+
+    def unscaled_grad(self) -> torch.Tensor:
+        """the flat gradient without the loss scale (a copy when the scale is not 1)."""
+        return self.grad if self.loss_scale == 1.0 else self.grad / self.loss_scale
+
+    @property
+    def dtype16(self) -> torch.dtype:
+        return torch.float16 if self.prec == L.PREC_F16 else torch.bfloat16
 
     def probe_step(self, *inputs) -> None:
         """one forward + backward WITHOUT collectives and without the optimizer: sizes every lazily allocated workspace and surfaces an
@@ -353,7 +394,7 @@ class _Engine:
         B, Cc, D, H, W = vol.shape
         if B != self.B or tuple(vol.shape[2:]) != pe.img_size or vol.dtype != torch.float32:
             raise L.HsError("volume must be contiguous fp32 on the GPU with the configured batch/geometry")
-        L.call("hs_patchify", vol.data_ptr(), patches.data_ptr(), B, Cc, D, H, W, *pe.patch_size, L.PREC_BF16, Fn._s())
+        L.call("hs_patchify", vol.data_ptr(), patches.data_ptr(), B, Cc, D, H, W, *pe.patch_size, self.prec, Fn._s())
 
 
 def _encoder_entries(unit: EncoderUnit, prefix: str):
@@ -381,8 +422,10 @@ class FlatEncoder(_Engine):
     """One encoder with flat parameter / gradient / moment buffers and an explicit fused train step (BASELINE configs[1])."""
 
     def __init__(self, model, batch: int, *, lr=1e-4, weight_decay=0.1, max_grad_norm: Optional[float] = 1.0, n_buckets=4, group=None,
-                 grad_wire="fp32", grad_algo="allreduce", recompute_mlp: bool = False):
-        self.unit = EncoderUnit(model, batch, trainable=True, recompute_mlp=recompute_mlp)
+                 grad_wire="fp32", grad_algo="allreduce", recompute_mlp: bool = False, precision: str = "bf16",
+                 loss_scale: Optional[float] = None):
+        self.prec = _engine_prec(precision)
+        self.unit = EncoderUnit(model, batch, trainable=True, recompute_mlp=recompute_mlp, prec=self.prec)
         self.model, self.dev, self.B = model, self.unit.dev, batch
         entries = _encoder_entries(self.unit, "")
         probe_names = [n for n, _, _ in entries]
@@ -395,14 +438,19 @@ class FlatEncoder(_Engine):
                      grad_wire=grad_wire, grad_algo=grad_algo)
         self.unit.bind()
         u = self.unit
-        self.patches = torch.empty(batch * u.Np, u.Pd, dtype=torch.bfloat16, device=self.dev)
+        self.patches = torch.empty(batch * u.Np, u.Pd, dtype=self.dtype16, device=self.dev)
         self.y, self.dy, self.hidden = u.y, u.dy, u.hidden
+        if self.prec == L.PREC_F16:
+            self.loss_scale = float(loss_scale) if loss_scale else default_loss_scale(self.y.numel())
+        elif loss_scale not in (None, 1, 1.0):
+            raise L.HsError("loss_scale belongs to precision 'f16'")
 
     def forward(self, vol: torch.Tensor, image_2d: Optional[torch.Tensor] = None) -> torch.Tensor:
         self._patchify(vol, self.model.patch_embedding, self.patches)
         return self.unit.forward(self.patches, image_2d)
 
     def backward(self, dy: torch.Tensor) -> None:
+        """dy = d(loss)/dy x self.loss_scale (1 unless precision 'f16'): the flat gradient comes out with the same factor."""
         Fn._need_as(dy, "dy", self.y.shape)
         self.grad.zero_()
         self.unit.backward(self.patches, dy, self.layer_chunks, self.buckets.reduce)
@@ -411,7 +459,7 @@ class FlatEncoder(_Engine):
     def train_step(self, vol: torch.Tensor, image_2d: Optional[torch.Tensor] = None, optimizer: bool = True) -> None:
         """one step of L = mean(y^2): fwd, dL/dy = 2 y / numel, bwd (+ bucketed all-reduce), clipped AdamW (optimizer=False: without it)."""
         y = self.forward(vol, image_2d)
-        L.call("hs_mse_grad", y.data_ptr(), self.dy.data_ptr(), None, y.numel(), Fn._s())
+        L.call("hs_mse_grad_scaled", y.data_ptr(), self.dy.data_ptr(), None, y.numel(), self.loss_scale, Fn._s())
         self.backward(self.dy)
         if optimizer:
             self.optimizer_step()
@@ -427,17 +475,20 @@ class DualEngine(_Engine):
 
     def __init__(self, tower: ViT3DTower_dual_encoders, packer1: VisualPacker_3d_phi_v3, packer2: VisualPacker_3d_phi_v3, batch: int, *,
                  lr=1e-4, weight_decay=0.1, max_grad_norm: Optional[float] = 1.0, n_buckets=4, group=None,
-                 two_streams: Optional[bool] = None, grad_wire="fp32", grad_algo="allreduce", recompute_mlp: bool = False):
-        """recompute_mlp: see EncoderUnit (activation memory 3.7 -> 2.5 GB per 256^3 volume for one more GEMM per layer in the backward)."""
+                 two_streams: Optional[bool] = None, grad_wire="fp32", grad_algo="allreduce", recompute_mlp: bool = False,
+                 precision: str = "bf16", loss_scale: Optional[float] = None):
+        """recompute_mlp: see EncoderUnit (activation memory 3.7 -> 2.5 GB per 256^3 volume for one more GEMM per layer in the backward).
+        precision / loss_scale: see _Engine."""
+        self.prec = _engine_prec(precision)
         if tower.select_feature != "patch" or tower.remain_2d3d_ViT_type != "dual_vits":
             raise L.HsError("DualEngine drives the shipped configuration: select_feature='patch', remain_2d3d_ViT_type='dual_vits'")
         self.tower, self.B = tower, batch
-        self.u1 = EncoderUnit(tower.vision_tower_stage1, batch, True, recompute_mlp)
-        self.u2 = EncoderUnit(tower.vision_tower_stage2, batch, True, recompute_mlp)
+        self.u1 = EncoderUnit(tower.vision_tower_stage1, batch, True, recompute_mlp, self.prec)
+        self.u2 = EncoderUnit(tower.vision_tower_stage2, batch, True, recompute_mlp, self.prec)
         self.dev = self.u1.dev
         off1 = 1 if self.u1.has_cls else 0
-        self.p1 = PackerUnit(packer1, batch, self.u1.N, off1, 2, 0, True)
-        self.p2 = PackerUnit(packer2, batch, self.u2.N, off1, 2, 1, True)
+        self.p1 = PackerUnit(packer1, batch, self.u1.N, off1, 2, 0, True, self.prec)
+        self.p2 = PackerUnit(packer2, batch, self.u2.N, off1, 2, 1, True, self.prec)
         if packer1.out_dim != packer2.out_dim or self.p1.cells != self.p2.cells:
             raise L.HsError("the two packers must agree on out_dim and token count")
         e1 = _encoder_entries(self.u1, "vision_tower_stage1.")
@@ -460,9 +511,13 @@ class DualEngine(_Engine):
                      grad_wire=grad_wire, grad_algo=grad_algo)
         for u in (self.u1, self.u2, self.p1, self.p2):
             u.bind()
-        self.patches = torch.empty(batch * self.u1.Np, self.u1.Pd, dtype=torch.bfloat16, device=self.dev)
+        self.patches = torch.empty(batch * self.u1.Np, self.u1.Pd, dtype=self.dtype16, device=self.dev)
         self.out = torch.empty(batch, 2 * self.p1.cells, packer1.out_dim, dtype=torch.float32, device=self.dev)
         self.dout = torch.empty_like(self.out)
+        if self.prec == L.PREC_F16:
+            self.loss_scale = float(loss_scale) if loss_scale else default_loss_scale(self.out.numel())
+        elif loss_scale not in (None, 1, 1.0):
+            raise L.HsError("loss_scale belongs to precision 'f16'")
         # The two encoder/packer chains are independent between the shared patchify and the loss: run the 2E3 chain on a side HIP
         # stream so the dispatcher can fill CUs one chain's launch leaves idle (small batches: a 4097-row GEMM has 153-204 tiles
         # for 256 CUs, an attention launch 396 blocks for 512 slots).  Measured gain: +29 % at 1 volume per GPU, +24 % at 2, +17 % at
@@ -493,6 +548,7 @@ class DualEngine(_Engine):
         return self.out
 
     def backward(self, dout: torch.Tensor) -> None:
+        """dout = d(loss)/d(out) x self.loss_scale (1 unless precision 'f16'): the flat gradient comes out with the same factor."""
         Fn._need_as(dout, "dout", self.out.shape)
         self.grad.zero_()
         n2 = len(self.chunks2)
@@ -510,7 +566,7 @@ class DualEngine(_Engine):
         """one step of L = mean(out^2) over the (B, 256, hidden) projector output (optimizer=False: forward + backward + all-reduce only)."""
         out = self.forward(vol, image_2d)
         self.loss.zero_()
-        L.call("hs_mse_grad", out.data_ptr(), self.dout.data_ptr(), self.loss.data_ptr(), out.numel(), Fn._s())
+        L.call("hs_mse_grad_scaled", out.data_ptr(), self.dout.data_ptr(), self.loss.data_ptr(), out.numel(), self.loss_scale, Fn._s())
         self.backward(self.dout)
         if optimizer:
             self.optimizer_step()

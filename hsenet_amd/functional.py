@@ -19,9 +19,12 @@ _default_precision = "bf16"
 
 def set_precision(p: str) -> None:
     """'bf16' (default; the reference's autocast policy: bf16 MFMA inputs, fp32 accumulate/residual) or
-    'f32' (exact-f32 MFMA parity mode: forward and backward, no bf16 rounding anywhere), or 'f16' (FORWARD ONLY: the same kernels with
-    fp16 operand packs -- the reference's eval / generation scripts run under torch.cuda.amp.autocast(), default dtype fp16,
-    Bench/eval/eval_HSENet_CT_Rate_MRG.py:383,423; a backward pass through an fp16-mode forward raises)."""
+    'f32' (exact-f32 MFMA parity mode: forward and backward, no bf16 rounding anywhere), or 'f16' (the same kernels with IEEE fp16
+    operand packs at the bf16 kernels' rate, forward AND backward since round 5 -- the reference's eval / generation scripts run under
+    torch.cuda.amp.autocast(), default dtype fp16, Bench/eval/eval_HSENet_CT_Rate_MRG.py:383,423.  fp16 has 5 exponent bits: a
+    backward pass wants its loss multiplied by a power of two so that the activation gradients sit in fp16's range, exactly as
+    torch.cuda.amp.GradScaler does for an fp16 autocast step -- the engines do it themselves (loss_scale), a module-API caller
+    scales the loss and unscales the gradients)."""
     global _default_precision
     if p not in _PREC:
         raise ValueError(f"precision must be one of {list(_PREC)}")
@@ -102,22 +105,23 @@ def gemm(A: torch.Tensor, Bm: torch.Tensor, layout: int, *, prec: int, out_f32: 
 
 
 def wgrad_group(dys, xs, outs, split_k: int = 1) -> None:
-    """outs[i] += dys[i]^T @ xs[i] for up to 4 (dY [rows][n_out], X [rows][n_in]) bf16 pairs in ONE launch (hs_gemm_group);
-    outs: fp32 [n_out][n_in], accumulated with float atomics (the caller zeroes them)."""
+    """outs[i] += dys[i]^T @ xs[i] for up to 4 (dY [rows][n_out], X [rows][n_in]) bf16 (or all-fp16) pairs in ONE launch
+    (hs_gemm_group_prec); outs: fp32 [n_out][n_in], accumulated with float atomics (the caller zeroes them)."""
     n = len(dys)
+    dt = dys[0].dtype if n else torch.bfloat16
     if not (1 <= n <= 4) or len(xs) != n or len(outs) != n:
         raise L.HsError("wgrad_group takes 1..4 (dY, X, out) triples")
     arr = (L.GemmArgs * n)()
     for g, dy, x, o in zip(arr, dys, xs, outs):
         _need(dy, x, o)
-        if dy.dtype != torch.bfloat16 or x.dtype != torch.bfloat16 or o.dtype != torch.float32:
-            raise L.HsError("wgrad_group: bf16 operands, fp32 outputs")
+        if dt not in (torch.bfloat16, torch.float16) or dy.dtype != dt or x.dtype != dt or o.dtype != torch.float32:
+            raise L.HsError("wgrad_group: bf16 (or all fp16) operands, fp32 outputs")
         if dy.dim() != 2 or x.dim() != 2 or dy.shape[0] != x.shape[0] or tuple(o.shape) != (dy.shape[1], x.shape[1]):
             raise L.HsError("wgrad_group: shape mismatch")
         g.A, g.B, g.M, g.N, g.K = dy.data_ptr(), x.data_ptr(), dy.shape[1], x.shape[1], dy.shape[0]
         g.lda, g.ldb, g.ldc, g.batch = dy.shape[1], x.shape[1], x.shape[1], 1
         g.out_f32, g.alpha, g.flags, g.layout, g.split_k = o.data_ptr(), 1.0, L.EPI_ATOMIC, L.GEMM_TN, split_k
-    L.call("hs_gemm_group", arr, n, _s())
+    L.call("hs_gemm_group_prec", arr, n, L.PREC_F16 if dt == torch.float16 else L.PREC_BF16, _s())
 
 
 def cast_bf16(x: torch.Tensor) -> torch.Tensor:
@@ -139,12 +143,6 @@ def cast16(x: torch.Tensor, prec: int) -> torch.Tensor:
     return y
 
 
-def _forward_only(prec: int) -> None:
-    if prec == L.PREC_F16:
-        raise L.HsError("precision 'f16' is forward-only (the reference uses fp16 autocast in its eval / generation scripts only): "
-                        "run it under torch.no_grad(), train in 'bf16'")
-
-
 def cast_f32(x: torch.Tensor) -> torch.Tensor:
     _need(x)
     y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
@@ -153,9 +151,10 @@ def cast_f32(x: torch.Tensor) -> torch.Tensor:
 
 
 def colsum(x: torch.Tensor, out: torch.Tensor) -> None:
-    """out[n] += sum_m x[m, n] (x 2-D bf16 or fp32)."""
+    """out[n] += sum_m x[m, n] (x 2-D bf16, fp16 or fp32)."""
     _need(x, out)
-    L.call("hs_colsum", x.data_ptr(), int(x.dtype == torch.bfloat16), out.data_ptr(), x.shape[0], x.shape[1], x.shape[1], _s())
+    fmt = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}[x.dtype]
+    L.call("hs_colsum", x.data_ptr(), fmt, out.data_ptr(), x.shape[0], x.shape[1], x.shape[1], _s())
 
 
 def _wgrad_split(Mo: int, No: int, K: int, tile=(256, 128), kt: int = 64) -> int:
@@ -184,12 +183,13 @@ def attn_fwd(qkv: torch.Tensor, H: int, prec: int, q_prescaled: bool = False):
 
 
 def attn_bwd(qkv, o, d_o, lse, H: int, q_prescaled: bool = False):
-    """dqkv from (qkv, o, dO, lse): bf16 tensors, or fp32 ones (exact-f32 parity mode, raw q)."""
+    """dqkv from (qkv, o, dO, lse): bf16 tensors, fp16 ones, or fp32 ones (exact-f32 parity mode, raw q)."""
     _need(qkv, o, d_o, lse)
     B, N, _ = qkv.shape
-    if not (qkv.dtype == o.dtype == d_o.dtype) or qkv.dtype not in (torch.bfloat16, torch.float32):
-        raise L.HsError("attn_bwd: qkv, o, dO must all be bf16 or all fp32")
-    flags = (L.ATTN_Q_PRESCALED if q_prescaled else 0) | (L.ATTN_F32 if qkv.dtype == torch.float32 else 0)
+    if not (qkv.dtype == o.dtype == d_o.dtype) or qkv.dtype not in (torch.bfloat16, torch.float16, torch.float32):
+        raise L.HsError("attn_bwd: qkv, o, dO must all be bf16, all fp16 or all fp32")
+    flags = ((L.ATTN_Q_PRESCALED if q_prescaled else 0) | (L.ATTN_F32 if qkv.dtype == torch.float32 else 0)
+             | (L.ATTN_F16 if qkv.dtype == torch.float16 else 0))
     dqkv = torch.empty_like(qkv)
     delta = torch.empty(2, B, H, N, dtype=torch.float32, device=qkv.device)   # row constants -delta | -lse*log2e
     L.call("hs_attn_bwd", qkv.data_ptr(), o.data_ptr(), d_o.data_ptr(), lse.data_ptr(), dqkv.data_ptr(), delta.data_ptr(),
@@ -266,9 +266,8 @@ class LinearFn(torch.autograd.Function):
     def backward(ctx, dy):
         xa, wa = ctx.saved_tensors
         prec = ctx.prec
-        _forward_only(prec)
         dy2 = _f32(dy).contiguous().view(-1, wa.shape[0])
-        dya = cast_bf16(dy2) if prec == L.PREC_BF16 else dy2
+        dya = cast16(dy2, prec) if prec != L.PREC_F32 else dy2
         M, N, K = xa.shape[0], wa.shape[0], wa.shape[1]
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
@@ -277,7 +276,7 @@ class LinearFn(torch.autograd.Function):
             dx = dx.view(ctx.xshape)
         if ctx.needs_input_grad[1]:
             dw = torch.zeros(N, K, dtype=torch.float32, device=dy.device)
-            tile, kt = ((256, 128), 64) if prec == L.PREC_BF16 else ((64, 64), 32)
+            tile, kt = ((256, 128), 64) if prec != L.PREC_F32 else ((64, 64), 32)
             gemm(dya, xa, L.GEMM_TN, prec=prec, out_f32=dw, flags=L.EPI_ATOMIC, split_k=_wgrad_split(N, K, M, tile, kt))
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = torch.zeros(N, dtype=torch.float32, device=dy.device)
@@ -379,12 +378,11 @@ class PatchEmbedFn(torch.autograd.Function):
     def backward(ctx, dy):
         (patches,) = ctx.saved_tensors
         prec = ctx.prec
-        _forward_only(prec)
         N, K = ctx.wshape
         dy2 = _f32(dy).contiguous().view(-1, N)
-        dya = cast_bf16(dy2) if prec == L.PREC_BF16 else dy2
+        dya = cast16(dy2, prec) if prec != L.PREC_F32 else dy2
         dw = torch.zeros(N, K, dtype=torch.float32, device=dy.device)
-        tile, kt = ((256, 128), 64) if prec == L.PREC_BF16 else ((64, 64), 32)
+        tile, kt = ((256, 128), 64) if prec != L.PREC_F32 else ((64, 64), 32)
         gemm(dya, patches, L.GEMM_TN, prec=prec, out_f32=dw, flags=L.EPI_ATOMIC,
              split_k=_wgrad_split(N, K, patches.shape[0], tile, kt))
         db = torch.zeros(N, dtype=torch.float32, device=dy.device)
@@ -619,8 +617,6 @@ class BlocksFn(torch.autograd.Function):
         Ln = (len(params) - 2) // 11
         # need_grad is decided by the caller (grad mode is off inside Function.forward, and
         # ctx.needs_input_grad ignores torch.no_grad())
-        if need_grad:
-            _forward_only(prec)
         desc = L.VitDesc(B, N, d, H, mlp, Ln, prec, int(need_grad), 0.0, None)
         nbytes = L.load().hs_vit_workspace_bytes(C.byref(desc))
         if nbytes == 0:

@@ -29,11 +29,14 @@ extern "C" {
 
 #define HS_PREC_BF16 0      /* bf16 MFMA inputs, fp32 accumulate, fp32 residual stream (reference autocast policy) */
 #define HS_PREC_F32 1       /* exact-f32 MFMA (v_mfma_f32_32x32x2_f32): parity mode */
-#define HS_PREC_F16 2       /* IEEE fp16 MFMA inputs, fp32 accumulate, fp32 residual stream: FORWARD ONLY.  The reference's eval /
-                             * generation scripts run the model under torch.cuda.amp.autocast() (default dtype fp16,
-                             * Bench/eval/eval_HSENet_CT_Rate_MRG.py:383,423).  Same kernels as HS_PREC_BF16 with fp16 operand packs;
-                             * accepted by hs_gemm (NT, no gradient epilogue), hs_attn_fwd, hs_patchify, hs_cast_f16 and
-                             * hs_vit_blocks_fwd (save_for_bwd = 0); every backward entry point refuses it (HS_ERR_ARG). */
+#define HS_PREC_F16 2       /* IEEE fp16 MFMA inputs, fp32 accumulate, fp32 residual stream.  The reference's eval / generation scripts run the
+                             * model under torch.cuda.amp.autocast() (default dtype fp16, Bench/eval/eval_HSENet_CT_Rate_MRG.py:383,423).
+                             * The SAME kernels as HS_PREC_BF16 with fp16 operand packs and the fp16 MFMA opcode (same rate); since round 5
+                             * forward AND backward: hs_gemm (every layout / epilogue), hs_gemm_group_prec, hs_attn_fwd (running-maximum
+                             * kernel), hs_attn_bwd (HS_ATTN_F16), hs_layernorm_bwd (HS_LN_DY_F16 / HS_LN_OUT_F16), hs_colsum (2), hs_patchify,
+                             * hs_cast_f16, hs_vit_blocks_fwd/bwd, hs_embed_*, hs_packer_* (descriptor prec).  fp16 has 5 exponent bits: a
+                             * training step scales its loss gradient by a power of two (hs_mse_grad_scaled; the engines' loss_scale) and
+                             * removes the factor in hs_adamw_masked's grad_scale; forward values need no scaling. */
 
 /* GEMM operand layouts: C[M,N] = sum_k A(m,k) * B(n,k).  "T" = the operand is stored [K][dim] (k is the row). */
 #define HS_GEMM_NT 0        /* A[M][K], B[N][K]   : forward nn.Linear  y = x W^T                      */
@@ -92,6 +95,8 @@ int hs_gemm(const hs_gemm_args* args, int prec, void* stream);
  * `count` hs_gemm calls; at one volume per GPU a lone wgrad cannot fill the chip without a deep split-K, the group can. */
 #define HS_GEMM_GROUP_MAX 4
 int hs_gemm_group(const hs_gemm_args* args, int count, void* stream);
+/* the same with the operands' 16-bit format given: HS_PREC_BF16 (= hs_gemm_group) or HS_PREC_F16 (fp16 training, round 5) */
+int hs_gemm_group_prec(const hs_gemm_args* args, int count, int prec, void* stream);
 
 /* ---- K1: 3D patch embedding.  Replaces x.clone() + einops 'b c (h p1)(w p2)(d p3) -> b (h w d)(p1 p2 p3 c)'
  * (vit.py:437,455) = the A operand of the patch-embed Linear.  out: [B*Np][Pd] bf16 (prec 0) / float (prec 1). */
@@ -298,6 +303,7 @@ typedef struct hs_embed_desc {
     int save_for_bwd;
     float drop_p;         /* 0 = eval(); 0.1 = train() (vit.py:46-47) */
     uint64_t seed[2], offset[2];
+    int prec;             /* HS_PREC_BF16 (0) or HS_PREC_F16: the 16-bit operand format of the driver's GEMMs (patches must be in it) */
 } hs_embed_desc;
 size_t hs_embed_workspace_bytes(const hs_embed_desc* desc);
 int hs_embed_fwd(const hs_embed_desc* desc, const void* patches, const float* image_2d, const float* const* params,
@@ -325,6 +331,7 @@ typedef struct hs_packer_desc {
     int save_for_bwd;
     float drop_p;
     uint64_t seed[2], offset[2];
+    int prec;             /* HS_PREC_BF16 (0) or HS_PREC_F16 */
 } hs_packer_desc;
 size_t hs_packer_workspace_bytes(const hs_packer_desc* desc);
 int hs_packer_fwd(const hs_packer_desc* desc, const float* feat, const float* const* params, float* out, void* ws, size_t ws_bytes,
@@ -341,6 +348,10 @@ int hs_packer_bwd(const hs_packer_desc* desc, const float* dout, const float* co
  *   squared norm of the SUMMED gradient; the update uses g * grad_scale * min(1, max_grad_norm / (sqrt(sumsq)*grad_scale + 1e-6))
  *   = torch.nn.utils.clip_grad_norm_ on the DP-mean gradient, without a host round trip. */
 int hs_mse_grad(const float* y, float* dy, float* loss, int64_t n, void* stream);
+/* hs_mse_grad with dy multiplied by grad_scale (> 0): the power-of-two loss scale of an HS_PREC_F16 backward pass -- every gradient of
+ * the step then carries the factor, and hs_adamw_masked's grad_scale (1 / (world * loss_scale)) takes it out; `loss` is unscaled.
+ * hs_adamw_masked skips the update (parameters and moments untouched) when grad_sumsq is not finite: an overflowed fp16 step. */
+int hs_mse_grad_scaled(const float* y, float* dy, float* loss, int64_t n, float grad_scale, void* stream);
 int hs_sumsq(const float* x, float* out, float* scratch, int64_t n, void* stream);
 int hs_adamw_masked(float* p, const float* g, float* m, float* v, const unsigned char* decay_mask, int64_t n, float lr, float beta1,
                     float beta2, float eps, float weight_decay, float grad_scale, const float* grad_sumsq, float max_grad_norm,

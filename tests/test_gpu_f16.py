@@ -1,7 +1,8 @@
-"""HS_PREC_F16 (GPU): the forward-only fp16 operand mode (the reference's eval / generation scripts run under
-torch.cuda.amp.autocast(), default dtype fp16: Bench/eval/eval_HSENet_CT_Rate_MRG.py:383,423).  Kernel level: each fp16 kernel
+"""HS_PREC_F16 (GPU): the fp16 operand mode (the reference's eval / generation scripts run under torch.cuda.amp.autocast(), default
+dtype fp16: Bench/eval/eval_HSENet_CT_Rate_MRG.py:383,423), forward and -- since round 5 -- backward.  Kernel level: each fp16 kernel
 through the C ABI against a torch fp64 statement on the SAME fp16-rounded operands (so only accumulation order and the output
-rounding differ).  The encoder-level fp16 parity against the golden vectors lives in tests/test_gpu_parity.py (prec "f16")."""
+rounding differ).  The encoder-level fp16 parity against the golden vectors lives in tests/test_gpu_parity.py (prec "f16"), the
+full-size fp16 gradients against the reference's in tests/test_gpu_grad_goldens.py."""
 import numpy as np
 import pytest
 import torch
@@ -57,19 +58,120 @@ def test_gemm_f16_nt_and_forward_epilogues(dev, M, N, K):
         assert rel(out, ref) < 1e-5
 
 
-def test_gemm_f16_refuses_everything_but_the_forward(dev):
+@pytest.mark.parametrize("M,N,K", [(8194, 768, 3072), (333, 256, 128), (1025, 3072, 768)])
+def test_gemm_f16_backward_layouts_and_epilogues(dev, M, N, K):
+    """round 5: dgrad (NN, and NT against a transposed weight), wgrad (TN with split-K atomics, grouped), the x gelu' epilogue with its
+    fused column sums and the forward epilogue that SAVES gelu' -- all at fp16 operands, against fp64 on the same fp16 values."""
     from hsenet_amd import functional as Fn, _lib as L
-    a, b = rnd((64, 64), 6, dev).half(), rnd((64, 64), 7, dev).half()
-    out = torch.empty(64, 64, device=dev)
-    z = torch.empty(64, 64, dtype=torch.float16, device=dev)
-    for kw in (dict(layout=L.GEMM_NN), dict(layout=L.GEMM_TN, flags=L.EPI_ATOMIC), dict(layout=L.GEMM_NT, flags=L.EPI_GELU_BWD, aux=z),
-               dict(layout=L.GEMM_NT, flags=L.EPI_BIAS | L.EPI_GELU, bias=out[0].contiguous(), aux_out=z),
-               dict(layout=L.GEMM_NT, colsum_out=out[0].contiguous())):
-        layout = kw.pop("layout")
-        with pytest.raises(L.HsError):
-            Fn.gemm(a, b, layout, prec=L.PREC_F16, out_f32=out, **kw)
+    dy, w = rnd((M, N), 21, dev).half(), rnd((N, K), 22, dev, 0.05).half()
+    x = rnd((M, K), 23, dev).half()
+    # dgrad NN: dx = dy @ w
+    ref = dy.double() @ w.double()
+    out = torch.empty(M, K, device=dev)
+    Fn.gemm(dy, w, L.GEMM_NN, prec=L.PREC_F16, out_f32=out)
+    assert rel(out, ref) < 1e-5
+    # the same product as an NT GEMM on w^T (what the fused backward runs), 16-bit output
+    o16 = torch.empty(M, K, dtype=torch.float16, device=dev)
+    Fn.gemm(dy, w.t().contiguous(), L.GEMM_NT, prec=L.PREC_F16, out_bf16=o16)
+    assert rel(o16.float(), ref) < 6e-4
+    # wgrad TN: dw = dy^T @ x, split-K atomics
+    dw = torch.zeros(N, K, device=dev)
+    Fn.gemm(dy, x, L.GEMM_TN, prec=L.PREC_F16, out_f32=dw, flags=L.EPI_ATOMIC, split_k=3)
+    refw = dy.double().t() @ x.double()
+    assert rel(dw, refw) < 1e-5
+    dw2 = torch.zeros(N, K, device=dev)
+    Fn.wgrad_group([dy], [x], [dw2], split_k=1)                                   # grouped launch at fp16
+    assert rel(dw2, refw) < 1e-5
+    # x gelu' epilogue with fused column sums: dz = (dy @ w) * g, db = colsum(dz)
+    g = torch.rand(M, K, device=dev).half()
+    dz = torch.empty(M, K, dtype=torch.float16, device=dev)
+    db = torch.zeros(K, device=dev)
+    Fn.gemm(dy, w.t().contiguous(), L.GEMM_NT, prec=L.PREC_F16, out_bf16=dz, aux=g, colsum_out=db, flags=L.EPI_GELU_BWD | L.EPI_SAVE_DGELU)
+    refz = ref * g.double()
+    assert rel(dz.float(), refz) < 6e-4 and rel(db, dz.double().sum(0)) < 1e-4 and rel(db, refz.sum(0)) < 2e-3
+    # forward epilogue that saves gelu'(z) as fp16
+    bias = rnd((N,), 24, dev)
+    a16 = torch.empty(M, N, dtype=torch.float16, device=dev)
+    gz = torch.empty(M, N, dtype=torch.float16, device=dev)
+    wn = rnd((N, K), 25, dev, 0.05).half()
+    Fn.gemm(x, wn, L.GEMM_NT, prec=L.PREC_F16, out_bf16=a16, aux_out=gz, bias=bias, flags=L.EPI_BIAS | L.EPI_GELU | L.EPI_SAVE_DGELU)
+    z = (x.double() @ wn.double().t() + bias.double()).float().half().double().requires_grad_()
+    act = torch.nn.functional.gelu(z)
+    act.sum().backward()
+    assert rel(a16.float(), act.detach()) < 8e-4 and rel(gz.float(), z.grad) < 8e-4
     with pytest.raises(L.HsError):                                              # operands of the wrong 16-bit type
-        Fn.gemm(a.bfloat16(), b.bfloat16(), L.GEMM_NT, prec=L.PREC_F16, out_f32=out)
+        Fn.gemm(dy.bfloat16(), w.bfloat16(), L.GEMM_NN, prec=L.PREC_F16, out_f32=out)
+
+
+@pytest.mark.parametrize("N", [9, 65, 513, 2049, 4097])
+def test_attn_bwd_f16_vs_fp64(dev, N):
+    """the two backward sweeps at fp16 operands (HS_ATTN_F16: P and dS carried times 2^6 inside the kernels) against fp64 autograd on the
+    same fp16 q, k, v, dO; compared with the bf16 sweeps on bf16-rounded copies of the same data."""
+    from hsenet_amd import functional as Fn, _lib as L
+    B, H = 2, (3 if N < 4097 else 12)
+    raw = rnd((B, N, 3 * H * 64), 30 + N, dev)
+    do_raw = rnd((B, N, H * 64), 31 + N, dev)
+    errs = {}
+    for dt, prec in ((torch.float16, L.PREC_F16), (torch.bfloat16, L.PREC_BF16)):
+        qkv, d_o = raw.to(dt), do_raw.to(dt)
+        q, k, v = (t.view(B, N, H, 64).permute(0, 2, 1, 3).double().requires_grad_() for t in qkv.split(H * 64, dim=-1))
+        ref = (torch.softmax(q @ k.transpose(-1, -2) / 8.0, -1) @ v).permute(0, 2, 1, 3).reshape(B, N, H * 64)
+        ref.backward(d_o.double())
+        want = torch.cat([t.grad.permute(0, 2, 1, 3).reshape(B, N, H * 64) for t in (q, k, v)], dim=-1)
+        o, lse = Fn.attn_fwd(qkv, H, prec)
+        dqkv = Fn.attn_bwd(qkv, o, d_o, lse, H)
+        assert dqkv.dtype == dt and torch.isfinite(dqkv).all()
+        errs[dt] = [rel(a.float(), b) for a, b in zip(dqkv.split(H * 64, dim=-1), want.split(H * 64, dim=-1))]
+    print(f"attention backward N = {N}: fp16 dq/dk/dv {errs[torch.float16]}, bf16 {errs[torch.bfloat16]}")
+    assert max(errs[torch.float16]) < 1.2e-3                         # (bf16: 3.1e-3 .. 3.5e-3)
+    assert max(errs[torch.float16]) < 0.5 * max(errs[torch.bfloat16])
+
+
+def test_attn_bwd_f16_small_and_large_gradients(dev):
+    """the range of fp16: dO at 2^-10 and at 2^7 of unit scale both give finite gradients of the same relative accuracy (the kernels'
+    2^6 shift of P keeps dS = P dP' out of the subnormals for a near-uniform row of N = 2049)."""
+    from hsenet_amd import functional as Fn, _lib as L
+    B, H, N = 1, 2, 2049
+    qkv = (rnd((B, N, 3 * H * 64), 40, dev) * 0.3).half()              # logit std ~0.7: near-uniform rows, P ~ 1 / N
+    base = rnd((B, N, H * 64), 41, dev)
+    o, lse = Fn.attn_fwd(qkv, H, L.PREC_F16)
+    q, k, v = (t.view(B, N, H, 64).permute(0, 2, 1, 3).double().requires_grad_() for t in qkv.split(H * 64, dim=-1))
+    ref = (torch.softmax(q @ k.transpose(-1, -2) / 8.0, -1) @ v).permute(0, 2, 1, 3).reshape(B, N, H * 64)
+    for sc in (2.0 ** -10, 1.0, 2.0 ** 7):
+        d_o = (base * sc).half()
+        for t in (q, k, v):
+            t.grad = None
+        ref.backward(d_o.double(), retain_graph=True)
+        want = torch.cat([t.grad.permute(0, 2, 1, 3).reshape(B, N, H * 64) for t in (q, k, v)], dim=-1)
+        dqkv = Fn.attn_bwd(qkv, o, d_o, lse, H)
+        e = rel(dqkv.float(), want)
+        print(f"dO scale {sc:g}: dqkv rel err {e:.2e}, |dqkv| max {float(dqkv.abs().max()):.3g}")
+        assert torch.isfinite(dqkv).all() and e < (1.5e-3 if sc >= 1 else 6e-3)
+
+
+def test_layernorm_bwd_and_colsum_f16_formats(dev):
+    from hsenet_amd import functional as Fn, _lib as L
+    rows, d = 1000, 768
+    x, dy = rnd((rows, d), 50, dev), rnd((rows, d), 51, dev)
+    gamma, beta = 1 + 0.1 * rnd((d,), 52, dev), rnd((d,), 53, dev)
+    _, _, mean, rstd = Fn.layernorm_fwd(x, gamma, beta)
+    xr = x.double().requires_grad_()
+    y = torch.nn.functional.layer_norm(xr, (d,), gamma.double(), beta.double(), 1e-5)
+    for fmt, dyt in ((L.LN_DY_F16, dy.half()), (L.LN_DY_F32 | L.LN_OUT_F16, dy)):
+        xr.grad = None
+        y.backward(dyt.double(), retain_graph=True)
+        dx = torch.empty_like(x)
+        dx16 = torch.empty(rows, d, dtype=torch.float16, device=dev)
+        dg, db, ds = torch.zeros(d, device=dev), torch.zeros(d, device=dev), torch.zeros(d, device=dev)
+        L.call("hs_layernorm_bwd", dyt.data_ptr(), fmt, x.data_ptr(), None, gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), None,
+               dx.data_ptr(), dx16.data_ptr(), dg.data_ptr(), db.data_ptr(), ds.data_ptr(), rows, d, Fn._s())
+        assert rel(dx, xr.grad) < 1e-5 and torch.equal(dx16, dx.half()) and rel(db, dyt.double().sum(0)) < 1e-5
+    with pytest.raises(L.HsError):
+        L.call("hs_layernorm_bwd", dy.data_ptr(), 3, x.data_ptr(), None, gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), None,
+               dx.data_ptr(), None, None, None, None, rows, d, Fn._s())
+    out = torch.zeros(d, device=dev)
+    Fn.colsum(dy.half(), out)
+    assert rel(out, dy.half().double().sum(0)) < 1e-5
 
 
 @pytest.mark.parametrize("N", [1, 9, 65, 200, 513, 2049])
@@ -106,35 +208,30 @@ def test_patchify_f16(dev):
         assert torch.equal(o16, o32.half())
 
 
-def test_block_stack_f16_vs_f32_and_backward_refused(dev):
-    """hs_vit_blocks_fwd at HS_PREC_F16 against its own exact-f32 mode (2 layers, ViT-B widths); a backward pass through an fp16
-    forward raises, and the C entry point refuses save_for_bwd = 1."""
-    import ctypes as C
+def test_block_stack_f16_forward_and_backward_vs_f32(dev):
+    """hs_vit_blocks_fwd / _bwd at HS_PREC_F16 against the exact-f32 mode (2 layers, ViT-B widths) through the module API: forward AND
+    every parameter gradient ~4x closer to f32 than the bf16 mode is (loss scaled by 2^10 and unscaled, as an fp16 training step does)."""
     import hsenet_amd as H
-    from hsenet_amd import _lib as L
     kw = dict(in_channels=1, img_size=(8, 64, 64), patch_size=(4, 16, 16), num_layers=2, pos_embed="perceptron", classification=True)
     torch.manual_seed(0)
     m = H.ViT_stage1(**kw).to(dev).eval()
     x = rnd((2, 1, 8, 64, 64), 12, dev)
-    out = {}
-    for prec in ("f32", "bf16", "f16"):
+    w = rnd((2, 33, 768), 13, dev)
+    out, grads = {}, {}
+    for prec, ls in (("f32", 1.0), ("bf16", 1.0), ("f16", 1024.0)):
         H.set_precision(prec)
         try:
-            with torch.no_grad():
-                out[prec] = m(x)[0]
+            m.zero_grad(set_to_none=True)
+            y, _ = m(x)
+            ((y * w).sum() * ls).backward()
+            torch.cuda.synchronize()
         finally:
             H.set_precision("bf16")
+        out[prec] = y.detach()
+        grads[prec] = {n: p.grad.detach() / ls for n, p in m.named_parameters()}
     e16, eb = rel(out["f16"], out["f32"]), rel(out["bf16"], out["f32"])
-    print(f"2-layer stage-1 forward vs exact f32: fp16 {e16:.2e}, bf16 {eb:.2e}")
-    assert e16 < 1.5e-3 and e16 < 0.5 * eb              # 2 more mantissa bits on every operand: ~4x closer than bf16
-    H.set_precision("f16")
-    try:
-        with pytest.raises(L.HsError, match="forward-only"):
-            y, _ = m(x)
-            (y * y).mean().backward()
-    finally:
-        H.set_precision("bf16")
-    desc = L.VitDesc(1, 65, 768, 12, 3072, 1, L.PREC_F16, 1, 0.0, None)
-    assert L.load().hs_vit_workspace_bytes(C.byref(desc)) == 0
-    desc.save_for_bwd = 0
-    assert L.load().hs_vit_workspace_bytes(C.byref(desc)) > 0
+    g16 = max(rel(grads["f16"][n], grads["f32"][n]) for n in grads["f32"])
+    gb = max(rel(grads["bf16"][n], grads["f32"][n]) for n in grads["f32"])
+    print(f"2-layer stage-1 vs exact f32: forward fp16 {e16:.2e} / bf16 {eb:.2e}; worst parameter gradient fp16 {g16:.2e} / bf16 {gb:.2e}")
+    assert e16 < 1.5e-3 and e16 < 0.5 * eb              # 3 more mantissa bits on every operand
+    assert g16 < 2e-3 and g16 < 0.5 * gb

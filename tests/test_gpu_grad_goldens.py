@@ -38,7 +38,7 @@ def check_grads(named_mine, g, what, tol=TOL):
     assert sorted(mine) == sorted(names), "parameter sets differ"
     big = float(norms.max())
     worst_norm, worst_val = ("", 0.0), ("", 0.0)
-    n_vals = 0
+    n_vals, worst_small = 0, 0.0
     for n, rn in zip(names, norms):
         gm = mine[n]
         # (1) norms.  A tensor whose reference gradient is ~0 (e.g. Wk.bias of a softmax attention: the output is invariant to
@@ -60,15 +60,16 @@ def check_grads(named_mine, g, what, tol=TOL):
         den = max(float(ref.norm()), floor, 1e-4 * big * (ref.numel() / gm.numel()) ** 0.5)
         e = float((got - ref).norm()) / den
         n_vals += 1
-        if rn < 1e-2 * big and tol >= TOL:
-            assert e < TOL_SMALL_SIGNAL, (what, n, e, "small-signal tensor")
+        if rn < 1e-2 * big and tol > TOL_F32:          # (16-bit modes; bf16: 5e-2, fp16: 4 x its tolerance)
+            worst_small = max(worst_small, e)
+            assert e < (TOL_SMALL_SIGNAL if tol >= TOL else 4 * tol), (what, n, e, "small-signal tensor")
             continue
-        if rk in g.files and tol >= TOL:
+        if rk in g.files and tol > TOL_F32:
             e /= 1.5          # three stored rows of a large matrix: a SAMPLE of the tensor's error (its norm is checked in full above)
         if e > worst_val[1]:
             worst_val = (n, e)
     print(f"{what}: {len(names)} tensor norms, worst {worst_norm[0]} {worst_norm[1]:.2e}; {n_vals} tensors by value, worst "
-          f"{worst_val[0]} {worst_val[1]:.2e}")
+          f"{worst_val[0]} {worst_val[1]:.2e}; worst small-signal tensor {worst_small:.2e}")
     assert worst_norm[1] < tol, (what, worst_norm)
     assert worst_val[1] < tol, (what, worst_val)
 
@@ -233,3 +234,76 @@ def test_f32_parity_mode_gradients_vit256(dev, golden):
     finally:
         H.set_precision("bf16")
     check_grads(list(m.named_parameters()), g, "f32 parity mode, ViT_stage1 256^3", tol=TOL_F32)
+
+
+# ---- round 5: fp16 operands through the backward (HS_PREC_F16 training) -------------------------------------------------------------
+TOL_F16 = 3e-3          # measured values are printed; the north-star's 1e-3 is the FORWARD tolerance (fp16 forward: 3e-4 .. 8e-4)
+
+
+@pytest.mark.parametrize("name", ["grad_native_dual.npz", "grad_dual256.npz"])
+def test_dual_engine_f16_vs_reference_gradients(dev, golden, name):
+    """DualEngine(precision='f16') -- the bench's f16_train leg -- against the REFERENCE's gradients: every 16-bit tensor of the step is
+    IEEE fp16, the loss gradient carries a power-of-two loss scale (here 16 on a unit-scale dout) that is divided out afterwards."""
+    from hsenet_amd.engine import DualEngine
+    g = golden(name)
+    tower, p1, p2, x, s, w = _dual_modules(g, dev)
+    eng = DualEngine(tower, p1, p2, 1, precision="f16", loss_scale=16.0)
+    out = eng.forward(x, s)
+    rows = [int(r) for r in g["out_rows_idx"]]
+    e_rows, e_norm = _rel(out[:, rows], g["out_rows"]), _rel(out.norm(dim=-1), g["out_row_norms"])
+    print(f"{name} fp16 forward: rows {e_rows:.2e} row norms {e_norm:.2e}")
+    assert e_rows < 1e-3 and e_norm < 1e-3
+    eng.dout.copy_(w * eng.loss_scale)
+    eng.backward(eng.dout)
+    eng.grad.div_(eng.loss_scale)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(eng.grad).all())
+    check_grads(_named(tower, p1, p2), g, f"DualEngine fp16 {name}", tol=TOL_F16)
+
+
+@pytest.mark.parametrize("path", ["engine", "module"])
+def test_vit256_stage1_f16_vs_reference_gradients(dev, golden, path):
+    """BASELINE configs[1] at fp16 operands: FlatEncoder(precision='f16') and the module API under set_precision('f16')."""
+    import hsenet_amd as H
+    from hsenet_amd.engine import FlatEncoder
+    from oracle import ref_cpu as R
+    g = golden("grad_vit256_stage1.npz")
+    img, patch = (256,) * 3, (16,) * 3
+    m = H.ViT_stage1(in_channels=1, img_size=img, patch_size=patch, pos_embed="perceptron", classification=True).eval()
+    m.load_state_dict(R.seeded_state_dict(m, int(g["seed_w"])))
+    m.to(dev)
+    x = R.synthetic_volume((1, 1) + img, int(g["seed_x"])).to(dev)
+    w = torch.from_numpy(np.random.default_rng(int(g["seed_dy"])).standard_normal((1, 4097, 768), dtype=np.float32)).to(dev)
+    if path == "engine":
+        eng = FlatEncoder(m, 1, n_buckets=4, precision="f16", loss_scale=8.0)
+        eng.forward(x)
+        eng.backward(w * eng.loss_scale)
+        eng.grad.div_(eng.loss_scale)
+    else:
+        H.set_precision("f16")
+        try:
+            y, _ = m(x)
+            ((y * w).sum() * 8.0).backward()
+        finally:
+            H.set_precision("bf16")
+        for p in m.parameters():
+            p.grad.div_(8.0)
+    torch.cuda.synchronize()
+    check_grads(list(m.named_parameters()), g, f"ViT_stage1 256^3 fp16 ({path})", tol=TOL_F16)
+
+
+def test_dual_module_path_f16_vs_reference_gradients(dev, golden):
+    import hsenet_amd as H
+    g = golden("grad_native_dual.npz")
+    tower, p1, p2, x, s, w = _dual_modules(g, dev)
+    H.set_precision("f16")
+    try:
+        out = H.encode_images(tower, p1, p2, x, s)
+        ((out * w).sum() * 4.0).backward()
+        torch.cuda.synchronize()
+    finally:
+        H.set_precision("bf16")
+    for m_ in (tower, p1, p2):
+        for p in m_.parameters():
+            p.grad.div_(4.0)
+    check_grads(_named(tower, p1, p2), g, "module path native dual fp16", tol=TOL_F16)
