@@ -238,6 +238,53 @@ def f32_mode_rate(workload, geom, dev, steps=2):
                     "reference: tests/test_gpu_parity.py); no optimizer step"}
 
 
+def train_accuracy_vs_f32(workload, geom, dev):
+    """forward output and one block's qkv weight gradient of ONE volume's train step (L = mean(out^2)) through the module API at each
+    16-bit operand format, as distances from the exact-f32 mode on the same volume and weights (that mode is within 1e-5 of the
+    reference's fp32 CPU path at full size: tests/test_gpu_grad_goldens.py).  fp16: loss scaled by 2^16 and the gradient unscaled."""
+    import hsenet_amd as H
+    img, patch = geom["img"], geom["patch"]
+    torch.manual_seed(1234)
+    rng = np.random.default_rng(97)
+    vol = torch.from_numpy(rng.random((1, 1) + img, dtype=np.float32)).to(dev)
+    s2d = torch.from_numpy(rng.standard_normal((1, 32, 768), dtype=np.float32)).to(dev)
+    if workload in ("dual256", "native_dual"):
+        tower = H.build_vision_tower(TowerCfg(img, patch)).to(dev)
+        pk = dict(grid=geom["grid"], kernel_size=geom["kernel"])
+        p1 = H.VisualPacker_3d_phi_v3(img, patch, 768, OUT_DIM, "mlp", 2, **pk).to(dev)
+        p2 = H.VisualPacker_3d_phi_v3(img, patch, 768, OUT_DIM, "mlp", 2, **pk).to(dev)
+        mods = [tower.eval(), p1.eval(), p2.eval()]
+        fwd = lambda: H.encode_images(tower, p1, p2, vol, s2d)
+        probes = {"3d_vit.blocks.0.qkv": tower.vision_tower_stage1.blocks[0].attn.qkv.weight,
+                  "2e3_vit.blocks.11.fc1": tower.vision_tower_stage2.blocks[-1].mlp.linear1.weight, "packer.Wk": p1.resolution_attention.Wk.weight}
+    elif workload == "vit256":
+        m = H.ViT_stage1(in_channels=1, img_size=img, patch_size=patch, pos_embed="perceptron", classification=True).to(dev).eval()
+        mods = [m]
+        fwd = lambda: m(vol)[0]
+        probes = {"blocks.0.qkv": m.blocks[0].attn.qkv.weight, "blocks.11.fc1": m.blocks[-1].mlp.linear1.weight}
+    else:
+        return None
+    got = {}
+    for prec, ls in (("f32", 1.0), ("bf16", 1.0), ("f16", 65536.0)):
+        H.set_precision(prec)
+        try:
+            for m_ in mods:
+                m_.zero_grad(set_to_none=True)
+            y = fwd()
+            ((y * y).mean() * ls).backward()
+            torch.cuda.synchronize()
+        finally:
+            H.set_precision("bf16")
+        got[prec] = (y.detach().double(), {k: (p.grad.detach().double() / ls) for k, p in probes.items()})
+    rel = lambda a, b: float((a - b).norm() / b.norm())
+    res = {"what": "one volume, module API, L = mean(out^2): distance of each 16-bit mode from the exact-f32 mode (forward output; worst of "
+                   f"the probed weight gradients {sorted(probes)})"}
+    for prec in ("bf16", "f16"):
+        res[prec + "_fwd_rel_err"] = float(f"{rel(got[prec][0], got['f32'][0]):.3e}")
+        res[prec + "_grad_rel_err"] = float(f"{max(rel(got[prec][1][k], got['f32'][1][k]) for k in probes):.3e}")
+    return res
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -335,7 +382,7 @@ def cpu_baseline(workload, geom, cap_seconds=150.0):
                        f"{cpu_model()} with {threads} threads: 1 warm-up ({warm:.1f} s) + {n} timed, median {med:.1f} s")
 
 
-def build_engine(workload, geom, batch, dev, group=None):
+def build_engine(workload, geom, batch, dev, group=None, precision="bf16"):
     import hsenet_amd as H
     from hsenet_amd.engine import DualEngine, FlatEncoder
     img, patch = geom["img"], geom["patch"]
@@ -349,9 +396,11 @@ def build_engine(workload, geom, batch, dev, group=None):
         p2 = H.VisualPacker_3d_phi_v3(img, patch, 768, OUT_DIM, "mlp", 2, **pk).to(dev)
         ts = os.environ.get("HS_DUAL_STREAMS")                     # (env: A/B runs only; default = the engine's batch rule)
         eng = DualEngine(tower, p1, p2, batch, lr=1e-4, weight_decay=0.1, group=group, two_streams=None if ts is None else ts != "0",
-                         recompute_mlp=bool(os.environ.get("HS_RECOMPUTE_MLP")), **dp)
+                         recompute_mlp=bool(os.environ.get("HS_RECOMPUTE_MLP")), precision=precision, **dp)
         pe = tower.vision_tower_stage1.patch_embedding
         return eng, pe, True
+    if precision != "bf16" and workload not in ("dual256", "native_dual", "vit256"):
+        sys.exit(f"--precision {precision} is wired into the dual256 / native_dual / vit256 engines")
     if workload == "clip_s1":
         from hsenet_amd.clip import M3DCLIPVision_stage1
         from hsenet_amd.clip_step import ClipStage1Engine
@@ -374,7 +423,7 @@ def build_engine(workload, geom, batch, dev, group=None):
     if workload == "mrg_c5":
         return build_mrg(geom, batch, dev, group)
     model = H.ViT_stage1(in_channels=1, img_size=img, patch_size=patch, pos_embed="perceptron", classification=True).to(dev)
-    eng = FlatEncoder(model, batch, lr=1e-4, weight_decay=0.1, group=group, **dp)
+    eng = FlatEncoder(model, batch, lr=1e-4, weight_decay=0.1, group=group, precision=precision, **dp)
     return eng, model.patch_embedding, False
 
 
@@ -475,6 +524,9 @@ def main():
                     "clip_c4a / clip_c4b / mrg_c5: 8, BASELINE configs[3]/[4])")
     ap.add_argument("--grad-wire", default=None, choices=["fp32", "bf16"], help="gradient exchange wire format (default fp32; also HS_GRAD_WIRE)")
     ap.add_argument("--grad-algo", default=None, choices=["allreduce", "rs_ag", "auto"], help="gradient exchange algorithm (default allreduce; also HS_GRAD_ALGO)")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "f16"], help="16-bit operand format of the whole step: bf16 (the reference's "
+                    "autocast policy, the headline) or f16 (IEEE fp16 operands + power-of-two loss scale: same kernels and rate, outputs within "
+                    "1e-3 of the fp32 reference); the default run reports the f16 step beside the headline as `f16_train`")
     ap.add_argument("--attn-logit-std", type=float, default=None, help="scale the q rows of the qkv weights so that the scaled attention "
                     "logits have this standard deviation (random init: 0.31)")
     a = ap.parse_args()
@@ -556,7 +608,7 @@ def main():
         eng = vols = slices = None
         ok = 1
         try:
-            eng, pe, needs_2d = build_engine(a.workload, geom, cand, dev)
+            eng, pe, needs_2d = build_engine(a.workload, geom, cand, dev, precision=a.precision)
             vols, slices = inputs(cand)
             # one untimed forward + backward WITHOUT collectives: the engines size some workspaces on first use, and a rank that runs
             # out of memory must find out before the vote below, not inside a step whose all-reduces the other ranks are waiting in
@@ -636,7 +688,7 @@ def main():
     extras = {}
     if not a.no_extras and a.workload != "mrg_c5":
         k = max(2, min(a.steps, 5))
-        dtn, _ = timed_run(eng, needs_2d, vols, slices, k, 1, sync, optimizer=False)       # every rank: the all-reduces are inside
+        dtn = timed_run(eng, needs_2d, vols, slices, k, 1, sync, optimizer=False)[0]       # every rank: the all-reduces are inside
         if world > 1:
             t = torch.tensor([dtn], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -647,6 +699,7 @@ def main():
             f = set_attn_logit_std(encoders_of(eng), 1.5)
             dtp, stepp = timed_run(eng, needs_2d, vols, slices, k, 1, sync)
             cls_p, roof_p = instrumented(stepp, n_inst)
+            stepp = None                                  # (the closure holds the engine: its HBM must be free for the f16_train leg)
             extras["peaky_attention"] = {"attn_logit_std": 1.5, "q_weight_factor": round(f, 3), "value": round(a.batch * k / dtp, 3),
                                          "unit": "CT-volumes/sec", "ms_per_step": round(1e3 * dtp / k, 3), "steps": k,
                                          "attention": attention_aggregate(cls_p),
@@ -678,7 +731,7 @@ def main():
     out = {
         "metric": METRIC, "value": round(vols_per_s, 3), "unit": "CT-volumes/sec",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
-        "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
         "config": {"workload": f"BASELINE {geom['cfg']}: {img[0]}x{img[1]}x{img[2]} volume, {desc}, random-init weights",
                    "batch_per_gpu": a.batch, "global_batch": a.batch * world, "parallelism": f"dp{world}",
                    "grad_exchange": f"{os.environ.get('HS_GRAD_WIRE', 'fp32')}/{os.environ.get('HS_GRAD_ALGO', 'allreduce')}"},
@@ -705,22 +758,40 @@ def main():
 
     out.update(extras)
 
+    # ---- the same step with fp16 operands (round 5): the mode whose outputs AND gradients sit inside ~1e-3 of the fp32 reference -----------
+    if not a.no_extras and world == 1 and a.precision == "bf16" and a.workload in ("dual256", "native_dual", "vit256"):
+        del eng, step
+        torch.cuda.empty_cache()
+        eng16, _, _ = build_engine(a.workload, geom, a.batch, dev, precision="f16")
+        k16 = max(2, min(a.steps, 5))
+        dt16 = timed_run(eng16, needs_2d, vols, slices, k16, 2, sync)[0]      # ([0]: the returned step closure would keep the engine alive)
+        fin16 = bool(torch.isfinite(eng16.flat).all().item()) and bool(torch.isfinite(eng16.params.gsq).all().item())
+        out["f16_train"] = {"value": round(a.batch * k16 / dt16, 3), "unit": "CT-volumes/sec", "ms_per_step": round(1e3 * dt16 / k16, 3), "steps": k16,
+                            "vs_bf16": round((a.batch * k16 / dt16) / vols_per_s, 4), "loss_scale": eng16.loss_scale, "outputs_finite": fin16,
+                            "what": "the SAME step (same kernels, batch, optimizer) with IEEE fp16 in place of bf16 in every 16-bit tensor, "
+                                    "forward and backward, power-of-two loss scale taken out inside AdamW (engine precision='f16')"}
+        del eng16
+        eng = None
+        torch.cuda.empty_cache()
+        acc = train_accuracy_vs_f32(a.workload, geom, dev)
+        if acc:
+            out["f16_train"]["accuracy"] = acc
+        torch.cuda.empty_cache()
+
     # ---- the same step at ONE volume per GPU (the per-GPU load of configs[3]/[4]: batch 8 over 8 GPUs) ----------
     if not a.no_batch1 and a.batch != 1 and world == 1:
-        del eng, vols, slices, step
+        eng = step = None
+        del vols, slices
         torch.cuda.empty_cache()
-        eng1, _, _ = build_engine(a.workload, geom, 1, dev)
+        eng1, _, _ = build_engine(a.workload, geom, 1, dev, precision=a.precision)
         v1, s1 = inputs(1)
         n1 = max(5, a.steps)
-        dt1, _ = timed_run(eng1, needs_2d, v1, s1, n1, max(2, a.warmup), sync)
+        dt1 = timed_run(eng1, needs_2d, v1, s1, n1, max(2, a.warmup), sync)[0]
         out["batch1"] = {"value": round(n1 / dt1, 3), "unit": "CT-volumes/sec", "ms_per_step": round(1e3 * dt1 / n1, 3), "steps": n1,
                          "mfma_roofline_frac_end_to_end": round(n1 / dt1 * fb / 1e12 / PEAK_BF16_TFLOPS, 4)}
         del eng1
     if rank == 0 and world == 1 and not a.no_extras:
-        try:
-            del eng, vols, slices
-        except NameError:
-            pass
+        eng = vols = slices = step = None
         torch.cuda.empty_cache()
         f32 = f32_mode_rate(a.workload, geom, dev)
         if f32:

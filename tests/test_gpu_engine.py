@@ -122,6 +122,72 @@ def test_dual_engine_vs_oracle(dev):
     print(f"optimizer step matches torch AdamW (+clip at |g| = {float(gn):.3f}) on {len(ref_named)} tensors")
 
 
+def test_dual_engine_f16_train_step_vs_oracle(dev):
+    """round 5: DualEngine(precision='f16') -- every 16-bit tensor IEEE fp16, default power-of-two loss scale -- against the fp32 oracle:
+    forward inside 1e-3, every gradient (after unscaling) ~4x closer than the bf16 engine's, the AdamW step equal to torch.optim.AdamW
+    on the UNSCALED gradients (the scale is divided out inside hs_adamw_masked, the clip acts on the true norm), and an overflowing
+    loss scale leaves parameters and moments untouched (non-finite norm -> skipped step)."""
+    from hsenet_amd.engine import DualEngine, decays, default_loss_scale
+    from oracle import ref_cpu as R
+    from test_gpu_parity import grad_errs
+    B = 3
+    tr, p1r, p2r, sds, x, s = _oracle(B, 900)
+    out_r = R.encode_images(tr, p1r, p2r, x, s)
+    (out_r * out_r).mean().backward()
+    worst = {}
+    for prec in ("bf16", "f16"):
+        tower, p1, p2 = _mine(sds, dev)
+        eng = DualEngine(tower, p1, p2, B, lr=1e-3, weight_decay=0.1, max_grad_norm=1.0, precision=prec)
+        if prec == "f16":
+            assert eng.loss_scale == default_loss_scale(B * 2 * p1.proj_out_num * OUT) == 2.0 ** 13 and eng.patches.dtype == torch.float16
+            assert default_loss_scale(53 * 256 * 3072) == 2.0 ** 25 and default_loss_scale(1) == 1.0
+        eng.train_step(x.to(dev), s.to(dev), optimizer=False)
+        torch.cuda.synchronize()
+        e = rel(eng.out, out_r.detach())
+        assert eng.unscaled_grad().shape == eng.grad.shape
+        if prec == "f16":
+            eng.grad.div_(eng.loss_scale)        # in place, so that the parameters' .grad views hold the true gradient for the comparison
+        errs = grad_errs(_named(tower, p1, p2), _named(tr, p1r, p2r))
+        w = max(errs, key=errs.get)
+        worst[prec] = (e, errs[w], w)
+        print(f"DualEngine [{prec}] vs the fp32 oracle: forward {e:.2e}; worst gradient {w} {errs[w]:.2e}; loss {float(eng.loss):.6f} / "
+              f"{float((out_r * out_r).mean()):.6f}")
+        if prec == "f16":
+            eng.grad.mul_(eng.loss_scale)        # back to what the optimizer step expects
+            assert abs(float(eng.loss) - float((out_r * out_r).mean())) < 2e-3 * float((out_r * out_r).mean())
+    assert worst["f16"][0] < 1e-3 and worst["f16"][1] < 1e-2 and worst["f16"][1] < 0.35 * worst["bf16"][1]
+    # ---- optimizer step on the scaled gradient == torch AdamW (+ clip) on the unscaled one
+    ref_named = _named(tr, p1r, p2r)
+    mine_named = dict(_named(tower, p1, p2))
+    dec = {}
+    for pre, mod in (("vision_tower.", tr), ("mm_projector.", p1r), ("mm_projector2.", p2r)):
+        dec.update({pre + n: v for n, v in decays(mod).items()})
+    for n, p in ref_named:
+        p.grad = (mine_named[n].grad.detach() / eng.loss_scale).cpu().clone()
+    opt = torch.optim.AdamW([{"params": [p for n, p in ref_named if dec[n]], "weight_decay": 0.1},
+                             {"params": [p for n, p in ref_named if not dec[n]], "weight_decay": 0.0}], lr=1e-3)
+    before = {n: p.detach().clone() for n, p in ref_named}
+    gn = torch.nn.utils.clip_grad_norm_([p for _, p in ref_named], 1.0)
+    opt.step()
+    eng.optimizer_step()
+    torch.cuda.synchronize()
+    for n, p in ref_named:
+        moved = float((p.detach() - before[n]).norm())
+        diff = float((mine_named[n].detach().cpu() - p.detach()).norm())
+        assert diff <= 1e-3 * moved + 1e-7, (n, diff, moved)
+    print(f"fp16 engine: optimizer step on the loss-scaled gradient matches torch AdamW on the unscaled one (clip at |g| = {float(gn):.3f})")
+    # ---- an absurd loss scale overflows fp16: the gradient norm is not finite and the step is skipped
+    eng.loss_scale = 2.0 ** 40
+    snap, m_snap = eng.flat.clone(), eng.params.m.clone()
+    eng.train_step(x.to(dev), s.to(dev))
+    torch.cuda.synchronize()
+    assert not bool(torch.isfinite(eng.params.gsq).all()) and torch.equal(eng.flat, snap) and torch.equal(eng.params.m, m_snap)
+    with pytest.raises(Exception):
+        DualEngine(*_mine(sds, dev), B, precision="f32")
+    with pytest.raises(Exception):
+        DualEngine(*_mine(sds, dev), B, precision="bf16", loss_scale=8.0)
+
+
 def test_dual_engine_matches_module_path(dev):
     """engine (fused drivers, flat buffers) == module API (per-op autograd Functions) on the same weights: same kernels
     underneath, so only summation order / epilogue fusion differ."""
@@ -454,7 +520,7 @@ def test_mlp_recompute_is_bit_identical_and_smaller(dev):
         b.train_step(xd, sd_)
     torch.cuda.synchronize()
     assert float((a.flat - b.flat).norm() / a.flat.norm()) < 1e-5
-    # the C entry point refuses the option outside the bf16 path
-    for prec in (L.PREC_F32, L.PREC_F16):
-        assert L.load().hs_vit_workspace_bytes(C.byref(L.VitDesc(1, 65, 768, 12, 3072, 2, prec, 2, 0.0, None))) == 0
+    # the C entry point refuses the option outside the 16-bit paths (bf16, and fp16 since round 5)
+    assert L.load().hs_vit_workspace_bytes(C.byref(L.VitDesc(1, 65, 768, 12, 3072, 2, L.PREC_F32, 2, 0.0, None))) == 0
+    assert L.load().hs_vit_workspace_bytes(C.byref(L.VitDesc(1, 65, 768, 12, 3072, 2, L.PREC_F16, 2, 0.0, None))) > 0
     assert L.load().hs_vit_workspace_bytes(C.byref(L.VitDesc(1, 65, 768, 12, 3072, 2, L.PREC_BF16, 3, 0.0, None))) == 0

@@ -88,7 +88,7 @@ def test_gemm_f16_backward_layouts_and_epilogues(dev, M, N, K):
     db = torch.zeros(K, device=dev)
     Fn.gemm(dy, w.t().contiguous(), L.GEMM_NT, prec=L.PREC_F16, out_bf16=dz, aux=g, colsum_out=db, flags=L.EPI_GELU_BWD | L.EPI_SAVE_DGELU)
     refz = ref * g.double()
-    assert rel(dz.float(), refz) < 6e-4 and rel(db, dz.double().sum(0)) < 1e-4 and rel(db, refz.sum(0)) < 2e-3
+    assert rel(dz.float(), refz) < 6e-4 and rel(db, dz.double().sum(0)) < 1e-3 and rel(db, refz.sum(0)) < 2e-3      # (the sums are taken before the fp16 rounding of dz)
     # forward epilogue that saves gelu'(z) as fp16
     bias = rnd((N,), 24, dev)
     a16 = torch.empty(M, N, dtype=torch.float16, device=dev)
@@ -210,7 +210,7 @@ def test_patchify_f16(dev):
 
 def test_block_stack_f16_forward_and_backward_vs_f32(dev):
     """hs_vit_blocks_fwd / _bwd at HS_PREC_F16 against the exact-f32 mode (2 layers, ViT-B widths) through the module API: forward AND
-    every parameter gradient ~4x closer to f32 than the bf16 mode is (loss scaled by 2^10 and unscaled, as an fp16 training step does)."""
+    every parameter gradient ~4x closer to f32 than the bf16 mode is (loss scaled by 2^4 and unscaled, as an fp16 training step does; 2^10 on this unit-scale dy overflows fp16 and yields NaN)."""
     import hsenet_amd as H
     kw = dict(in_channels=1, img_size=(8, 64, 64), patch_size=(4, 16, 16), num_layers=2, pos_embed="perceptron", classification=True)
     torch.manual_seed(0)
@@ -218,7 +218,7 @@ def test_block_stack_f16_forward_and_backward_vs_f32(dev):
     x = rnd((2, 1, 8, 64, 64), 12, dev)
     w = rnd((2, 33, 768), 13, dev)
     out, grads = {}, {}
-    for prec, ls in (("f32", 1.0), ("bf16", 1.0), ("f16", 1024.0)):
+    for prec, ls in (("f32", 1.0), ("bf16", 1.0), ("f16", 16.0)):
         H.set_precision(prec)
         try:
             m.zero_grad(set_to_none=True)
