@@ -199,8 +199,13 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_bf16_kernel(const bf16_t* __r
 // otherwise.  tests/test_gpu_kernels.py forces both the overflow and the underflow side.
 // ------------------------------------------------------------------------------------------------------
 
-__global__ __launch_bounds__(256, 2) void attn_fwd_fast_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
-                                                            float* __restrict__ lse, int N, int H, float qmul) {
+// F16 (round 5): the same kernel on IEEE fp16 operands.  fp16 has 5 exponent bits, so the window in which the un-referenced P = exp2(s')
+// is exact to rounding is narrower: a row is accepted when its l = sum P lies in [1, 2^15) -- then no P can have overflowed (every P < l <
+// 65504) and the row's largest P is >= l / N, a normal fp16 number; any other row gets lse = NaN and is redone by the running-maximum kernel.
+// Random-init attention (l ~ N) and moderately peaked rows (largest scaled logit below ~10 nats) stay on this kernel.
+template <bool F16>
+__device__ __forceinline__ void attn_fwd_fast_body(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
+                                                   float* __restrict__ lse, int N, int H, float qmul) {
     // qmul: factor applied to the Q fragments (dh^-0.5 * log2(e), or exactly 1 when q arrives pre-scaled)
     __shared__ __attribute__((aligned(16))) char smem[3 * 16384];     // stage: K image 8 KiB | V image 8 KiB
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31;
@@ -246,7 +251,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fast_kernel(const bf16_t* __r
         const int qrow = min(q0 + 32 * qb + c, N - 1);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
-            qf[qb][ks] = scale_frag(buf_load16(rs, (unsigned)(((long)qrow * D3 + head * 64 + ks * 16 + 8 * h) * 2)), qmul);
+            qf[qb][ks] = scale_frag<F16>(buf_load16(rs, (unsigned)(((long)qrow * D3 + head * 64 + ks * 16 + 8 * h) * 2)), qmul);
     }
     // transposed-read bases (image R): rows 4h+q and 4h+q+8 of a 16-row group, 32-column block db
     unsigned tb0[2][2];
@@ -295,8 +300,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fast_kernel(const bf16_t* __r
                     // an asm v_add: hipcc pads no hazards inside asm, and a VALU reading a v_exp result needs a wait state)
                     l[qb] += p;
                 }
-                pf[qb][0] = pack8(s[kb][qb], 0);
-                pf[qb][1] = pack8(s[kb][qb], 1);
+                pf[qb][0] = pack8<F16>(s[kb][qb], 0);
+                pf[qb][1] = pack8<F16>(s[kb][qb], 1);
             }
         };
         auto pv = [&](u32x4 (&f)[2], int sp) {               // 4 MFMAs: 16 keys x (2 d blocks) x (2 query blocks)
@@ -304,7 +309,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fast_kernel(const bf16_t* __r
             for (int db = 0; db < 2; ++db)
 #pragma unroll
                 for (int qb = 0; qb < 2; ++qb)
-                    oacc[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f[db]), pf[qb][sp], oacc[qb][db], 0, 0, 0);
+                    oacc[qb][db] = mfma32<F16>(__builtin_bit_cast(bf16x8, f[db]), pf[qb][sp], oacc[qb][db]);
         };
         // K row fragments of both key blocks are issued up front (asm reads, counted waits); each feeds two MFMAs
         u32x4 ka[4], kc[4];
@@ -317,8 +322,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fast_kernel(const bf16_t* __r
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const bf16x8 kf = __builtin_bit_cast(bf16x8, ka[ks]);
-            s[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[0][ks], s[0][0], 0, 0, 0);
-            s[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[1][ks], s[0][1], 0, 0, 0);
+            s[0][0] = mfma32<F16>(kf, qf[0][ks], s[0][0]);
+            s[0][1] = mfma32<F16>(kf, qf[1][ks], s[0][1]);
         }
         // V fragments of keys 0..15 fly while step 2 runs
         trR_issue<VB + 0>(va[0], tb[0][0], tb[0][1]);
@@ -328,8 +333,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fast_kernel(const bf16_t* __r
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const bf16x8 kf = __builtin_bit_cast(bf16x8, kc[ks]);
-            s[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[0][ks], s[1][0], 0, 0, 0);
-            s[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[1][ks], s[1][1], 0, 0, 0);
+            s[1][0] = mfma32<F16>(kf, qf[0][ks], s[1][0]);
+            s[1][1] = mfma32<F16>(kf, qf[1][ks], s[1][1]);
         }
         softmax(0);
         // steps 3, 4: O^T += V^T P^T, 16 keys at a time, the next fragments in flight behind each group of MFMAs;
@@ -380,12 +385,20 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fast_kernel(const bf16_t* __r
     for (int qb = 0; qb < 2; ++qb) {
         const int query = q0 + 32 * qb + c;
         const float lt = l[qb] + __shfl_xor(l[qb], 32, 64);
-        const bool ok = lt > 8.6736174e-19f && lt < 1.2676506e30f;          // 2^-60 .. 2^100
+        const bool ok = F16 ? (lt >= 1.0f && lt < 32768.0f) : (lt > 8.6736174e-19f && lt < 1.2676506e30f);   // bf16: 2^-60 .. 2^100; fp16: 1 .. 2^15
         if (query < N) {
-            store_dT(o + ((long)b * N + query) * Dm + head * 64, oacc[qb], 1.0f / lt, h);
+            store_dT<F16>(o + ((long)b * N + query) * Dm + head * 64, oacc[qb], 1.0f / lt, h);
             if (h == 0) lse[((long)b * H + head) * N + query] = ok ? __logf(lt) : __builtin_nanf("");
         }
     }
+}
+__global__ __launch_bounds__(256, 2) void attn_fwd_fast_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
+                                                            float* __restrict__ lse, int N, int H, float qmul) {
+    attn_fwd_fast_body<false>(qkv, o, lse, N, H, qmul);
+}
+__global__ __launch_bounds__(256, 2) void attn_fwd_fast_f16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
+                                                                float* __restrict__ lse, int N, int H, float qmul) {
+    attn_fwd_fast_body<true>(qkv, o, lse, N, H, qmul);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1198,10 +1211,17 @@ extern "C" int hs_attn_fwd(const void* qkv, void* o, float* lse, int B, int N, i
     } else if (prec == HS_PREC_F32) {
         hipLaunchKernelGGL(attn_fwd_f32_kernel, grid, dim3(256), 0, s, (const float*)qkv, (float*)o, lse, N, H, c2);
     } else if (prec == HS_PREC_F16) {
-        // fp16 operands (forward only): the running-maximum kernel -- P = exp2(s - max) <= 1 sits in fp16's range, as the softmax ->
-        // .half() of the reference's autocast does; the optimistic kernel's un-referenced exp2(s) would leave it beyond +-16
+        // fp16 operands: the optimistic kernel with fp16's narrower acceptance window (row sums in [1, 2^15): no P overflowed, the largest P
+        // is a normal number), then the running-maximum kernel -- P = exp2(s - max) <= 1, what the reference's softmax -> .half() produces --
+        // over exactly the 128-query blocks that hold a rejected row (normally none: one load and exit)
         if (!lse) return HS_ERR_ARG;
-        hipLaunchKernelGGL((attn_fwd_bf16_kernel<false, true>), grid1, dim3(256), 0, s, (const bf16_t*)qkv, (bf16_t*)o, lse, N, H, c2);
+        if (g_hs_dbg[0] == 1) {       // diagnostic: the exact (running-max) kernel alone
+            hipLaunchKernelGGL((attn_fwd_bf16_kernel<false, true>), grid1, dim3(256), 0, s, (const bf16_t*)qkv, (bf16_t*)o, lse, N, H, c2);
+        } else {
+            dim3 grid2((unsigned)(((N + 255) / 256) * H * B));
+            hipLaunchKernelGGL(attn_fwd_fast_f16_kernel, grid2, dim3(256), 0, s, (const bf16_t*)qkv, (bf16_t*)o, lse, N, H, c2);
+            hipLaunchKernelGGL((attn_fwd_bf16_kernel<true, true>), grid1, dim3(256), 0, s, (const bf16_t*)qkv, (bf16_t*)o, lse, N, H, c2);
+        }
     } else {
         return HS_ERR_ARG;
     }
