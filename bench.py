@@ -778,18 +778,26 @@ def main():
             out["f16_train"]["accuracy"] = acc
         torch.cuda.empty_cache()
 
-    # ---- the same step at ONE volume per GPU (the per-GPU load of configs[3]/[4]: batch 8 over 8 GPUs) ----------
+    # ---- the same step at the per-GPU batches the reference itself trains with: 1 volume (configs[3]/[4]: batch 8 over 8 GPUs), 2 (MRG
+    # finetune, script/train_vlm_mrg.sh:15) and 3 (CLIP pretrain, script/train_clip_stage1.sh:12) ----------
     if not a.no_batch1 and a.batch != 1 and world == 1:
         eng = step = None
         del vols, slices
         torch.cuda.empty_cache()
-        eng1, _, _ = build_engine(a.workload, geom, 1, dev, precision=a.precision)
-        v1, s1 = inputs(1)
-        n1 = max(5, a.steps)
-        dt1 = timed_run(eng1, needs_2d, v1, s1, n1, max(2, a.warmup), sync)[0]
-        out["batch1"] = {"value": round(n1 / dt1, 3), "unit": "CT-volumes/sec", "ms_per_step": round(1e3 * dt1 / n1, 3), "steps": n1,
-                         "mfma_roofline_frac_end_to_end": round(n1 / dt1 * fb / 1e12 / PEAK_BF16_TFLOPS, 4)}
-        del eng1
+        for bsmall in (1, 2, 3):
+            if bsmall >= a.batch:
+                continue
+            engs, _, _ = build_engine(a.workload, geom, bsmall, dev, precision=a.precision)
+            vs_, ss_ = inputs(bsmall)
+            ns = max(5, a.steps)
+            dts = timed_run(engs, needs_2d, vs_, ss_, ns, max(2, a.warmup), sync)[0]
+            out[f"batch{bsmall}"] = {"value": round(bsmall * ns / dts, 3), "unit": "CT-volumes/sec", "ms_per_step": round(1e3 * dts / ns, 3), "steps": ns,
+                                     "batch_per_gpu": bsmall,
+                                     "mfma_roofline_frac_end_to_end": round(bsmall * ns / dts * fb / 1e12 / PEAK_BF16_TFLOPS, 4)}
+            del engs, vs_, ss_
+            torch.cuda.empty_cache()
+        out["batch3"]["what"] = "3 volumes per GPU = the reference's CLIP-pretraining per-device batch (script/train_clip_stage1.sh:12)"
+        out["batch2"]["what"] = "2 volumes per GPU = the reference's MRG-finetuning per-device batch (script/train_vlm_mrg.sh:15)"
     if rank == 0 and world == 1 and not a.no_extras:
         eng = vols = slices = step = None
         torch.cuda.empty_cache()

@@ -16,7 +16,7 @@ HS_OK, HS_ERR_SHAPE, HS_ERR_ARCH, HS_ERR_LAUNCH, HS_ERR_ARG = 0, -1, -2, -3, -4
 PREC_BF16, PREC_F32, PREC_F16 = 0, 1, 2
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 EPI_BIAS, EPI_GELU, EPI_GELU_BWD, EPI_RESID, EPI_ATOMIC, EPI_BIAS_M, EPI_SAVE_DGELU = 1, 2, 4, 8, 16, 32, 64
-ATTN_Q_PRESCALED, ATTN_F32, ATTN_ONE_SWEEP, ATTN_ONE_SWEEP_TILES, ATTN_F16 = 1, 2, 4, 8, 16
+ATTN_Q_PRESCALED, ATTN_F32, ATTN_F16 = 1, 2, 16
 LN_DY_F32, LN_DY_BF16, LN_DY_F16, LN_OUT_F16 = 0, 1, 2, 4
 Q_PRESCALE = 0.125 * 1.44269504088896341   # dh^-0.5 * log2(e) for dh = 64 (hs_gemm scale_cols_alpha for the q third)
 
@@ -73,9 +73,6 @@ SIGNATURES = {
     "hs_layernorm_bwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "hs_attn_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "hs_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
-    "hs_attn_bwd_ws_bytes": [_i, _i, _i, _i],
-    "hs_attn_bwd2": [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _vp],
-    "hs_attn_bwd_ws_error": [_vp, _i, _i, _i, _i, _vp],
     "hs_cross_attn_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _u64, _u64, _vp],
     "hs_cross_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _u64, _u64, _vp],
     "hs_dropout": [_vp, _vp, _i64, _f, _u64, _u64, _vp],
@@ -129,7 +126,7 @@ SIGNATURES = {
     "hs_debug_gemm_stamps": [_vp, _i],
     "hs_debug_gemm_trace": [_vp, _i],
 }
-_RESTYPE = {"hs_vit_workspace_bytes": _sz, "hs_attn_bwd_ws_bytes": _sz, "hs_embed_workspace_bytes": _sz, "hs_packer_workspace_bytes": _sz,
+_RESTYPE = {"hs_vit_workspace_bytes": _sz, "hs_embed_workspace_bytes": _sz, "hs_packer_workspace_bytes": _sz,
             "hs_prof_name": C.c_char_p, "hs_build_id": C.c_char_p, "hs_debug_set": None, "hs_debug_gemm_stamps": None,
             "hs_debug_gemm_trace": None}
 

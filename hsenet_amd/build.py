@@ -14,12 +14,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libhsenet_hip.so")
-SOURCES = ["gemm.hip", "attn.hip", "attn_bwd1.hip", "norm.hip", "small.hip", "vit.hip", "path.hip", "prof.hip", "prep.hip"]
+SOURCES = ["gemm.hip", "attn.hip", "norm.hip", "small.hip", "vit.hip", "path.hip", "prof.hip", "prep.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 # attn.hip: no SLP vectorizer.  It packs the independent f32 adds/multiplies of two softmax streams into v_pk_*_f32, which
 # take more issue time beside MFMAs than the scalar ops they replace (MI355X_MICROARCH.md, cycle constants).
 EXTRA = {"attn.hip": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form"],
-         "attn_bwd1.hip": ["-fno-slp-vectorize"],
          # prep.hip: the reference applies scale and shift (and torch its interpolation taps) as separate roundings
          "prep.hip": ["-ffp-contract=off"]}
 

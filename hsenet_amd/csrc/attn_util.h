@@ -1,4 +1,4 @@
-// Helpers shared by the attention kernels (attn.hip, attn_bwd1.hip): accumulator <-> operand packing, image-R fragment reads,
+// Helpers shared by the attention kernels (attn.hip; tools/experiments/attn_bwd_one_sweep/attn_bwd1.hip): accumulator <-> operand packing, image-R fragment reads,
 // asm-issued transposed LDS reads.  gfx950 only.
 #pragma once
 #include "common.h"

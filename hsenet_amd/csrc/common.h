@@ -182,7 +182,7 @@ __device__ __forceinline__ float dropout_scale(unsigned long long seed, unsigned
 enum { HS_PROF_GEMM_NT = 0, HS_PROF_GEMM_NN, HS_PROF_GEMM_TN, HS_PROF_ATTN_FWD, HS_PROF_ATTN_DELTA, HS_PROF_ATTN_DKDV,
        HS_PROF_ATTN_DQ, HS_PROF_LN_FWD, HS_PROF_LN_BWD, HS_PROF_COLSUM, HS_PROF_CAST, HS_PROF_PATCHIFY, HS_PROF_OTHER,
        HS_PROF_GEMM_NT16_PLAIN, HS_PROF_GEMM_NT16_RESID, HS_PROF_GEMM_NT16_GELU, HS_PROF_GEMM_NT16_DGELU, HS_PROF_GEMM_TN_GROUP,
-       HS_PROF_ADAMW, HS_PROF_GEMM_NT16_BIAS, HS_PROF_ATTN_BWD1, HS_PROF_COUNT };
+       HS_PROF_ADAMW, HS_PROF_GEMM_NT16_BIAS, HS_PROF_COUNT };
 int hs_prof_begin(int id, void* stream, double flops, double bytes);
 void hs_prof_end(int token, void* stream);
 struct ProfScope {

@@ -70,7 +70,7 @@ extern "C" int hs_prof_read(int id, int* count, double* total_ms, double* flops,
 static const char* kNames[HS_PROF_COUNT] = {"gemm_nt", "gemm_nn", "gemm_tn", "attn_fwd", "attn_bwd_pre", "attn_bwd_dkdv",
                                             "attn_bwd_dq", "layernorm_fwd", "layernorm_bwd", "colsum", "cast", "patchify", "other",
                                             "gemm_nt16_plain", "gemm_nt16_bias_resid", "gemm_nt16_bias_gelu", "gemm_nt16_dgelu",
-                                            "gemm_tn_group", "adamw", "gemm_nt16_bias", "attn_bwd_fused"};
+                                            "gemm_tn_group", "adamw", "gemm_nt16_bias"};
 extern "C" const char* hs_prof_name(int id) { return (id >= 0 && id < HS_PROF_COUNT) ? kNames[id] : ""; }
 
 // Diagnostic knob for kernel A/B work (tools/kbench.cpp): selects a kernel variant per class; every value defaults to 0 = the

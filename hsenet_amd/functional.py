@@ -197,31 +197,6 @@ def attn_bwd(qkv, o, d_o, lse, H: int, q_prescaled: bool = False):
     return dqkv
 
 
-def attn_bwd_one_sweep(qkv, o, d_o, lse, H: int, q_prescaled: bool = False, tiles: bool = False, ws=None):
-    """The same gradients from the ONE-sweep kernel (csrc/attn_bwd1.hip; bf16, N = 256 * 2^k (+1)): S and dP computed once, dQ summed
-    over the key blocks by an ordered hand-off.  Slower than the two sweeps on MI355X — nothing selects it by
-    itself; this wrapper exists for the tests and for measurements.  `ws`: a zeroed uint8 workspace to reuse across calls (returned)."""
-    _need(qkv, o, d_o, lse)
-    B, N, _ = qkv.shape
-    if not (qkv.dtype == o.dtype == d_o.dtype == torch.bfloat16):
-        raise L.HsError("attn_bwd_one_sweep: bf16 tensors only")
-    flags = (L.ATTN_Q_PRESCALED if q_prescaled else 0) | L.ATTN_ONE_SWEEP | (L.ATTN_ONE_SWEEP_TILES if tiles else 0)
-    need = L.load().hs_attn_bwd_ws_bytes(B, N, H, flags)
-    if need <= 2 * B * H * N * 4:
-        raise L.HsError(f"attn_bwd_one_sweep: N = {N} does not fit the one-sweep kernel (N = 256 * 2^k (+ 1), k <= 5)")
-    if ws is None:
-        ws = torch.zeros(need, dtype=torch.uint8, device=qkv.device)
-    if ws.numel() < need or ws.dtype != torch.uint8 or ws.device != qkv.device:
-        raise L.HsError("attn_bwd_one_sweep: workspace too small / wrong dtype / wrong device")
-    dqkv = torch.empty_like(qkv)
-    L.call("hs_attn_bwd2", qkv.data_ptr(), o.data_ptr(), d_o.data_ptr(), lse.data_ptr(), dqkv.data_ptr(), ws.data_ptr(), ws.numel(),
-           B, N, H, 64, flags, _s())
-    err = L.load().hs_attn_bwd_ws_error(ws.data_ptr(), B, N, H, flags, _s())
-    if err != 0:
-        raise L.HsError(f"attn_bwd_one_sweep: the hand-off raised its error word ({err}): a bounded wait ran out, gradients void")
-    return dqkv, ws
-
-
 def layernorm_fwd(x, gamma, beta, *, resid=None, want_f32=True, want_bf16=False, eps=1e-5):
     _need(x, gamma, beta, resid)
     rows, d = x.numel() // x.shape[-1], x.shape[-1]

@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
     assert sorted(_lib.SIGNATURES) == names, "hsenet_amd/_lib.py SIGNATURES must mirror the header one to one"
     assert lib.hs_version() >= 1
     names = [lib.hs_prof_name(i).decode() for i in range(lib.hs_prof_count())]
-    assert len(names) == len(set(names)) == 21 and names[3] == "attn_fwd" and lib.hs_prof_name(99) == b""
+    assert len(names) == len(set(names)) == 20 and names[3] == "attn_fwd" and lib.hs_prof_name(99) == b""
     # one class per HOT kernel function: the dominant class of a run is a kernel, not a sum over a GEMM layout
     assert {"attn_bwd_dkdv", "attn_bwd_dq", "gemm_nt16_plain", "gemm_nt16_bias_resid", "gemm_nt16_bias_gelu", "gemm_nt16_dgelu",
             "gemm_nt16_bias", "gemm_tn_group", "adamw"} <= set(names)

@@ -92,19 +92,8 @@ def test_kernel_shape_checks():
     assert lib.hs_attn_fwd(P, P, P, 1, 128, 12, 64, L.PREC_BF16, 64, None) == L.HS_ERR_ARG
     assert lib.hs_attn_fwd(P, P, None, 1, 128, 12, 64, L.PREC_BF16, 0, None) == L.HS_ERR_ARG              # bf16 needs the lse output
     assert lib.hs_attn_bwd(P, P, P, P, P, P, 1, 128, 12, 48, 0, None) == S
-    # hs_attn_bwd2: workspace sizes, unknown flags, alignment; the one-sweep kernel needs its own (larger) workspace
-    two = 2 * 4 * 12 * 513 * 4
-    assert lib.hs_attn_bwd_ws_bytes(4, 513, 12, 0) == two
-    one = lib.hs_attn_bwd_ws_bytes(4, 513, 12, L.ATTN_ONE_SWEEP)
-    assert one > two and lib.hs_attn_bwd_ws_bytes(4, 513, 12, L.ATTN_ONE_SWEEP | L.ATTN_ONE_SWEEP_TILES) > one
-    assert lib.hs_attn_bwd_ws_bytes(4, 500, 12, L.ATTN_ONE_SWEEP) == 2 * 4 * 12 * 500 * 4        # shape does not fit: the two-sweep scratch
-    assert lib.hs_attn_bwd_ws_bytes(4, 513, 12, L.ATTN_ONE_SWEEP | L.ATTN_F32) == two
-    assert lib.hs_attn_bwd_ws_bytes(0, 513, 12, 0) == 0
-    assert lib.hs_attn_bwd2(P, P, P, P, P, P, two - 1, 4, 513, 12, 64, 0, None) == S              # workspace too small
-    assert lib.hs_attn_bwd2(P, P, P, P, P, P + 8, one, 4, 513, 12, 64, L.ATTN_ONE_SWEEP, None) == S  # misaligned workspace
-    assert lib.hs_attn_bwd2(P, P, P, P, P, P, one, 4, 513, 12, 64, 64, None) == L.HS_ERR_ARG      # unknown flag
-    assert lib.hs_attn_bwd2(P, P, P, P, P, None, one, 4, 513, 12, 64, 0, None) == L.HS_ERR_ARG
-    assert lib.hs_attn_bwd2(P, P, P, P, P, P, one, 4, 513, 12, 32, 0, None) == S
+    assert lib.hs_attn_bwd(P, P, P, P, P, P, 1, 128, 12, 64, 4, None) == L.HS_ERR_ARG                       # unknown flag (4 / 8 were the retired one-sweep's)
+    assert lib.hs_attn_bwd(P, P, P, P, P, P, 1, 128, 12, 64, L.ATTN_F32 | L.ATTN_F16, None) == L.HS_ERR_ARG   # one operand format at a time
 
 
 @no_gpu_only
@@ -148,6 +137,14 @@ def test_driver_descriptor_checks():
     em = L.EmbedDesc(1, 32, 1024, 768, 1, 1, 32, 1, 0.0)
     assert lib.hs_embed_workspace_bytes(C.byref(em)) > 0
     assert lib.hs_embed_workspace_bytes(C.byref(L.EmbedDesc(1, 0, 1024, 768, 1, 1, 32, 1, 0.0))) == 0
+    # round 5: the drivers' 16-bit operand format is a descriptor field: bf16 or fp16, nothing else (the exact-f32 mode is the module API's)
+    for prec, ok_ in ((L.PREC_BF16, True), (L.PREC_F16, True), (L.PREC_F32, False), (7, False)):
+        em.prec, pk.prec = prec, prec
+        assert (lib.hs_embed_workspace_bytes(C.byref(em)) > 0) == ok_ and (lib.hs_packer_workspace_bytes(C.byref(pk)) > 0) == ok_
+    assert lib.hs_gemm_group_prec(C.byref(_gemm()), 1, L.PREC_F32, None) == L.HS_ERR_ARG
+    assert lib.hs_mse_grad_scaled(FAKE, FAKE, None, 64, 0.0, None) == L.HS_ERR_ARG                       # the loss scale must be positive
+    assert lib.hs_layernorm_bwd(FAKE, 3, FAKE, None, FAKE, FAKE, FAKE, None, FAKE, None, None, None, None, 8, 64, None) == L.HS_ERR_ARG
+    assert lib.hs_colsum(FAKE, 3, FAKE, 8, 64, 64, None) == L.HS_ERR_ARG
 
 
 def test_debug_selector_is_inert_in_the_product_build(capfd):

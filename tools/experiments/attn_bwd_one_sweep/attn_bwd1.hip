@@ -31,8 +31,10 @@
 //     (~12 cycles each), ~100 VALU instructions (528 cycles of exp2 / multiply / pack) and 7 vector-memory instructions (110-180 cycles
 //     each with four waves in step) -> ~4400 cycles per slice, 35 % matrix-pipe utilisation, whatever the placement.  Two waves per
 //     SIMD issue two streams; that is why the two-sweep kernels (57-62 % busy on 14 N^2 d) still win.
-#include "common.h"
-#include "attn_util.h"
+#include "../../../hsenet_amd/csrc/common.h"
+#include "../../../hsenet_amd/csrc/attn_util.h"
+#include "one_sweep.h"
+#define HS_PROF_ATTN_BWD1 HS_PROF_OTHER      // (the product library has no profiling class for this kernel any more)
 #include <type_traits>
 
 namespace {

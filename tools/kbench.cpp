@@ -161,11 +161,14 @@ int main(int argc, char** argv) {
                 }
         } else {
             auto bwd1 = sym<attn_bwd_t>("hs_attn_bwd");
-            auto bwd2 = sym<attn_bwd2_t>("hs_attn_bwd2");
-            auto wsb = sym<attn_ws_t>("hs_attn_bwd_ws_bytes");
-            auto wserr = sym<attn_err_t>("hs_attn_bwd_ws_error");
-            const int oflags = aflags | HS_ATTN_ONE_SWEEP | (getenv("HS_TILES") ? HS_ATTN_ONE_SWEEP_TILES : 0);
-            const size_t ws_bytes = wsb(B, N, H, oflags);
+            // the retired one-sweep kernel: present only in tools/experiments/attn_bwd_one_sweep/libhsenet_one_sweep.so (HS_LIB=...)
+            auto bwd2 = (attn_bwd2_t)dlsym(g_lib, "hs_attn_bwd2");
+            auto wsb = (attn_ws_t)dlsym(g_lib, "hs_attn_bwd_ws_bytes");
+            auto wserr = (attn_err_t)dlsym(g_lib, "hs_attn_bwd_ws_error");
+            const int kOneSweep = 4, kOneSweepTiles = 8;
+            if ((vA >= 100 || vB >= 100) && (!bwd2 || !wsb || !wserr)) { fprintf(stderr, "variant >= 100 needs HS_LIB=tools/experiments/attn_bwd_one_sweep/libhsenet_one_sweep.so\n"); return 2; }
+            const int oflags = aflags | kOneSweep | (getenv("HS_TILES") ? kOneSweepTiles : 0);
+            const size_t ws_bytes = wsb ? wsb(B, N, H, oflags) : (size_t)B * H * N * 8;
             void* ws2 = dev_zero(ws_bytes);
             printf("attn bwd workspace: %.1f MB (two-sweep scratch %.1f MB)\n", ws_bytes / 1e6, (double)B * H * N * 8 / 1e6);
             // variant >= 100: hs_attn_bwd2 with HS_ATTN_ONE_SWEEP (HS_TILES=1 in the environment: the per-key-block tile form); else hs_attn_bwd
