@@ -93,16 +93,21 @@ def flops_per_volume(workload, Np, Pd, d=768, L=12, ns=32, cells=128, out=OUT_DI
     return 3.0 * enc
 
 
-def measured_pmc(kernel, batch, workload):
-    """rocprofv3 --pmc figures of `kernel` at this batch / workload from the newest committed summary (profiles/r04_pmc.json from
-    tools/collect_traffic.sh + tools/collect_util.sh + tools/util_to_json.py; profiles/r02_traffic.json from round 2): HBM bytes per
-    launch (FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled as the MI355X microarch guide prescribes) and, where
-    collected, the share of matrix-pipe cycles with an MFMA executing.  {} when nothing is committed for this kernel / batch / workload."""
-    for name in ("r04_pmc.json", "r03_pmc.json", "r02_traffic.json"):
+def measured_pmc(kernel, batch, workload, build_id=None):
+    """rocprofv3 --pmc figures of `kernel` at this batch / workload from the newest committed summary (profiles/r0N_pmc.json from
+    tools/collect_traffic.sh + tools/collect_util.sh + tools/util_to_json.py): HBM bytes per launch (FETCH_SIZE and WRITE_SIZE in
+    separate passes, FETCH_SIZE doubled as the MI355X microarch guide prescribes) and the share of matrix-pipe cycles with an MFMA
+    executing.  The counters cannot be collected inside the timed run (counter collection serialises kernels), so they are tied to
+    the library instead: with `build_id` given, a summary whose `_build_id` differs from the loaded library's is NOT used
+    (-> {"stale": file}).  {} when nothing is committed for this kernel / batch / workload."""
+    for name in ("r05_pmc.json", "r04_pmc.json", "r03_pmc.json"):
         try:
-            e = json.load(open(os.path.join(ROOT, "profiles", name))).get(kernel)
+            allk = json.load(open(os.path.join(ROOT, "profiles", name)))
+            e = allk.get(kernel)
             if e and int(e.get("batch", -1)) == int(batch) and e.get("workload") == workload and "hbm_bytes_per_launch" in e:
-                return dict(e, source=f"profiles/{name}")
+                if build_id is not None and allk.get("_build_id") != build_id:
+                    return {"stale": f"profiles/{name}", "build_id": allk.get("_build_id")}
+                return dict(e, source=f"profiles/{name}", build_id=allk.get("_build_id"))
         except Exception:
             pass
     return {}
@@ -190,6 +195,41 @@ def eval_forward_rates(workload, geom, dev, batch=4, steps=3):
         else:
             res[prec + "_rel_err_vs_f32"] = float(f"{float((y.double() - ref).norm() / ref.norm()):.3e}")
     return res
+
+
+def eval_latency(workload, geom, dev, reps=10):
+    """ms of ONE sample through encoders + packers at fp16 operands under torch.no_grad(): the generation path runs the vision side once
+    per sample (language_model/lamed_phi3.py:151-228) under torch.cuda.amp.autocast() = fp16 (Bench/eval/eval_HSENet_CT_Rate_MRG.py:383,423)."""
+    import hsenet_amd as H
+    if workload not in ("dual256", "native_dual"):
+        return None
+    img, patch = geom["img"], geom["patch"]
+    torch.manual_seed(1234)
+    rng = np.random.default_rng(96)
+    vol = torch.from_numpy(rng.random((1, 1) + img, dtype=np.float32)).to(dev)
+    s2d = torch.from_numpy(rng.standard_normal((1, 32, 768), dtype=np.float32)).to(dev)
+    tower = H.build_vision_tower(TowerCfg(img, patch)).to(dev).eval()
+    pk = dict(grid=geom["grid"], kernel_size=geom["kernel"])
+    p1 = H.VisualPacker_3d_phi_v3(img, patch, 768, OUT_DIM, "mlp", 2, **pk).to(dev).eval()
+    p2 = H.VisualPacker_3d_phi_v3(img, patch, 768, OUT_DIM, "mlp", 2, **pk).to(dev).eval()
+    res = {}
+    for prec in ("f16", "bf16"):
+        H.set_precision(prec)
+        try:
+            with torch.no_grad():
+                for _ in range(2):
+                    H.encode_images(tower, p1, p2, vol, s2d)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    H.encode_images(tower, p1, p2, vol, s2d)
+                torch.cuda.synchronize()
+            res[prec] = round(1e3 * (time.perf_counter() - t0) / reps, 3)
+        finally:
+            H.set_precision("bf16")
+    return {"f16": res["f16"], "bf16": res["bf16"], "unit": "ms per sample", "batch": 1, "reps": reps,
+            "what": "one volume -> dual encoders -> two Spatial Packers -> (1,256,3072), module API under torch.no_grad(): the vision side of "
+                    "one generate() call"}
 
 
 def f32_mode_rate(workload, geom, dev, steps=2):
@@ -663,12 +703,15 @@ def main():
                 c["gbs"] = c["bytes"] / (c["total_ms"] * 1e-3) / 1e9
             mf = [c for c in classes_ if c["flops"]]
             dom = max(mf, key=lambda c: c["total_ms"])
-            pmc = measured_pmc(dom["name"], a.batch, a.workload)
+            pmc = measured_pmc(dom["name"], a.batch, a.workload, L.build_id())
             roof_ = dict(kernel=dom["name"], bound="mfma", achieved=round(dom["tflops"], 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
                          frac=round(dom["tflops"] / PEAK_BF16_TFLOPS, 4), traffic=pmc.get("hbm_bytes_per_launch"),
                          avg_launch_us=round(dom["avg_us"], 2), flops_per_launch=dom["flops"] / dom["launches"])
-            if pmc:
-                roof_["traffic_source"] = pmc["source"]
+            if pmc.get("stale"):
+                roof_["traffic_note"] = (f"{pmc['stale']} was collected with library build {pmc['build_id']}, this run loaded {L.build_id()}: "
+                                         "its counters are not reported (re-run tools/r5_profiles.sh)")
+            elif pmc:
+                roof_["traffic_source"], roof_["traffic_build_id"] = pmc["source"], pmc["build_id"]
                 if pmc.get("mfma_busy_frac") is not None:
                     roof_["mfma_busy_frac_pmc"] = round(pmc["mfma_busy_frac"], 4)
             if forked:
@@ -808,6 +851,10 @@ def main():
         ev = eval_forward_rates(a.workload, geom, dev)
         if ev:
             out["eval_forward"] = ev
+        torch.cuda.empty_cache()
+        el = eval_latency(a.workload, geom, dev)
+        if el:
+            out["eval_latency_ms"] = el
     if rank == 0 and world == 1 and not a.no_cpu_baseline and a.workload != "mrg_c5":      # (the LLM-dominated step has no CPU leg)
         out["cpu_baseline"] = cpu_baseline(a.workload, geom)
     if rank == 0:

@@ -1,6 +1,6 @@
 """profiles/<tag>_pmc.json: per kernel class of one bench.py run, rocprof-reported HBM bytes / GB/s and MFMA utilisation.
 
-    python tools/util_to_json.py <outdir> <batch> [workload] [tag]
+    python tools/util_to_json.py <outdir> <batch> [workload] [tag] [bench-line.json]
 
 Inputs: the three separate --pmc passes of tools/collect_traffic.sh (FETCH_SIZE, WRITE_SIZE) and tools/collect_util.sh (SQ/GRBM).
   hbm_bytes_per_launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024     (KiB counters; FETCH_SIZE doubled on gfx950, MI355X_MICROARCH.md "HBM")
@@ -19,7 +19,7 @@ import sys
 
 out, batch = sys.argv[1], int(sys.argv[2])
 workload = sys.argv[3] if len(sys.argv) > 3 else "dual256"
-tag = sys.argv[4] if len(sys.argv) > 4 else "r04"
+tag = sys.argv[4] if len(sys.argv) > 4 else "r05"
 # kernel-name substring -> class (= hs_prof_name() of the library's per-kernel timers); first match wins
 CLASS = [("attn_fwd_fast_kernel", "attn_fwd"), ("attn_bwd_dkdv16_w4_kernel", "attn_bwd_dkdv"), ("attn_bwd_dq2_w4", "attn_bwd_dq"),
          ("gemm_nt16_persist_kernel<0,", "gemm_nt16_plain"), ("gemm_nt16_persist_kernel<9,", "gemm_nt16_bias_resid"), ("gemm_nt16_persist_kernel<1,", "gemm_nt16_bias"),
@@ -101,6 +101,19 @@ for c in sorted(set(list(util) + list(fetch))):
     if insts is not None and us:
         e["mfma_tflops_executed"] = insts / us / 1e6
     res[c] = e
+# tie the counters to the library they were taken with: bench.py reports them only while the loaded library's hs_build_id matches
+try:
+    sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+    from hsenet_amd import _lib as _L
+    res["_build_id"] = _L.build_id()
+except Exception as e:                     # noqa: BLE001
+    res["_build_id"] = None
+    print("no build id:", e)
+if len(sys.argv) > 5:                      # the bench line measured beside the passes (volumes/s of the un-profiled run)
+    try:
+        res["_bench_value"] = json.load(open(sys.argv[5]))["value"]
+    except Exception as e:                 # noqa: BLE001
+        print("no bench value:", e)
 res["_note"] = ("separate rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ+GRBM), FETCH_SIZE doubled (gfx950); durations from the "
                 "SQ+GRBM pass' kernel trace; see tools/util_to_json.py for the formulas")
 json.dump(res, open(f"profiles/{tag}_pmc.json", "w"), indent=1)
