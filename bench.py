@@ -439,13 +439,11 @@ def build_engine(workload, geom, batch, dev, group=None, precision="bf16"):
                          recompute_mlp=bool(os.environ.get("HS_RECOMPUTE_MLP")), precision=precision, **dp)
         pe = tower.vision_tower_stage1.patch_embedding
         return eng, pe, True
-    if precision != "bf16" and workload not in ("dual256", "native_dual", "vit256"):
-        sys.exit(f"--precision {precision} is wired into the dual256 / native_dual / vit256 engines")
     if workload == "clip_s1":
         from hsenet_amd.clip import M3DCLIPVision_stage1
         from hsenet_amd.clip_step import ClipStage1Engine
         model = M3DCLIPVision_stage1(img, patch).to(dev)
-        eng = ClipStage1Engine(model, batch, lr=1e-4, weight_decay=0.1, group=group, **dp)
+        eng = ClipStage1Engine(model, batch, lr=1e-4, weight_decay=0.1, group=group, precision=precision, **dp)
         rng = np.random.default_rng(4321 + int(os.environ.get("RANK", "0")))
         eng.set_text_features(torch.nn.functional.normalize(torch.from_numpy(rng.standard_normal((batch, 768), dtype=np.float32)), dim=-1).to(dev))
         return eng, model.vision_encoder.patch_embedding, False
@@ -454,20 +452,20 @@ def build_engine(workload, geom, batch, dev, group=None, precision="bf16"):
         model = make_clip_stage2(img, patch).to(dev)
         if workload == "clip_c4b":
             model.stage1_pretrained_CLIP.requires_grad_(True)
-        eng = ClipStage2Engine(model, batch, lr=1e-4, weight_decay=0.1, group=group, train_stage1=workload == "clip_c4b", **dp)
+        eng = ClipStage2Engine(model, batch, lr=1e-4, weight_decay=0.1, group=group, train_stage1=workload == "clip_c4b", precision=precision, **dp)
         rng = np.random.default_rng(4321 + int(os.environ.get("RANK", "0")))
         txt = [torch.nn.functional.normalize(torch.from_numpy(rng.standard_normal((batch, 768), dtype=np.float32)), dim=-1).to(dev)
                for _ in range(2)]                                   # frozen text embeddings: normalize(N(0,1))
         eng.set_text_features(*txt)
         return eng, model.vision_encoder.patch_embedding, True
     if workload == "mrg_c5":
-        return build_mrg(geom, batch, dev, group)
+        return build_mrg(geom, batch, dev, group, precision)
     model = H.ViT_stage1(in_channels=1, img_size=img, patch_size=patch, pos_embed="perceptron", classification=True).to(dev)
     eng = FlatEncoder(model, batch, lr=1e-4, weight_decay=0.1, group=group, precision=precision, **dp)
     return eng, model.patch_embedding, False
 
 
-def build_mrg(geom, batch, dev, group):
+def build_mrg(geom, batch, dev, group, precision="bf16"):
     """BASELINE configs[4]: dual encoders (frozen) + two packers (trainable) spliced into a stock HF Phi-4-mini-shaped decoder
     (random-init from its config -- no weights offline --, bf16, frozen; the LLM runs on PyTorch-ROCm and is OUT OF SCOPE of the HIP
     path: it is there so that the step has the reference's shape, lamed_phi3.py:41-148)."""
@@ -479,7 +477,7 @@ def build_mrg(geom, batch, dev, group):
     pk = dict(grid=geom["grid"], kernel_size=geom["kernel"])
     p1 = H.VisualPacker_3d_phi_v3(img, patch, 768, OUT_DIM, "mlp", 2, **pk).to(dev)
     p2 = H.VisualPacker_3d_phi_v3(img, patch, 768, OUT_DIM, "mlp", 2, **pk).to(dev)
-    eng = MRGStepEngine(tower, p1, p2, batch, lr=1e-4, weight_decay=0.0, group=group)       # script/train_vlm_mrg.sh:14,26: lr 1e-4, wd 0
+    eng = MRGStepEngine(tower, p1, p2, batch, lr=1e-4, weight_decay=0.0, group=group, precision=precision)       # script/train_vlm_mrg.sh:14,26: lr 1e-4, wd 0
     cfg = Phi3Config(hidden_size=OUT_DIM, intermediate_size=8192, num_hidden_layers=32, num_attention_heads=24, num_key_value_heads=8,
                      vocab_size=200064, max_position_embeddings=4096, pad_token_id=0, bos_token_id=1, eos_token_id=2,
                      tie_word_embeddings=True, attn_implementation="sdpa")

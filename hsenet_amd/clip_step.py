@@ -27,7 +27,7 @@ import torch.distributed as dist
 from . import _lib as L
 from . import functional as Fn
 from .clip import M3DCLIPVision_stage1, M3DCLIPVision_stage2, relation_loss_weight
-from .engine import EncoderUnit, _Engine, _al, _encoder_bounds, _encoder_entries, decays
+from .engine import EncoderUnit, _Engine, _al, _encoder_bounds, _encoder_entries, _engine_prec, decays
 
 
 def make_clip_stage2(img_size, patch_size, **kw) -> M3DCLIPVision_stage2:
@@ -83,6 +83,14 @@ def _clip_flat(unit: EncoderUnit, model, n_buckets: int):
     return entries, chunks, bounds
 
 
+def _clip_loss_scale(prec: int, loss_scale, n_global: int) -> float:
+    if prec != L.PREC_F16:
+        if loss_scale not in (None, 1, 1.0):
+            raise L.HsError("loss_scale belongs to precision 'f16'")
+        return 1.0
+    return float(loss_scale) if loss_scale else float(2 ** (8 + max(1, int(n_global)).bit_length() - 1))
+
+
 class _ClipEngine(_Engine):
     def _gather(self, local: torch.Tensor, all_feats: torch.Tensor) -> None:
         """collective C2: every rank's feature rows, in rank order.  A muted engine (``probe_step``: the collective-free fit probe) fills
@@ -101,13 +109,16 @@ class ClipStage1Engine(_ClipEngine):
     text features: the L2-normalised cls text features [B_local, d] of the (out-of-scope) BERT tower, frozen inputs."""
 
     def __init__(self, model: M3DCLIPVision_stage1, batch: int, *, lr=1e-4, weight_decay=0.1, max_grad_norm: Optional[float] = 1.0,
-                 n_buckets=4, group=None, grad_wire="fp32", grad_algo="allreduce"):
+                 n_buckets=4, group=None, grad_wire="fp32", grad_algo="allreduce", precision: str = "bf16", loss_scale: Optional[float] = None):
+        """precision 'f16': the encoder runs on IEEE fp16 operands (engine._Engine); dL/dlogits is multiplied by ``loss_scale`` (default
+        2^(8 + floor(log2(global batch))): InfoNCE gradients of the cls features are O(1 / batch)) and AdamW divides it out."""
+        self.prec = _engine_prec(precision)
         if model.local_loss or not model.gather_loss:
             raise L.HsError("ClipStage1Engine drives the shipped configuration: gather_loss=True, local_loss=False")
         if not all(p.requires_grad for p in model.parameters()):
             raise L.HsError("ClipStage1Engine trains every parameter of the model: requires_grad_(True) first")
         self.model, self.B, self.group = model, batch, group
-        self.u = EncoderUnit(model.vision_encoder, batch, trainable=True)
+        self.u = EncoderUnit(model.vision_encoder, batch, trainable=True, prec=self.prec)
         self.dev = self.u.dev
         on = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(group) if on else 1
@@ -119,7 +130,8 @@ class ClipStage1Engine(_ClipEngine):
         self.head = _Head(self.u, model.mm_vision_proj, True)
         d, n = self.u.d, batch * self.world
         f32 = dict(dtype=torch.float32, device=self.dev)
-        self.patches = torch.empty(batch * self.u.Np, self.u.Pd, dtype=torch.bfloat16, device=self.dev)
+        self.patches = torch.empty(batch * self.u.Np, self.u.Pd, dtype=self.dtype16, device=self.dev)
+        self.loss_scale = _clip_loss_scale(self.prec, loss_scale, n)
         self.local = torch.empty(batch, 2 * d, **f32)              # [img | txt] of this rank
         self.all = torch.empty(n, 2 * d, **f32)                    # ... of every rank (ONE all-gather per step)
         self.raw, self.logits = torch.empty(n, n, **f32), torch.empty(n, n, **f32)
@@ -142,6 +154,8 @@ class ClipStage1Engine(_ClipEngine):
         L.call("hs_scale_dev", self.raw.data_ptr(), self.logits.data_ptr(), self.model.logit_scale.data_ptr(), 1.0, n * n, s)
         self.acc.zero_()
         L.call("hs_clip_ce", self.logits.data_ptr(), self.dlog.data_ptr(), self.acc.data_ptr(), n, s)
+        if self.loss_scale != 1.0:        # fp16 backward: every gradient of the step is linear in dL/dlogits
+            L.call("hs_scale", self.dlog.data_ptr(), self.dlog.data_ptr(), self.loss_scale, n * n, s)
 
     def backward_from_all(self, all_feats: torch.Tensor, row_stride: int, col_txt: int) -> None:
         """self.dlog -> every gradient of this model (flat gradient zeroed here), bucketed all-reduce launched and awaited."""
@@ -201,18 +215,21 @@ class ClipStage2Engine(_ClipEngine):
     docstring): ``self.s1`` is a ``ClipStage1Engine`` over ``model.stage1_pretrained_CLIP`` (whose parameters must then require grad)."""
 
     def __init__(self, model: M3DCLIPVision_stage2, batch: int, *, lr=1e-4, weight_decay=0.1, max_grad_norm: Optional[float] = 1.0,
-                 n_buckets=4, group=None, grad_wire="fp32", grad_algo="allreduce", train_stage1: bool = False):
+                 n_buckets=4, group=None, grad_wire="fp32", grad_algo="allreduce", train_stage1: bool = False, precision: str = "bf16",
+                 loss_scale: Optional[float] = None):
+        self.prec = _engine_prec(precision)
         if model.local_loss or not model.gather_loss:
             raise L.HsError("ClipStage2Engine drives the shipped configuration: gather_loss=True, local_loss=False")
         self.model, self.B, self.group = model, batch, group
         self.s1 = None
         if train_stage1:
             self.s1 = ClipStage1Engine(model.stage1_pretrained_CLIP, batch, lr=lr, weight_decay=weight_decay, max_grad_norm=max_grad_norm,
-                                       n_buckets=n_buckets, group=group, grad_wire=grad_wire, grad_algo=grad_algo)
+                                       n_buckets=n_buckets, group=group, grad_wire=grad_wire, grad_algo=grad_algo, precision=precision,
+                                       loss_scale=loss_scale)
             self.u1 = self.s1.u
         else:
-            self.u1 = EncoderUnit(model.stage1_pretrained_CLIP.vision_encoder, batch, trainable=False)
-        self.u2 = EncoderUnit(model.vision_encoder, batch, trainable=True)
+            self.u1 = EncoderUnit(model.stage1_pretrained_CLIP.vision_encoder, batch, trainable=False, prec=self.prec)
+        self.u2 = EncoderUnit(model.vision_encoder, batch, trainable=True, prec=self.prec)
         self.dev = self.u2.dev
         on = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(group) if on else 1
@@ -232,7 +249,8 @@ class ClipStage2Engine(_ClipEngine):
         d, n = u.d, batch * self.world
         f32 = dict(dtype=torch.float32, device=self.dev)
         # (both-trainable: ONE patch matrix, the stage-1 engine's -- its embedding backward reads it)
-        self.patches = self.s1.patches if self.s1 is not None else torch.empty(batch * u.Np, u.Pd, dtype=torch.bfloat16, device=self.dev)
+        self.patches = self.s1.patches if self.s1 is not None else torch.empty(batch * u.Np, u.Pd, dtype=self.dtype16, device=self.dev)
+        self.loss_scale = _clip_loss_scale(self.prec, loss_scale, n)
         self.local = torch.empty(batch, 4 * d, **f32)              # [img1 | txt1 | img2 | txt2] of this rank
         self.all = torch.empty(n, 4 * d, **f32)                    # ... of every rank (ONE all-gather per step)
         self.raw1, self.raw2 = torch.empty(n, n, **f32), torch.empty(n, n, **f32)
@@ -282,6 +300,8 @@ class ClipStage2Engine(_ClipEngine):
         L.call("hs_relation_mse", self.logits1.data_ptr(), self.logits2.data_ptr(), self.dlog.data_ptr(), self.acc.data_ptr() + 8, n * n,
                float(w), 1, s)
         self._w = w
+        if self.loss_scale != 1.0:        # fp16 backward: scale dL/dlogits (InfoNCE + weighted relation term), AdamW takes it out
+            L.call("hs_scale", self.dlog.data_ptr(), self.dlog.data_ptr(), self.loss_scale, n * n, s)
         if self.s1 is not None:                                         # the stage-1 model's own InfoNCE, with ITS logit_scale
             self.s1.loss_from_all(self.all, 4 * d, 0, 1)
 

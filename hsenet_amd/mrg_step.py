@@ -22,22 +22,30 @@ from . import _lib as L
 from . import functional as Fn
 from .clip import splice_image_features
 from .encoder import ViT3DTower_dual_encoders
-from .engine import EncoderUnit, PackerUnit, _Engine, _al, decays
+from .engine import EncoderUnit, PackerUnit, _Engine, _al, _engine_prec, decays
 from .projector import VisualPacker_3d_phi_v3
 
 
 class MRGStepEngine(_Engine):
     def __init__(self, tower: ViT3DTower_dual_encoders, packer1: VisualPacker_3d_phi_v3, packer2: VisualPacker_3d_phi_v3, batch: int, *,
-                 lr=1e-4, weight_decay=0.0, max_grad_norm: Optional[float] = 1.0, group=None):
+                 lr=1e-4, weight_decay=0.0, max_grad_norm: Optional[float] = 1.0, group=None, precision: str = "bf16",
+                 loss_scale: Optional[float] = None):
+        """precision 'f16': towers and packers on fp16 operands (the reference's eval-time autocast dtype; engine._Engine); the caller's LLM
+        loss is multiplied by ``loss_scale`` (default 2^10) before its backward and AdamW divides the packer gradients by it."""
+        self.prec = _engine_prec(precision)
+        if self.prec == L.PREC_F16:
+            self.loss_scale = float(loss_scale) if loss_scale else 1024.0
+        elif loss_scale not in (None, 1, 1.0):
+            raise L.HsError("loss_scale belongs to precision 'f16'")
         if tower.select_feature != "patch" or tower.remain_2d3d_ViT_type != "dual_vits":
             raise L.HsError("MRGStepEngine drives the shipped configuration: select_feature='patch', remain_2d3d_ViT_type='dual_vits'")
         self.tower, self.B = tower, batch
-        self.u1 = EncoderUnit(tower.vision_tower_stage1, batch, trainable=False)
-        self.u2 = EncoderUnit(tower.vision_tower_stage2, batch, trainable=False)
+        self.u1 = EncoderUnit(tower.vision_tower_stage1, batch, trainable=False, prec=self.prec)
+        self.u2 = EncoderUnit(tower.vision_tower_stage2, batch, trainable=False, prec=self.prec)
         self.dev = self.u1.dev
         off1 = 1 if self.u1.has_cls else 0
-        self.p1 = PackerUnit(packer1, batch, self.u1.N, off1, 2, 0, True)
-        self.p2 = PackerUnit(packer2, batch, self.u2.N, off1, 2, 1, True)
+        self.p1 = PackerUnit(packer1, batch, self.u1.N, off1, 2, 0, True, self.prec)
+        self.p2 = PackerUnit(packer2, batch, self.u2.N, off1, 2, 1, True, self.prec)
         d1, d2 = decays(packer1), decays(packer2)
         e1 = [("mm_projector." + n, p, d1[n]) for n, p in self.p1.flat_order()]
         e2 = [("mm_projector2." + n, p, d2[n]) for n, p in self.p2.flat_order()]
@@ -46,7 +54,7 @@ class MRGStepEngine(_Engine):
         self._finish(e1 + e2, [(split, total), (0, split)], lr=lr, weight_decay=weight_decay, max_grad_norm=max_grad_norm, group=group)
         for u in (self.u1, self.u2, self.p1, self.p2):
             u.bind()
-        self.patches = torch.empty(batch * self.u1.Np, self.u1.Pd, dtype=torch.bfloat16, device=self.dev)
+        self.patches = torch.empty(batch * self.u1.Np, self.u1.Pd, dtype=self.dtype16, device=self.dev)
         self.out = torch.empty(batch, 2 * self.p1.cells, packer1.out_dim, dtype=torch.float32, device=self.dev)
         self.side = torch.cuda.Stream(device=self.dev)
         self.last_loss = None
@@ -68,7 +76,7 @@ class MRGStepEngine(_Engine):
         feats = self.encode_images(vol, image_2d).detach().requires_grad_()
         emb = splice_image_features(inputs_embeds.detach().float(), feats)                       # lamed_arch.py:153-154
         loss = llm_loss(emb)
-        loss.backward()
+        (loss * self.loss_scale if self.loss_scale != 1.0 else loss).backward()
         self.last_loss = loss.detach()
         if feats.grad is None:
             raise L.HsError("llm_loss(emb) must depend on the spliced image features (no gradient reached them)")
