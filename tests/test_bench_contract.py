@@ -30,16 +30,21 @@ def test_default_batch_and_pmc_summary_are_consistent():
     blocks = bench.DEFAULT_BATCH * 33 * 12                   # attention-backward grid: 33 blocks of 128 keys/queries x 12 heads per volume
     assert abs(blocks / 512.0 - round(blocks / 512.0)) < 0.02 and blocks / 512.0 < round(blocks / 512.0)      # just under a whole number of rounds
     pmc = bench.measured_pmc("attn_bwd_dkdv", bench.DEFAULT_BATCH, "dual256")
-    assert pmc and pmc["source"] == "profiles/r04_pmc.json" and pmc["hbm_bytes_per_launch"] > 1e9 and 0.4 < pmc["mfma_busy_frac"] < 0.8
+    assert pmc and pmc["source"] == "profiles/r05_pmc.json" and pmc["hbm_bytes_per_launch"] > 1e9 and 0.4 < pmc["mfma_busy_frac"] < 0.8
+    # round 5: the summary names the library it was collected with, and a run that loaded another library does not get its counters
+    e = json.load(open(os.path.join(ROOT, "profiles", "r05_pmc.json")))
+    assert len(e["_build_id"]) == 16 and e["_bench_value"] > 0 and pmc["build_id"] == e["_build_id"]
+    assert bench.measured_pmc("attn_bwd_dkdv", bench.DEFAULT_BATCH, "dual256", e["_build_id"])["source"] == "profiles/r05_pmc.json"
+    stale = bench.measured_pmc("attn_bwd_dkdv", bench.DEFAULT_BATCH, "dual256", "0" * 16)
+    assert stale == {"stale": "profiles/r05_pmc.json", "build_id": e["_build_id"]}
     # round 4: FETCH_SIZE and WRITE_SIZE are kept apart in the committed summary (the verdict's item 3(0)), and sum to the total
-    e = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc.json")))
     for k in ("gemm_nt16_bias_gelu", "gemm_nt16_dgelu", "gemm_tn_group", "attn_bwd_dkdv"):
         assert abs(e[k]["fetch_bytes_per_launch"] + e[k]["write_bytes_per_launch"] - e[k]["hbm_bytes_per_launch"]) < 1.0, k
     assert bench.measured_pmc("attn_bwd_dkdv", 7, "dual256") == {}                  # nothing committed for that batch: traffic = null
 
 
 def test_committed_bench_line_keeps_the_contract():
-    lines = sorted(glob.glob(os.path.join(ROOT, "profiles", "r04_bench_dual_batch53.json")))
+    lines = sorted(glob.glob(os.path.join(ROOT, "profiles", "r05_bench_dual_batch53.json")))
     assert lines, "the bench line of the default run is committed with the profiles"
     d = json.load(open(lines[-1]))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
@@ -49,7 +54,8 @@ def test_committed_bench_line_keeps_the_contract():
     assert d["config"]["workload"].startswith("BASELINE configs[2]") and d["config"]["batch_per_gpu"] == 53 and "model" not in d["config"]
     r = d["roofline"]
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
-    assert r["kernel"] == "attn_bwd_dkdv" and r["traffic"] > 0
+    assert r["kernel"] == "attn_bwd_dkdv" and (r["traffic"] is None or r["traffic"] > 0)      # (null + traffic_note when the PMC summary is another library's)
+    assert ("traffic_build_id" in r) != ("traffic_note" in r)
     # achieved = algorithmic FLOPs per launch / average launch time (6 N^2 d per (batch, head): dV, dP, dK of SURVEY 8(d)'s 8 N^2 d backward)
     assert abs(r["flops_per_launch"] - 6.0 * 4097 ** 2 * 64 * 12 * 53) < 1e6
     assert abs(r["achieved"] - r["flops_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e12) < 1.0
@@ -65,6 +71,12 @@ def test_committed_bench_line_keeps_the_contract():
     ev = d["eval_forward"]
     assert ev["f16"] > 0 and ev["bf16"] > 0 and ev["f32"] > 0 and ev["f16_rel_err_vs_f32"] < 1e-3 < ev["bf16_rel_err_vs_f32"]
     assert d["batch1"]["value"] > 0 and d["config"]["grad_exchange"] == "fp32/allreduce" and d["config"]["batch_changed_from"] == 20
+    # round 5: the fp16 train step beside the headline, the reference's own per-device batches, the one-sample eval latency
+    f = d["f16_train"]
+    assert f["outputs_finite"] is True and 0.9 < f["vs_bf16"] < 1.1 and f["loss_scale"] == 2.0 ** 25
+    assert f["accuracy"]["f16_fwd_rel_err"] < 1e-3 < f["accuracy"]["bf16_fwd_rel_err"] and f["accuracy"]["f16_grad_rel_err"] < 2e-3 < f["accuracy"]["bf16_grad_rel_err"]
+    assert d["batch1"]["value"] < d["batch2"]["value"] < d["batch3"]["value"] < d["value"] and d["batch3"]["batch_per_gpu"] == 3
+    assert 0 < d["eval_latency_ms"]["f16"] < 50 and d["dtype"] == "bf16"
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     # the step is the sum of its kernels: per-class totals of the instrumented pass (3 steps) against ms_per_step
@@ -78,9 +90,9 @@ def test_bench_cli_has_the_round4_flags():
     for w in ("dual256", "vit256", "clip_c4a", "clip_c4b", "clip_s1", "native_dual", "mrg_c5"):
         assert w in bench.GEOM
     src = open(os.path.join(ROOT, "bench.py")).read()
-    for flag in ("--scaling", "--global-batch", "--attn-logit-std", "--grad-wire", "--grad-algo", "--no-extras"):
+    for flag in ("--scaling", "--global-batch", "--attn-logit-std", "--grad-wire", "--grad-algo", "--no-extras", "--precision"):
         assert f'"{flag}"' in src, flag
-    for key in ('"attention"', '"optimizer_excluded"', '"peaky_attention"', '"f32_mode"', '"eval_forward"'):
+    for key in ('"attention"', '"optimizer_excluded"', '"peaky_attention"', '"f32_mode"', '"eval_forward"', '"f16_train"', '"eval_latency_ms"'):
         assert key in src, key
 
 
