@@ -4,13 +4,17 @@
 TEST INFRASTRUCTURE.  Reads /root/reference at run time (never copies from it):
   * multimodal_projector/spatial_pooling_projector.py is imported as-is;
   * multimodal_encoder/vit.py is imported with ``sys.modules`` stubs for ``monai`` (its two block classes
-    are bound to the oracle's restatement — MONAI 1.3.0 is absent, see ref_cpu.py header) and ``open_clip``.
+    are bound to the oracle's restatement — MONAI 1.3.0 is absent, see ref_cpu.py header) and ``open_clip``;
+  * (round 5) the CLIP wrappers LaMed.src.model.CLIP_stage1 / CLIP_stage2 are imported as the reference's own package and RUN (random-init
+    one-layer BERT in place of the absent pretrained weights; world size 1 and, in two gloo processes, world size 2); lamed_arch.py's
+    LamedMetaForCausalLM mixin over the reference's builders (one stand-in module for the out-of-scope segmentation builder); the CT
+    script's resize_array / nii_img_to_tensor on a synthetic scan.
 For each case the oracle restatement and the reference get the same seeded weights/inputs
 (``ref_cpu.seeded_state_dict`` / ``synthetic_*``), are asserted equal, and the REFERENCE's outputs
 (or a row subset + per-token norms for the big geometries) are written as fixtures.  Weights and
 inputs are NOT stored: tests regenerate them from the seeds recorded in each file.
 
-Usage:  python oracle/make_goldens.py [--skip-big] [--only grads]
+Usage:  python oracle/make_goldens.py [--skip-big] [--only grads | clip | mixin | prep]
 """
 from __future__ import annotations
 

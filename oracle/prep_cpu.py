@@ -2,10 +2,13 @@
 preprocessing chain, Data/data_processing/CT-RATE/CT-RATE_nii_to_3D_volume_npy_file.py:25-124, and of the train-time
 augmentation, LaMed/src/dataset/multi_dataset.py:148-158.
 
-Pinning: `resize_array` and the HU / min-max arithmetic are the reference's own torch calls restated line by line (the
-script itself is not importable here: it imports monai and nibabel at module scope, both absent).  MONAI's
-CropForeground / Resize / RandRotate90 / RandFlip / RandScaleIntensity / RandShiftIntensity are third-party
-(monai==1.3.0, not under /root/reference): restated from their published semantics -> parity unpinned for those steps."""
+Pinning (round 5): `resize_array` and `nii_img_to_tensor` are pinned by RUNNING the reference script's own functions in the build
+container (oracle/make_goldens.py --only prep: the script imported with empty stand-ins for the absent monai.transforms / nibabel, nib.load
+replaced by a synthetic scan, Tensor.to('cuda') mapped to the CPU for the call): bit-equal, fixture tests/golden/prep_ref.npz.  MONAI's
+CropForeground / Resize / RandRotate90 / RandFlip / RandScaleIntensity / RandShiftIntensity are third-party (monai==1.3.0, not under
+/root/reference): restated from their published semantics -> parity unpinned for those steps (the reference function takes its
+`transform` as an argument, so the pin above passes this file's crop + resize in).
+"""
 import numpy as np
 import torch
 import torch.nn.functional as F
