@@ -44,7 +44,7 @@ def test_default_batch_and_pmc_summary_are_consistent():
 
 
 def test_committed_bench_line_keeps_the_contract():
-    lines = sorted(glob.glob(os.path.join(ROOT, "profiles", "r05_bench_dual_batch53.json")))
+    lines = sorted(glob.glob(os.path.join(ROOT, "profiles", "r05_bench_dual_default.json")))
     assert lines, "the bench line of the default run is committed with the profiles"
     d = json.load(open(lines[-1]))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
