@@ -503,6 +503,57 @@ def build_mrg(geom, batch, dev, group, precision="bf16"):
     return _Step(), tower.vision_tower_stage1.patch_embedding, True
 
 
+def pcie_inclusive_rate(eng, needs_2d, vols, slices, dev, sync, steps):
+    """volumes/s when every step's volumes come from pinned host memory (the boundary a data loader hands over: fp32 (B,1,D,H,W) host
+    tensors, dataset/multi_dataset.py): double-buffered hipMemcpyAsync on a copy stream, the upload of step i + 1 beside the compute of
+    step i.  Also the bare host-to-device rate of one such upload."""
+    B = vols[0].shape[0]
+    host = [torch.empty(vols[0].shape, dtype=torch.float32).pin_memory() for _ in range(2)]
+    for h, v in zip(host, vols):
+        h.copy_(v)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    vols[0].copy_(host[0], non_blocking=True)
+    torch.cuda.synchronize()
+    h2d_gbs = host[0].numel() * 4 / (time.perf_counter() - t0) / 1e9
+    copy = torch.cuda.Stream(device=dev)
+    main = torch.cuda.current_stream()
+    ready = [torch.cuda.Event(), torch.cuda.Event()]
+    freed = [torch.cuda.Event(), torch.cuda.Event()]
+    for k in range(2):
+        freed[k].record(main)
+
+    def upload(k):
+        with torch.cuda.stream(copy):
+            copy.wait_event(freed[k])                  # the step that read buffer k has been enqueued and has consumed it
+            vols[k].copy_(host[k], non_blocking=True)
+            ready[k].record(copy)
+
+    def step(i):
+        k = i % 2
+        main.wait_event(ready[k])
+        if needs_2d:
+            eng.train_step(vols[k], slices[k])
+        else:
+            eng.train_step(vols[k])
+        freed[k].record(main)
+        upload(k)                                      # refill buffer k for step i + 2 while step i + 1 computes
+    upload(0), upload(1)
+    step(0), step(1)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(i)
+    sync()
+    dt = time.perf_counter() - t0
+    main.wait_event(ready[0]), main.wait_event(ready[1])
+    torch.cuda.synchronize()
+    return {"value": round(B * steps / dt, 3), "unit": "CT-volumes/sec", "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps,
+            "h2d_gbs": round(h2d_gbs, 1), "upload_mb_per_step": round(host[0].numel() * 4 / 1e6, 1),
+            "what": "the same step with every batch uploaded from pinned host memory (fp32 volumes, double-buffered copy stream beside the "
+                    "compute); `value` of the line is the HBM-resident number"}
+
+
 def timed_run(eng, needs_2d, vols, slices, steps, warmup, sync, optimizer=True):
     kw = {} if optimizer else {"optimizer": False}
 
@@ -798,6 +849,15 @@ def main():
                           for c in sorted(classes, key=lambda c: -c["total_ms"])]
 
     out.update(extras)
+
+    # ---- PCIe-inclusive rate: the volumes start in (pinned) HOST memory and are uploaded for every step --------------------------------------
+    if not a.no_extras and world == 1 and a.workload in ("dual256", "native_dual", "vit256"):
+        try:
+            extras_h2d = pcie_inclusive_rate(eng, needs_2d, vols, slices, dev, sync, max(3, min(a.steps, 5)))
+            if extras_h2d:
+                out["pcie_inclusive"] = extras_h2d
+        except RuntimeError as e:                  # (no pinned host memory to spare: report nothing rather than fail the bench)
+            print(f"[bench] pcie_inclusive leg skipped: {e}", file=sys.stderr, flush=True)
 
     # ---- the same step with fp16 operands (round 5): the mode whose outputs AND gradients sit inside ~1e-3 of the fp32 reference -----------
     if not a.no_extras and world == 1 and a.precision == "bf16" and a.workload in ("dual256", "native_dual", "vit256"):

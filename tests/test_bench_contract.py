@@ -92,7 +92,7 @@ def test_bench_cli_has_the_round4_flags():
     src = open(os.path.join(ROOT, "bench.py")).read()
     for flag in ("--scaling", "--global-batch", "--attn-logit-std", "--grad-wire", "--grad-algo", "--no-extras", "--precision"):
         assert f'"{flag}"' in src, flag
-    for key in ('"attention"', '"optimizer_excluded"', '"peaky_attention"', '"f32_mode"', '"eval_forward"', '"f16_train"', '"eval_latency_ms"'):
+    for key in ('"attention"', '"optimizer_excluded"', '"peaky_attention"', '"f32_mode"', '"eval_forward"', '"f16_train"', '"eval_latency_ms"', '"pcie_inclusive"'):
         assert key in src, key
 
 
