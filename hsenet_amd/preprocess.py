@@ -87,6 +87,28 @@ def nii_to_volume(raw: torch.Tensor, slope: float, intercept: float, z_spacing: 
     return resample(vol, out_size, (origin, size), sub=mn, den=float(den)).unsqueeze(0)
 
 
+def bimcv_nii_to_volume(raw: torch.Tensor, out_size: Sequence[int] = OUT_SIZE) -> torch.Tensor:
+    """The BIMCV-R variant of the chain (Data/data_processing/BIMCV_R/2. BIMCV_R_nii_to_3D_volume_npy_file.py:30-87): float32 voxels
+    (H, W, D) -> clamp [-1000, 200] -> (D, H, W) -> min-max -> CropForeground -> Resize, with NO rescale slope / intercept and NO
+    respacing.  Same kernels as nii_to_volume (HU window + transpose, min/max, bounding box, one crop-normalise-resize gather)."""
+    _need(raw)
+    if raw.dim() != 3 or raw.dtype not in (torch.float32, torch.float64):
+        raise L.HsError("bimcv_nii_to_volume expects the (H,W,D) voxel array as float32/float64")
+    raw = raw.float().contiguous()                                       # the script reads the scan as float32 (get_fdata(dtype=np.float32))
+    H, W, D = raw.shape
+    hu = torch.empty(D, H, W, dtype=torch.float64, device=raw.device)    # (float32 values held exactly; the gather below reads f64)
+    L.call("hs_prep_hu_window", raw.data_ptr(), 0, hu.data_ptr(), H, W, D, 1.0, 0.0, HU_MIN, HU_MAX, _s())
+    mm = minmax(hu.float()).cpu()
+    mn, mx = float(mm[0]), float(mm[1])
+    den = max(np.float32(mx) - np.float32(mn), np.float32(1e-8))
+    volf = hu.float()
+    box = foreground_bbox(volf, mn).cpu().tolist()
+    if box[3] < 0:
+        box = [0, 0, 0, D - 1, H - 1, W - 1]
+    origin, size = box[:3], [box[3 + a] - box[a] + 1 for a in range(3)]
+    return resample(volf, out_size, (origin, size), sub=mn, den=float(den)).unsqueeze(0)
+
+
 def draw_augmentation(rng: np.random.RandomState):
     """The random decisions of train_transform (multi_dataset.py:148-158), in its order: (rot_k, flip_mask, scale, shift)."""
     k = int(rng.randint(3) + 1) if rng.rand() < 0.5 else 0               # RandRotate90(prob=0.5, max_k=3)

@@ -52,6 +52,19 @@ def nii_img_to_tensor(img_data, slope, intercept, z_spacing, xy_spacing, out_siz
     return monai_resize(crop_foreground(norm), out_size)
 
 
+def bimcv_nii_to_tensor(img_data, out_size=(32, 256, 256)):
+    """Data/data_processing/BIMCV_R/2. BIMCV_R_nii_to_3D_volume_npy_file.py:30-87 (convert_nii_to_npy, the main path): the float32 voxel
+    array (H, W, D) -> clamp [-1000, 200] -> (D, H, W) -> min-max -> CropForeground -> Resize.  No rescale slope / intercept and no
+    respacing in this script.  Restated from the source text (the function needs a CUDA device object to exist before its first line of
+    arithmetic, and builds its MONAI transform internally); every step it shares with the CT-RATE function is pinned through that one."""
+    x = torch.tensor(np.asarray(img_data, dtype=np.float32), dtype=torch.float32)
+    x = torch.clamp(x, min=-1000, max=200)
+    tensor = x.permute(2, 0, 1).unsqueeze(0)
+    mn, mx = torch.min(tensor), torch.max(tensor)
+    norm = (tensor - mn) / torch.clamp(mx - mn, min=1e-8)
+    return monai_resize(crop_foreground(norm), out_size)
+
+
 def augment(image, k, flips, scale, shift):                                # multi_dataset.py:148-158 with the draws fixed
     x = torch.rot90(image, k, dims=(2, 3)) if k else image
     for bit, ax in ((1, 1), (2, 2), (4, 3)):

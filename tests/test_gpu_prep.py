@@ -38,6 +38,21 @@ def test_nii_to_volume_matches_reference_chain(dev, shape, zs, xys):
     assert got.min() >= 0 and got.max() <= 1
 
 
+@pytest.mark.parametrize("shape", [(48, 40, 30), (33, 47, 40)])
+@pytest.mark.gpu
+def test_bimcv_nii_to_volume_matches_reference_chain(dev, shape):
+    """the BIMCV-R variant (BIMCV_R/2. BIMCV_R_nii_to_3D_volume_npy_file.py:30-87): float32 voxels already in HU, no slope / intercept,
+    no respacing: clamp -> (D,H,W) -> min-max -> crop -> resize."""
+    from hsenet_amd import preprocess as P
+    from oracle import prep_cpu as R
+    raw = (synthetic_ct(shape, 9) - 1024.0).astype(np.float32)
+    ref = R.bimcv_nii_to_tensor(raw, out_size=(16, 64, 64))
+    got = P.bimcv_nii_to_volume(torch.from_numpy(raw).to(dev), out_size=(16, 64, 64)).cpu()
+    assert got.shape == ref.shape == (1, 16, 64, 64)
+    assert (got - ref).abs().max() < 2e-6, (got - ref).abs().max()
+    assert got.min() >= 0 and got.max() <= 1
+
+
 @pytest.mark.gpu
 def test_pieces(dev):
     from hsenet_amd import preprocess as P

@@ -466,3 +466,15 @@ def test_prep_oracle_equals_reference_script_fixture(golden):
     y = P.nii_img_to_tensor(raw, float(g["slope"]), float(g["intercept"]), float(g["z_spacing"]), float(g["xy_spacing"]),
                             tuple(int(v) for v in g["out_size"]))
     assert np.array_equal(y.numpy(), g["out"])
+
+
+def test_bimcv_chain_is_the_pinned_ct_chain_without_respacing():
+    """the BIMCV-R script's chain (restated from its source text) equals the CT-RATE chain -- pinned bit-equal against the reference
+    script run -- with slope 1, intercept 0 and the spacing already at the target (an identity trilinear resize): bit for bit."""
+    from oracle import prep_cpu as P
+    rng = np.random.default_rng(0)
+    raw = np.full((20, 24, 10), -1200.0, dtype=np.float32)
+    raw[3:15, 4:20, 2:8] = rng.uniform(-900, 700, size=(12, 16, 6)).astype(np.float32)
+    a = P.bimcv_nii_to_tensor(raw, (8, 16, 16))
+    b = P.nii_img_to_tensor(raw.astype(np.float64), 1.0, 0.0, 1.5, 0.75, (8, 16, 16))
+    assert a.shape == (1, 8, 16, 16) and torch.equal(a, b)
