@@ -181,6 +181,8 @@ __device__ __forceinline__ void epi_store(const GemmP& p, long idx, f32x4 v, u32
 
 // Tile configurations.  BIG: 256x256 block, 8 waves as 2(M) x 4(N), wave tile 128x64 (4x2 MFMA blocks, 32 MFMAs per
 // K-tile per wave), 2 stages x 64 KiB.  !BIG: 256x128 block, waves 4 x 2, wave tile 64x64, 3 stages x 48 KiB.
+// HALF (a flag of the !BIG NT kernel, round 5): 128x128 block, the same 4 x 2 waves on 32x64 wave tiles, its own main loop
+// (half_mainloop) and the !BIG epilogue on 32-row pieces.
 template <bool BIG> struct GCfg {
     static constexpr int MB = BIG ? 4 : 2;            // 32-row MFMA blocks per wave along M
     static constexpr int WAVES_N = BIG ? 4 : 2;
@@ -519,6 +521,85 @@ __device__ __forceinline__ void big_mainloop16(f32x4 (&acc)[8][4], char* smem, i
     }
 }
 
+// ---- main loop of the 128x128 tile (HALF, NT): 8 waves as 4(M) x 2(N) on 32x64 wave tiles, FIVE 32-KiB stages ------------
+// For launches whose 256x128 tiles would leave more than half of the CUs idle (hs_gemm: the N = 768 outputs at one volume per GPU,
+// 102 tiles on 256 CUs).  Half the MFMA work per K-tile and wave (8 MFMAs) means half the time to hide a K-tile's load latency
+// in: the ring is five stages deep (A 16 KiB + B 16 KiB each = all 160 KiB; the LDS-staged epilogue reuses it), i.e. four K-tiles
+// of prefetch distance, and the pipeline is big_mainloop's -- asm-issued fragment reads one k-step ahead with counted lgkmcnt, the
+// tile barrier between k-steps 2 and 3, k-step 3 reading the next tile's first fragments; the tile NS ahead is issued into the stage
+// that barrier has just freed.  Waits: loads retire in issue order, each tile is 4 pieces per wave, so "tile t+1 has landed" is
+// vmcnt(4 x tiles issued after it).  Same k order per output element as every other tile shape: bit-identical results.
+template <int CNT>
+__device__ __forceinline__ void lds_wait3(u32x4& a, u32x4& b, u32x4& c) { asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "i"(CNT) : "memory"); }
+__device__ __forceinline__ void vm_wait_tiles4(int newer) {            // at most 4 * newer vector-memory operations still outstanding
+    if (newer >= 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (newer == 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (newer == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (newer == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+template <bool F16 = false>
+__device__ __forceinline__ void half_mainloop(f32x16 (&acc)[2], char* smem, int row0, int col0, int wave, int lane,
+                                              __amdgpu_buffer_rsrc_t rsA, __amdgpu_buffer_rsrc_t rsB, const unsigned (&va)[4],
+                                              const unsigned (&vb)[2], int kt0, int kt1) {
+    constexpr unsigned ST = 32768u, BOFF = 16384u;
+    constexpr int NS = 5;
+    const int h = lane >> 5, c = lane & 31;
+    unsigned ab0[4], bb0[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        ab0[ks] = lds_off(smem) + offR(row0 + c, 2 * ks + h);
+        bb0[ks] = lds_off(smem) + BOFF + offR(col0 + c, 2 * ks + h);
+    }
+    u32x4 fa[2], fb[2][2];
+    auto rd = [&](auto set_tag, auto ks_tag, unsigned so) {
+        constexpr int S = decltype(set_tag)::value, KS = decltype(ks_tag)::value;
+        ldsr128<0>(fa[S], ab0[KS] + so);
+        ldsr128<0>(fb[S][0], bb0[KS] + so);
+        ldsr128<4096>(fb[S][1], bb0[KS] + so);
+    };
+    auto settle = [&](auto set_tag, auto cnt_tag) {
+        constexpr int S = decltype(set_tag)::value, CNT = decltype(cnt_tag)::value;
+        lds_wait3<CNT>(fa[S], fb[S][0], fb[S][1]);
+    };
+    auto mma = [&](auto set_tag) {
+        constexpr int S = decltype(set_tag)::value;
+        acc[0] = mfma32<F16>(as_frag(fa[S]), as_frag(fb[S][0]), acc[0]);
+        acc[1] = mfma32<F16>(as_frag(fa[S]), as_frag(fb[S][1]), acc[1]);
+    };
+    auto dma = [&](int kt, unsigned so) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) dma_piece(rsA, smem + so, q, wave, va[q], (unsigned)kt * 128u);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) dma_piece(rsB, smem + so + BOFF, q, wave, vb[q], (unsigned)kt * 128u);
+    };
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 1> I1;
+    typedef std::integral_constant<int, 2> I2;
+    typedef std::integral_constant<int, 3> I3;
+#pragma unroll
+    for (int i = 0; i < NS; ++i)
+        if (kt0 + i < kt1) dma(kt0 + i, (unsigned)i * ST);
+    vm_wait_tiles4(min(NS - 1, kt1 - 1 - kt0));
+    __builtin_amdgcn_s_barrier();
+    rd(I0{}, I0{}, 0u);
+    unsigned so = 0;
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const bool has1 = kt + 1 < kt1;
+        const unsigned so1 = so == (NS - 1) * ST ? 0u : so + ST;
+        rd(I1{}, I1{}, so); settle(I0{}, I3{}); mma(I0{});
+        rd(I0{}, I2{}, so); settle(I1{}, I3{}); mma(I1{});
+        rd(I1{}, I3{}, so); settle(I0{}, I3{}); mma(I0{});
+        settle(I1{}, I0{});                                  // lgkmcnt(0): every read of this stage has landed
+        vm_wait_tiles4(has1 ? min(NS - 2, kt1 - 2 - kt) : 0);  // tile kt+1 landed; up to three younger tiles stay in flight
+        __builtin_amdgcn_s_barrier();
+        if (has1) rd(I0{}, I0{}, so1);
+        mma(I1{});
+        if (kt + NS < kt1) dma(kt + NS, so);                 // this tile's stage: free since the barrier
+        so = so1;
+    }
+}
+
 // diagnostic (dbg == 4): per-phase cycle sums of the epilogue, wave 0 lane 0 of every block (tools/kbench)
 extern "C" void hs_debug_gemm_stamps(unsigned long long* out, int reset) {
     if (out) (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gemm_stamps), sizeof(g_gemm_stamps));
@@ -741,15 +822,18 @@ static_assert(EF >= 0, "the 16x16x32 kernels are launched with compile-time epil
 // conditions): the flag tests fold away.  Run-time flags (EF = -1) cost ~1500 cycles of branches per epilogue step --
 // 24k cycles per 256x256 tile, more than half of a K = 768 main loop.
 // (the body is shared by the one-problem kernel and the grouped one: b = this block's index among the nb blocks of problem p)
-template <bool ATR, bool BTR, bool BIG, int EF, bool M16 = false, bool F16 = false>
+template <bool ATR, bool BTR, bool BIG, int EF, bool M16 = false, bool F16 = false, bool HALF = false>
 __device__ __forceinline__ void gemm_bf16_body(const GemmP& p, const int b_, const int nb_) {
     static_assert(!M16 || (BIG && !ATR && !BTR), "the 16x16x32 main loop exists for the 256x256 NT tile");
+    static_assert(!HALF || (!BIG && !ATR && !BTR && !M16), "the 128x128 tile exists for the NT layout");
     typedef GCfg<BIG> C;
-    __shared__ __attribute__((aligned(16))) char smem[M16 ? 163840 : C::SMEM];     // (16x16x32 kernels: 3 A + 2 B stages, no epilogue staging)
+    __shared__ __attribute__((aligned(16))) char smem[(M16 || HALF) ? 163840 : C::SMEM];     // (16x16x32 kernels: 3 A + 2 B stages, no epilogue staging; HALF: 5 stages)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = BIG ? wave >> 2 : wave >> 1, wn = BIG ? wave & 3 : wave & 1;
-    const int row0 = wm * (C::MB * 32), col0 = wn * 64;        // this wave's tile inside the block tile
+    const int row0 = wm * (HALF ? 32 : C::MB * 32), col0 = wn * 64;        // this wave's tile inside the block tile
+    constexpr int TM = HALF ? 128 : 256;                       // block tile height
+    constexpr int WROWS = HALF ? 32 : 64;                      // rows of one staged epilogue piece
     // XCD-aware tile order.  A CU can pull only ~13 B/clk from beyond its XCD's L2 (a lone block needs ~3000 cycles
     // per K-tile), so speed hinges on the ~32 blocks an XCD runs at once SHARING operand tiles out of that L2.
     // Blocks are dealt round-robin over the 8 XCDs (b % 8 labels the blocks sharing an L2): give each XCD a
@@ -758,7 +842,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmP& p, const int b_, con
     // all column tiles, column-major inside a group (GM small: see hs_gemm).  Placement only affects speed, never results.
     int tm, tn, z;
     tile_order(b_, nb_, p.tiles_m, p.tiles_n, tm, tn, z, p.gm, p.np);
-    const int m0 = tm * 256, n0 = tn * C::BN;
+    const int m0 = tm * TM, n0 = tn * C::BN;
     const int bz = p.split_k > 1 ? 0 : z;
     const bf16_t* A = (const bf16_t*)p.A + bz * p.sA;
     const bf16_t* B = (const bf16_t*)p.B + bz * p.sB;
@@ -820,6 +904,8 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmP& p, const int b_, con
         big_mainloop16<F16>(acc16, smem, row0, col0, wave, lane, rsA, rsB, va, vb, ka, kb, kt0, kt1);
     } else if constexpr (BIG) {
         big_mainloop<BTR, F16>(acc, smem, row0, col0, wave, lane, rsA, rsB, va, vb, ka, kb, kt0, kt1, HS_DBG(p.dbg_));
+    } else if constexpr (HALF) {
+        half_mainloop<F16>(acc[0], smem, row0, col0, wave, lane, rsA, rsB, va, vb, kt0, kt1);      // (K % 64 == 0: hs_gemm)
     } else {
     // ring: prefetch distance D = NSTAGE-1 tiles.  At step kt: wait until tile kt has landed (D-1 newer tiles may stay
     // in flight: counted vmcnt), barrier, then issue tile kt+D into the stage every wave finished reading before
@@ -879,7 +965,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmP& p, const int b_, con
 #pragma unroll
     for (int half = 0; half < C::MB / 2; ++half) {
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb)
+        for (int mb = 0; mb < (HALF ? 1 : 2); ++mb)
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
@@ -892,7 +978,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmP& p, const int b_, con
         if (flags & HS_EPI_ATOMIC) {
             // one float per lane: every atomic wave-instruction is 256 contiguous bytes of one row
             const int n = nw + lane;
-            for (int row = 0; row < 64; ++row) {
+            for (int row = 0; row < WROWS; ++row) {
                 const int m = mw + row;
                 if (m < p.M && n < p.N) atomicAdd(p.out_f32 + cz + (long)m * p.ldc + n, my[row * G_EPI_LD + lane] * p.alpha);
             }
@@ -915,7 +1001,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmP& p, const int b_, con
                 // groups of GS steps: all loads in flight -> all math -> all stores (see epi_math).  The 256x256 tile still holds
                 // 64-128 accumulator registers here: smaller groups keep the epilogue out of scratch (a reload is a memory round trip)
 #pragma unroll 1
-                for (int g = 0; g < 8 / GS; ++g) {
+                for (int g = 0; g < WROWS / 8 / GS; ++g) {
                     f32x4 vlo[GS], vhi[GS];
                     u32x4 zb[GS];
                     bool in[GS];
@@ -988,7 +1074,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmP& p, const int b_, con
                 if ((flags & HS_EPI_BIAS) && !(flags & HS_EPI_BIAS_M) && nw + cc + 3 < p.N) bias_n = *(const f32x4*)(p.bias + nw + cc);
                 // groups of 8 steps: 8+8 loads in flight -> all math -> all stores (see epi_math)
 #pragma unroll 1
-                for (int g = 0; g < 2; ++g) {
+                for (int g = 0; g < WROWS / 32; ++g) {
                     f32x4 val[8];
                     u32x2 zbv[8];
                     bool in[8];
@@ -1018,7 +1104,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmP& p, const int b_, con
                 }
             } else {   // rare path (N or ldc not a multiple of 4): element-wise, rolled
 #pragma unroll 1
-                for (int step = 0; step < 16; ++step) {
+                for (int step = 0; step < WROWS / 4; ++step) {
                     const int row = step * 4 + rr;
                     const f32x4 v = *(const f32x4*)(my + row * G_EPI_LD + cc);
 #pragma unroll 1
@@ -1047,9 +1133,9 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmP& p, const int b_, con
     TRACE(2);
 }
 
-template <bool ATR, bool BTR, bool BIG, int EF, bool M16 = false, bool F16 = false>
+template <bool ATR, bool BTR, bool BIG, int EF, bool M16 = false, bool F16 = false, bool HALF = false>
 __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmP p) {
-    gemm_bf16_body<ATR, BTR, BIG, EF, M16, F16>(p, blockIdx.x, gridDim.x);
+    gemm_bf16_body<ATR, BTR, BIG, EF, M16, F16, HALF>(p, blockIdx.x, gridDim.x);
 }
 
 // Persistent form of the 16x16x32 NT kernel (round 4; the default whenever a launch has more tiles than CUs): ONE block per CU walks the
@@ -1250,13 +1336,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmP p) {
 namespace {
 struct GemmEnv {
     bool no_nt, no_m16;
-    char tile;      // 0, 'b' (big) or 's' (small)
+    char tile;      // 0, 'b' (big), 's' (small: never the 128x128 form) or 'h' (128x128 wherever it exists)
     int gm;         // 0, or the tile order's group height
     int np;         // 0, or the tile order's panel width (column tiles)
     int persist;    // 16x16x32 NT kernels as persistent blocks (0 / 1), HS_GEMM_PERSIST
     GemmEnv() : no_nt(getenv("HS_GEMM_NO_NT") != nullptr), no_m16(getenv("HS_GEMM_NO_M16") != nullptr), tile(0) {
         const char* t = getenv("HS_GEMM_TILE");
-        if (t && (t[0] == 'b' || t[0] == 's')) tile = t[0];
+        if (t && (t[0] == 'b' || t[0] == 's' || t[0] == 'h')) tile = t[0];
         gm = getenv("HS_GEMM_GM") ? atoi(getenv("HS_GEMM_GM")) : 0;
         np = getenv("HS_GEMM_NP") ? atoi(getenv("HS_GEMM_NP")) : 0;
         persist = getenv("HS_GEMM_PERSIST") ? atoi(getenv("HS_GEMM_PERSIST")) : 1;      // default on (round 4); 0 = one tile per block, for A/B runs
@@ -1267,7 +1353,7 @@ const GemmEnv kEnv;
 
 // kernel selection of the 16-bit GEMMs, once per operand format (H = false: bf16, the training policy; H = true: IEEE fp16 -- since round 5
 // every layout and epilogue, i.e. forward AND backward: same kernels, fp16 packs and the fp16 MFMA opcode)
-struct Launch16 { int layout, f; bool big, col8, m16_ok, persist; int pgrid; };
+struct Launch16 { int layout, f; bool big, col8, m16_ok, persist; int pgrid; bool half; };
 template <bool H>
 static void launch16(const GemmP& p, const Launch16& c, dim3 grid, hipStream_t s) {
     const int f = c.f;
@@ -1281,7 +1367,12 @@ static void launch16(const GemmP& p, const Launch16& c, dim3 grid, hipStream_t s
         if (c.persist) hipLaunchKernelGGL((gemm_nt16_persist_kernel<EF, H>), dim3(c.pgrid), dim3(512), 0, s, p);      \
         else hipLaunchKernelGGL((gemm_bf16_kernel<false, false, true, EF, true, H>), grid, dim3(512), 0, s, p);       \
     } while (0)
-    if (c.m16_ok) {
+#define HS_LAUNCH_H(EF) hipLaunchKernelGGL((gemm_bf16_kernel<false, false, false, EF, false, H, true>), grid, dim3(512), 0, s, p)
+    if (c.half) {                                                  // (NT, 128x128 tiles: hs_gemm)
+        if (c.col8 && f == 0) HS_LAUNCH_H(0);
+        else if (c.col8 && f == (HS_EPI_BIAS | HS_EPI_RESID)) HS_LAUNCH_H(HS_EPI_BIAS | HS_EPI_RESID);
+        else HS_LAUNCH_H(-1);
+    } else if (c.m16_ok) {
         if (f == 0) HS_LAUNCH_M16(0);
         else if (f == HS_EPI_BIAS) HS_LAUNCH_M16(HS_EPI_BIAS);        // patch embedding, scorer / packer projections (fp32 out)
         else if (f == (HS_EPI_BIAS | HS_EPI_RESID)) HS_LAUNCH_M16(HS_EPI_BIAS | HS_EPI_RESID);
@@ -1303,6 +1394,7 @@ static void launch16(const GemmP& p, const Launch16& c, dim3 grid, hipStream_t s
     }
 #undef HS_LAUNCH_E
 #undef HS_LAUNCH_M16
+#undef HS_LAUNCH_H
 }
 
 extern "C" int hs_gemm_group(const hs_gemm_args* args, int count, void* stream) { return hs_gemm_group_prec(args, count, HS_PREC_BF16, stream); }
@@ -1403,6 +1495,10 @@ extern "C" int hs_gemm(const hs_gemm_args* a, int prec, void* stream) {
         // (kEnv.tile: 'b' / 's' force the NT / NN tile for A/B runs; the TN kernel only exists with the 256x128 tile)
         const bool big = !(a->K & 63) && a->layout != HS_GEMM_TN && (kEnv.tile ? kEnv.tile == 'b' : 2 * big_blocks > ncu);
         p.tiles_n = (a->N + (big ? 255 : 127)) / (big ? 256 : 128);
+        // 128x128 tiles when the 256x128 ones would fill at most half of the CUs (the N = 768 outputs at 4097 rows: 102 -> 198 blocks):
+        // one round of the chip either way, half the main loop per block
+        const bool half = !big && a->layout == HS_GEMM_NT && !(a->K & 63) && (kEnv.tile ? kEnv.tile == 'h' : 2l * p.tiles_m * p.tiles_n * zdim <= ncu);
+        if (half) p.tiles_m = (a->M + 127) / 128;
         // group height of the tile order: the column tiles that share an A row panel must run AT THE SAME TIME (they then pull
         // each A K-tile into the XCD's L2 once); with few column tiles a tall group puts the sharers 16-32 dispatch slots apart and
         // the N = 768 / K = 3072 shapes re-read their 1.5-MiB A panels (measured, tools/gm_sweep.sh at M = 81940: fc2 417 -> 380 us,
@@ -1427,7 +1523,7 @@ extern "C" int hs_gemm(const hs_gemm_args* a, int prec, void* stream) {
                          : f == (HS_EPI_BIAS | HS_EPI_RESID) ? HS_PROF_GEMM_NT16_RESID
                          : f == (HS_EPI_GELU_BWD | HS_EPI_SAVE_DGELU) ? HS_PROF_GEMM_NT16_DGELU : HS_PROF_GEMM_NT16_GELU;
         ProfScope prof(pclass, stream, 2.0 * mnk, prof_bytes);
-        const Launch16 ln = {a->layout, f, big, col8, m16_ok, persist, pgrid};
+        const Launch16 ln = {a->layout, f, big, col8, m16_ok, persist, pgrid, half};
         if (h16) launch16<true>(p, ln, grid, s);
         else launch16<false>(p, ln, grid, s);
     } else {

@@ -141,3 +141,47 @@ def test_dgelu_column_sums_ignore_rows_outside_the_matrix(dev):
     assert rel(o16[1:].float(), want[1:]) < 4e-3
     # columns 16.. : row 0's aux is finite there -> exact column sums; columns 0..15 hold row 0's own NaN / Inf and nothing else is expected
     assert torch.isfinite(cs[16:]).all() and rel(cs[16:], want[:, 16:].sum(0)) < 1e-4
+
+
+HALF_SHAPES = [(4097, 768, 768), (4097, 768, 3072), (4097, 768, 2304), (130, 136, 64), (1, 8, 64), (129, 776, 128), (640, 264, 192), (2049, 768, 768)]
+
+
+@pytest.mark.parametrize("prec", ["bf16", "f16"])
+@pytest.mark.parametrize("fs", ["none", "bias_resid", "bias", "dgelu_colsum"])
+def test_gemm_half_tile_shapes(dev, prec, fs):
+    """The 128x128 tile of the NT kernel (gemm.hip half_mainloop; hs_gemm picks it when K % 64 == 0 and the 256x128 tiles would fill at
+    most half of the CUs — every shape here, among them the encoder layer's N = 768 outputs at one 256³ / native volume per GPU): its
+    three instantiations (plain, bias + residual, generic epilogue), ragged M / N, one K-tile, fewer K-tiles than ring stages, both
+    16-bit operand formats; against an fp64 statement."""
+    from hsenet_amd import functional as Fn, _lib as L
+    P = L.PREC_BF16 if prec == "bf16" else L.PREC_F16
+    dt = torch.bfloat16 if prec == "bf16" else torch.float16
+    tol16 = 4e-3 if prec == "bf16" else 6e-4
+    for i, (M, N, K) in enumerate(HALF_SHAPES):
+        g = torch.Generator().manual_seed(900 + i)
+        a = torch.randn(M, K, generator=g).to(dt)
+        b = (torch.randn(N, K, generator=g) * (0.05 if prec == "f16" else 1.0)).to(dt)
+        acc = a.double() @ b.double().t()
+        A, Bm = a.to(dev), b.to(dev)
+        bias = torch.randn(N, generator=g).to(dev)
+        resid = torch.randn(M, N, generator=g).to(dev)
+        aux = (0.3 * torch.randn(M, N, generator=g)).to(dt).to(dev)
+        tag = f"{prec} {fs}: M={M} N={N} K={K}"
+        o32 = torch.full((M, N), float("nan"), device=dev)
+        o16 = torch.full((M, N), float("nan"), dtype=dt, device=dev)
+        if fs == "none":
+            Fn.gemm(A, Bm, L.GEMM_NT, prec=P, out_bf16=o16, alpha=0.5)
+            assert rel(o16.float(), 0.5 * acc) < tol16, tag
+        elif fs == "bias":
+            Fn.gemm(A, Bm, L.GEMM_NT, prec=P, out_f32=o32, bias=bias, flags=L.EPI_BIAS)
+            assert rel(o32, acc + bias.double().cpu()) < 1e-5, tag
+        elif fs == "bias_resid":
+            Fn.gemm(A, Bm, L.GEMM_NT, prec=P, out_f32=o32, bias=bias, resid=resid, flags=L.EPI_BIAS | L.EPI_RESID)
+            assert rel(o32, acc + bias.double().cpu() + resid.double().cpu()) < 1e-5, tag
+        else:
+            cs = torch.zeros(N, device=dev)
+            Fn.gemm(A, Bm, L.GEMM_NT, prec=P, out_bf16=o16, aux=aux, flags=L.EPI_GELU_BWD | L.EPI_SAVE_DGELU, colsum_out=cs)
+            want = acc * aux.double().cpu()
+            assert rel(o16.float(), want) < tol16, tag
+            assert rel(cs, want.sum(0)) < 1e-4, tag
+    torch.cuda.synchronize()
