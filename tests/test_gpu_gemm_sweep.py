@@ -185,3 +185,39 @@ def test_gemm_half_tile_shapes(dev, prec, fs):
             assert rel(o16.float(), want) < tol16, tag
             assert rel(cs, want.sum(0)) < 1e-4, tag
     torch.cuda.synchronize()
+
+
+_TILE_PROBE = r"""
+import hashlib, torch
+from hsenet_amd import functional as Fn, _lib as L
+dev = torch.device("cuda:0")
+h = hashlib.sha256()
+for i, (M, N, K) in enumerate([(4097, 768, 768), (4097, 768, 3072), (129, 776, 128)]):
+    g = torch.Generator().manual_seed(4200 + i)
+    a = torch.randn(M, K, generator=g).bfloat16().to(dev)
+    b = torch.randn(N, K, generator=g).bfloat16().to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    resid = torch.randn(M, N, generator=g).to(dev)
+    o32 = torch.empty(M, N, device=dev)
+    o16 = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    Fn.gemm(a, b, L.GEMM_NT, prec=L.PREC_BF16, out_f32=o32, bias=bias, resid=resid, flags=L.EPI_BIAS | L.EPI_RESID)
+    Fn.gemm(a, b, L.GEMM_NT, prec=L.PREC_BF16, out_bf16=o16)
+    torch.cuda.synchronize()
+    h.update(o32.cpu().numpy().tobytes()); h.update(o16.view(torch.int16).cpu().numpy().tobytes())
+print("TILE_PROBE", h.hexdigest())
+"""
+
+
+def test_half_tile_is_bit_identical_to_the_256x128_tile(dev):
+    """gemm.hip claims that the tile shape never changes a result (every output element accumulates its k-steps in the same order with the
+    same MFMA): the same seeded products in two child processes, one forced to the 256x128 tile (HS_GEMM_TILE=s, read once at library
+    load), one to the 128x128 tile (=h), must hash equal."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = []
+    for tile in ("s", "h"):
+        env = dict(os.environ, HS_GEMM_TILE=tile, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        out = subprocess.run([sys.executable, "-c", _TILE_PROBE], env=env, capture_output=True, text=True, timeout=300, cwd=root)
+        assert out.returncode == 0, out.stderr[-2000:]
+        digests.append([ln.split()[1] for ln in out.stdout.splitlines() if ln.startswith("TILE_PROBE")][0])
+    assert digests[0] == digests[1]
