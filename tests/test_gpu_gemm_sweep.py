@@ -147,7 +147,7 @@ HALF_SHAPES = [(4097, 768, 768), (4097, 768, 3072), (4097, 768, 2304), (130, 136
 
 
 @pytest.mark.parametrize("prec", ["bf16", "f16"])
-@pytest.mark.parametrize("fs", ["none", "bias_resid", "bias", "dgelu_colsum"])
+@pytest.mark.parametrize("fs", ["none", "bias_resid", "bias", "dgelu_colsum", "atomic_split"])
 def test_gemm_half_tile_shapes(dev, prec, fs):
     """The 128x128 tile of the NT kernel (gemm.hip half_mainloop; hs_gemm picks it when K % 64 == 0 and the 256x128 tiles would fill at
     most half of the CUs — every shape here, among them the encoder layer's N = 768 outputs at one 256³ / native volume per GPU): its
@@ -178,6 +178,10 @@ def test_gemm_half_tile_shapes(dev, prec, fs):
         elif fs == "bias_resid":
             Fn.gemm(A, Bm, L.GEMM_NT, prec=P, out_f32=o32, bias=bias, resid=resid, flags=L.EPI_BIAS | L.EPI_RESID)
             assert rel(o32, acc + bias.double().cpu() + resid.double().cpu()) < 1e-5, tag
+        elif fs == "atomic_split":          # split-K slices of the 128x128 tile accumulating with float atomics (K-tile ranges kt0..kt1 of the ring)
+            o32.zero_()
+            Fn.gemm(A, Bm, L.GEMM_NT, prec=P, out_f32=o32, flags=L.EPI_ATOMIC, split_k=min(3, K // 64))
+            assert rel(o32, acc) < 1e-5, tag
         else:
             cs = torch.zeros(N, device=dev)
             Fn.gemm(A, Bm, L.GEMM_NT, prec=P, out_bf16=o16, aux=aux, flags=L.EPI_GELU_BWD | L.EPI_SAVE_DGELU, colsum_out=cs)
