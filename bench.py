@@ -100,7 +100,7 @@ def measured_pmc(kernel, batch, workload, build_id=None):
     executing.  The counters cannot be collected inside the timed run (counter collection serialises kernels), so they are tied to
     the library instead: with `build_id` given, a summary whose `_build_id` differs from the loaded library's is NOT used
     (-> {"stale": file}).  {} when nothing is committed for this kernel / batch / workload."""
-    for name in ("r05_pmc.json", "r04_pmc.json", "r03_pmc.json"):
+    for name in ("r06_pmc.json", "r05_pmc.json", "r04_pmc.json", "r03_pmc.json"):
         try:
             allk = json.load(open(os.path.join(ROOT, "profiles", name)))
             e = allk.get(kernel)
@@ -113,8 +113,11 @@ def measured_pmc(kernel, batch, workload, build_id=None):
     return {}
 
 
-def attention_aggregate(classes):
-    """credited TFLOP/s over attention forward + backward (forward 4 N^2 d, backward 8 N^2 d per (batch, head, layer))."""
+def attention_aggregate(classes, prefix="attn_"):
+    """credited TFLOP/s over attention forward + backward (SURVEY 8(d): forward 4 N^2 d, backward 8 N^2 d per (batch, head, layer));
+    prefix "attn_fwd": the forward alone (the optimistic kernel + its fix-up pass) -- the north-star's ">= 40 % on the 3D-ViT attention"
+    holds for the forward and not for forward + backward, and the line says so with both figures."""
+    classes = [c for c in classes if c["name"].startswith(prefix)]
     att = [c for c in classes if c["name"].startswith("attn_") and c["flops"]]
     if not att:
         return None
@@ -407,7 +410,9 @@ def cpu_baseline(workload, geom, cap_seconds=150.0):
     step()                                           # warm-up (allocator, thread pool, first-touch)
     warm = time.perf_counter() - t0
     print(f"[bench] cpu_baseline: warm-up iteration {warm:.1f} s", file=sys.stderr, flush=True)
-    n = max(1, min(3, int((cap_seconds - warm) // max(warm, 1e-3))))
+    # bounded sample: one volume is ~25 s of CPU work on 16 cores -- ONE timed iteration after the warm-up then (a median of 3 only when
+    # an iteration is short), so that the default run stays inside a few minutes
+    n = 1 if warm > 10.0 else max(1, min(3, int((cap_seconds - warm) // max(warm, 1e-3))))
     times = []
     for _ in range(n):
         for m in mods:
@@ -572,31 +577,51 @@ def timed_run(eng, needs_2d, vols, slices, steps, warmup, sync, optimizer=True):
     return time.perf_counter() - t0, step
 
 
+def visible_gpus():
+    """GPUs this process could use, counted WITHOUT initialising the GPU runtime (the N ranks are started from this process: it must not
+    hold a GPU context): KFD topology nodes with SIMDs, narrowed by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES;
+    torch.cuda.device_count() (which does not initialise the GPU on this image's amdsmi path) only when the topology is unreadable."""
+    n = None
+    try:
+        root = "/sys/class/kfd/kfd/topology/nodes"
+        n = 0
+        for node in os.listdir(root):
+            for line in open(os.path.join(root, node, "properties")):
+                k, _, v = line.partition(" ")
+                if k == "simd_count" and int(v) > 0:
+                    n += 1
+    except Exception:
+        n = None
+    if not n:
+        return torch.cuda.device_count()
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def launch_ranks(n, argv):
     """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment: start the N ranks here, as the reference's launcher does
     (script/train_clip_stage1.sh:4 `accelerate launch`, README.md:78-105: 8 processes), and exit with their status.  Called BEFORE anything
-    in this process touches the GPU (torch.cuda.device_count() does not initialise it on this image); the ranks are fresh children of
-    `python -m torch.distributed.run`, never a re-exec of this process.  Refuses (exit 2) when fewer than N devices are visible -- unless
-    HS_BENCH_BACKEND=gloo asks for the one-GPU rehearsal of the N-rank control flow."""
-    import socket
+    in this process touches the GPU; the ranks are fresh children of `python -m torch.distributed.run --standalone` (which picks its own
+    free rendezvous port: no bind-then-close race between concurrent benches), never a re-exec of this process.  Refuses (exit 2) when
+    fewer than N devices are visible -- unless HS_BENCH_BACKEND=gloo asks for the one-GPU rehearsal of the N-rank control flow."""
     import subprocess
-    have = torch.cuda.device_count()
+    have = visible_gpus()
     if have < n and os.environ.get("HS_BENCH_BACKEND", "nccl") == "nccl":
         sys.stderr.write(f"bench.py: --gpus {n} but only {have} GPU(s) are visible; not printing a line for a different world size\n")
         return 2
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", f"--nproc-per-node={n}",
+           os.path.abspath(__file__)] + list(argv)
     print(f"[bench] starting {n} ranks: {' '.join(cmd[1:8])} bench.py ...", file=sys.stderr, flush=True)
     return subprocess.run(cmd, env=env).returncode
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks = GPUs (default: WORLD_SIZE when a launcher set it, else 1)")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=None, help=f"volumes per GPU per step (default: {DEFAULT_BATCH}; clip_c4a / mrg_c5: 1 = global batch 8 on 8 GPUs)")
@@ -606,6 +631,7 @@ def main():
     ap.add_argument("--recompute-mlp", action="store_true", help="dual256 / native_dual: do not keep the MLP activations (46 %% of the saved "
                     "activation bytes), re-run fc1 + GELU per layer in the backward; config.recompute says so (NOT the default headline)")
     ap.add_argument("--no-batch1", action="store_true")
+    ap.add_argument("--no-module-api", action="store_true", help="skip the module_api_train leg (the drop-in train step beside the engine's)")
     ap.add_argument("--no-extras", action="store_true", help="skip the optimizer_excluded / peaky_attention / f32_mode / eval_forward legs")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: --batch volumes on EVERY GPU; strong: --global-batch volumes in total, split over the GPUs")
@@ -619,6 +645,8 @@ def main():
     ap.add_argument("--attn-logit-std", type=float, default=None, help="scale the q rows of the qkv weights so that the scaled attention "
                     "logits have this standard deviation (random init: 0.31)")
     a = ap.parse_args()
+    if a.gpus is None:
+        a.gpus = int(os.environ.get("WORLD_SIZE", "1"))
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
         sys.exit(launch_ranks(a.gpus, sys.argv[1:]))
     if int(os.environ.get("WORLD_SIZE", "1")) != a.gpus:
@@ -758,7 +786,7 @@ def main():
                          avg_launch_us=round(dom["avg_us"], 2), flops_per_launch=dom["flops"] / dom["launches"])
             if pmc.get("stale"):
                 roof_["traffic_note"] = (f"{pmc['stale']} was collected with library build {pmc['build_id']}, this run loaded {L.build_id()}: "
-                                         "its counters are not reported (re-run tools/r5_profiles.sh)")
+                                         "its counters are not reported (re-run tools/r6_profiles.sh)")
             elif pmc:
                 roof_["traffic_source"], roof_["traffic_build_id"] = pmc["source"], pmc["build_id"]
                 if pmc.get("mfma_busy_frac") is not None:
@@ -787,6 +815,28 @@ def main():
             dtn = float(t.item())
         extras["optimizer_excluded"] = {"value": round(world * a.batch * k / dtn, 3), "unit": "CT-volumes/sec", "ms_per_step": round(1e3 * dtn / k, 3),
                                         "steps": k, "what": "forward + backward + gradient all-reduce, no AdamW / clip pass"}
+        if world > 1 and hasattr(eng, "buckets"):
+            # what the gradient exchange costs THIS step: the same forward + backward with the collectives muted (no optimizer pass in
+            # either, so the replicas stay identical), timed the same way -- the difference is the communication the backward did not hide
+            bk = eng.buckets
+            muted_engines = [eng] + ([eng.s1] if getattr(eng, "s1", None) is not None else [])
+            for e_ in muted_engines:
+                e_.buckets.muted = True
+            try:
+                dtm = timed_run(eng, needs_2d, vols, slices, k, 1, sync, optimizer=False)[0]
+            finally:
+                for e_ in muted_engines:
+                    e_.buckets.muted = False
+            t = torch.tensor([dtm], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dtm = float(t.item())
+            wire = 2 if bk.wire == "bf16" else 4
+            extras["comm"] = {"comm_bytes_per_step": int(sum((b_ - a_) * wire for e_ in muted_engines for a_, b_ in e_.buckets.bounds)),
+                              "buckets": sum(len(e_.buckets.bounds) for e_ in muted_engines), "wire": bk.wire, "algo": bk.algo,
+                              "comm_ms_exposed": round(1e3 * (dtn - dtm) / k, 3), "ms_per_step_muted": round(1e3 * dtm / k, 3),
+                              "what": "gradient bytes each rank puts on the wire per step (flat fp32 gradient in backward-completion-order "
+                                      "buckets) and the part of their exchange the backward did not hide: (fwd + bwd + exchange) - (fwd + bwd "
+                                      "with the collectives muted), max over ranks"}
         if world == 1 and a.attn_logit_std is None and encoders_of(eng) and not a.no_roofline:
             f = set_attn_logit_std(encoders_of(eng), 1.5)
             dtp, stepp = timed_run(eng, needs_2d, vols, slices, k, 1, sync)
@@ -832,8 +882,6 @@ def main():
         "outputs_finite": finite,
         "peak_hbm_gb": round((torch.cuda.max_memory_allocated(dev) - (reserved.numel() if reserved is not None else 0)) / 1e9, 2),
     }
-    if batch_defaulted and a.workload == "dual256" and a.batch == DEFAULT_BATCH:
-        out["config"]["batch_changed_from"] = 20          # rounds 1-2 quoted this metric at 20 volumes per GPU (same code: --batch 20)
     if os.environ.get("HS_RECOMPUTE_MLP") and a.workload in ("dual256", "native_dual"):
         out["config"]["recompute"] = "mlp activations re-made in the backward (one more fc1 + GELU GEMM per layer)"
     if a.attn_logit_std:
@@ -845,6 +893,10 @@ def main():
         if att:
             att["ms_per_step_share"] = round(att["total_ms"] / n_inst / (1e3 * dt / a.steps), 4)
             out["attention"] = att
+            attf = attention_aggregate(classes, "attn_fwd")
+            if attf:
+                attf["ms_per_step_share"] = round(attf["total_ms"] / n_inst / (1e3 * dt / a.steps), 4)
+                out["attention_fwd"] = attf
         out["kernels"] = [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in c.items() if k != "bytes" and k != "flops"}
                           for c in sorted(classes, key=lambda c: -c["total_ms"])]
 
@@ -869,8 +921,10 @@ def main():
         fin16 = bool(torch.isfinite(eng16.flat).all().item()) and bool(torch.isfinite(eng16.params.gsq).all().item())
         out["f16_train"] = {"value": round(a.batch * k16 / dt16, 3), "unit": "CT-volumes/sec", "ms_per_step": round(1e3 * dt16 / k16, 3), "steps": k16,
                             "vs_bf16": round((a.batch * k16 / dt16) / vols_per_s, 4), "loss_scale": eng16.loss_scale, "outputs_finite": fin16,
+                            "steps_applied": eng16.step_no, "steps_skipped": eng16.skipped_steps,
                             "what": "the SAME step (same kernels, batch, optimizer) with IEEE fp16 in place of bf16 in every 16-bit tensor, "
-                                    "forward and backward, power-of-two loss scale taken out inside AdamW (engine precision='f16')"}
+                                    "forward and backward, power-of-two loss scale taken out inside AdamW (engine precision='f16'); "
+                                    "steps_skipped = optimizer passes the device refused for a non-finite gradient norm (must be 0)"}
         del eng16
         eng = None
         torch.cuda.empty_cache()
@@ -881,10 +935,14 @@ def main():
 
     # ---- the same step at the per-GPU batches the reference itself trains with: 1 volume (configs[3]/[4]: batch 8 over 8 GPUs), 2 (MRG
     # finetune, script/train_vlm_mrg.sh:15) and 3 (CLIP pretrain, script/train_clip_stage1.sh:12) ----------
+    engine_rates = {}
     if not a.no_batch1 and a.batch != 1 and world == 1:
         eng = step = None
         del vols, slices
         torch.cuda.empty_cache()
+        what = {1: "1 volume per GPU = BASELINE configs[3] / [4] (batch 8 over 8 GPUs)",
+                2: "2 volumes per GPU = the reference's MRG-finetuning per-device batch (script/train_vlm_mrg.sh:15)",
+                3: "3 volumes per GPU = the reference's CLIP-pretraining per-device batch (script/train_clip_stage1.sh:12)"}
         for bsmall in (1, 2, 3):
             if bsmall >= a.batch:
                 continue
@@ -893,12 +951,26 @@ def main():
             ns = max(5, a.steps)
             dts = timed_run(engs, needs_2d, vs_, ss_, ns, max(2, a.warmup), sync)[0]
             out[f"batch{bsmall}"] = {"value": round(bsmall * ns / dts, 3), "unit": "CT-volumes/sec", "ms_per_step": round(1e3 * dts / ns, 3), "steps": ns,
-                                     "batch_per_gpu": bsmall,
+                                     "batch_per_gpu": bsmall, "what": what[bsmall],
                                      "mfma_roofline_frac_end_to_end": round(bsmall * ns / dts * fb / 1e12 / PEAK_BF16_TFLOPS, 4)}
+            engine_rates[(bsmall, a.precision)] = bsmall * ns / dts
             del engs, vs_, ss_
             torch.cuda.empty_cache()
-        out["batch3"]["what"] = "3 volumes per GPU = the reference's CLIP-pretraining per-device batch (script/train_clip_stage1.sh:12)"
-        out["batch2"]["what"] = "2 volumes per GPU = the reference's MRG-finetuning per-device batch (script/train_vlm_mrg.sh:15)"
+    # ---- the step a DROP-IN user runs: the reference's own call pattern (nn.Module.forward -> autograd -> torch.optim.AdamW + clip) on the
+    # hsenet_amd modules, beside the engine's rate on the same box / batch / inputs (bench_module_api.py) ----------
+    if not a.no_extras and world == 1 and a.workload == "dual256" and not a.no_module_api:
+        eng = vols = slices = step = None
+        torch.cuda.empty_cache()
+        from bench_module_api import module_api_train
+        mat = module_api_train(dev, batches=(1, 3, 13), precisions=("bf16", "f16"), steps=5, warmup=2, geom=geom, engine_rates=engine_rates)
+        out["module_api_train"] = mat
+        # the batch sweep as one object (volumes/s of the ENGINE step at each per-GPU batch; 13 from the leg above, the headline batch last)
+        sweep = {str(b): out[f"batch{b}"]["value"] for b in (1, 2, 3) if f"batch{b}" in out}
+        if a.precision in mat.get("b13", {}):
+            sweep["13"] = mat["b13"][a.precision]["engine"]
+        sweep[str(a.batch)] = round(vols_per_s, 3)
+        out["batch_sweep"] = {"unit": "CT-volumes/sec", "volumes_per_gpu": sweep,
+                              "what": "engine step (fwd + bwd + clipped AdamW) at each per-GPU batch; 13 volumes = 51 GB of HBM, the headline's 53 = 197 GB"}
     if rank == 0 and world == 1 and not a.no_extras:
         eng = vols = slices = step = None
         torch.cuda.empty_cache()

@@ -38,22 +38,33 @@ class GemmArgs(C.Structure):
                 ("scale_cols", C.c_int), ("scale_cols_alpha", C.c_float)]
 
 
-class VitDesc(C.Structure):
-    _fields_ = [("B", C.c_int), ("N", C.c_int), ("d", C.c_int), ("H", C.c_int), ("mlp", C.c_int), ("L", C.c_int),
-                ("prec", C.c_int), ("save_for_bwd", C.c_int), ("ln_eps", C.c_float), ("qkv_bias", C.c_void_p)]
+ABI_VERSION = 2          # include/hsenet_hip.h HS_ABI_VERSION: load() refuses a library of another ABI
 
 
-class EmbedDesc(C.Structure):
-    _fields_ = [("B", C.c_int), ("Np", C.c_int), ("Pd", C.c_int), ("d", C.c_int), ("has_cls", C.c_int), ("scorer", C.c_int),
-                ("ns", C.c_int), ("save_for_bwd", C.c_int), ("drop_p", C.c_float), ("seed", C.c_uint64 * 2), ("offset", C.c_uint64 * 2),
-                ("prec", C.c_int)]
+class _Desc(C.Structure):
+    """descriptor structs start with `struct_size` (ABI 2): filled in here, so call sites keep passing the reference-facing fields."""
+
+    def __init__(self, *args, **kw):
+        super().__init__(C.sizeof(type(self)), *args, **kw)
 
 
-class PackerDesc(C.Structure):
-    _fields_ = [("B", C.c_int), ("gd", C.c_int), ("gh", C.c_int), ("gw", C.c_int), ("kd", C.c_int), ("kh", C.c_int), ("kw", C.c_int),
-                ("d", C.c_int), ("out_dim", C.c_int), ("in_row_offset", C.c_int), ("in_batch_stride", C.c_int64),
-                ("out_batch_stride", C.c_int64), ("save_for_bwd", C.c_int), ("drop_p", C.c_float), ("seed", C.c_uint64 * 2),
+class VitDesc(_Desc):
+    _fields_ = [("struct_size", C.c_uint32), ("B", C.c_int), ("N", C.c_int), ("d", C.c_int), ("H", C.c_int), ("mlp", C.c_int), ("L", C.c_int),
+                ("prec", C.c_int), ("save_for_bwd", C.c_int), ("ln_eps", C.c_float), ("qkv_bias", C.c_void_p),
+                ("w16", C.c_void_p), ("w16t", C.c_void_p)]
+
+
+class EmbedDesc(_Desc):
+    _fields_ = [("struct_size", C.c_uint32), ("B", C.c_int), ("Np", C.c_int), ("Pd", C.c_int), ("d", C.c_int), ("has_cls", C.c_int),
+                ("scorer", C.c_int), ("ns", C.c_int), ("save_for_bwd", C.c_int), ("drop_p", C.c_float), ("seed", C.c_uint64 * 2),
                 ("offset", C.c_uint64 * 2), ("prec", C.c_int)]
+
+
+class PackerDesc(_Desc):
+    _fields_ = [("struct_size", C.c_uint32), ("B", C.c_int), ("gd", C.c_int), ("gh", C.c_int), ("gw", C.c_int), ("kd", C.c_int),
+                ("kh", C.c_int), ("kw", C.c_int), ("d", C.c_int), ("out_dim", C.c_int), ("in_row_offset", C.c_int),
+                ("in_batch_stride", C.c_int64), ("out_batch_stride", C.c_int64), ("save_for_bwd", C.c_int), ("drop_p", C.c_float),
+                ("seed", C.c_uint64 * 2), ("offset", C.c_uint64 * 2), ("prec", C.c_int)]
 
 
 _vp, _i, _f, _i64, _sz, _u64 = C.c_void_p, C.c_int, C.c_float, C.c_int64, C.c_size_t, C.c_uint64
@@ -103,6 +114,8 @@ SIGNATURES = {
     "hs_prof_name": [_i],
     "hs_prof_count": [],
     "hs_vit_workspace_bytes": [C.POINTER(VitDesc)],
+    "hs_vit_weights_elems": [C.POINTER(VitDesc)],
+    "hs_vit_cast_weights": [C.POINTER(VitDesc), _vp, _vp, _vp, _vp],
     "hs_vit_blocks_fwd": [C.POINTER(VitDesc), _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
     "hs_vit_blocks_bwd": [C.POINTER(VitDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _vp],
     "hs_embed_workspace_bytes": [C.POINTER(EmbedDesc)],
@@ -115,6 +128,7 @@ SIGNATURES = {
     "hs_mse_grad_scaled": [_vp, _vp, _vp, _i64, _f, _vp],
     "hs_sumsq": [_vp, _vp, _vp, _i64, _vp],
     "hs_adamw_masked": [_vp, _vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _f, _vp, _f, _i, _vp],
+    "hs_adamw_fused": [_vp, _vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _f, _vp, _f, _i, _vp, _i, _vp, _vp],
     "hs_rows_copy": [_vp, _i64, _vp, _vp, _i64, _i, _i, _i, _vp],
     "hs_rows_scatter": [_vp, _vp, _i, _i, _i, _i, _i, _vp],
     "hs_scale_dev": [_vp, _vp, _vp, _f, _i64, _vp],
@@ -126,7 +140,7 @@ SIGNATURES = {
     "hs_debug_gemm_stamps": [_vp, _i],
     "hs_debug_gemm_trace": [_vp, _i],
 }
-_RESTYPE = {"hs_vit_workspace_bytes": _sz, "hs_embed_workspace_bytes": _sz, "hs_packer_workspace_bytes": _sz,
+_RESTYPE = {"hs_vit_workspace_bytes": _sz, "hs_vit_weights_elems": _sz, "hs_embed_workspace_bytes": _sz, "hs_packer_workspace_bytes": _sz,
             "hs_prof_name": C.c_char_p, "hs_build_id": C.c_char_p, "hs_debug_set": None, "hs_debug_gemm_stamps": None,
             "hs_debug_gemm_trace": None}
 
@@ -154,6 +168,9 @@ def load() -> C.CDLL:
             fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
             fn.argtypes = args
             fn.restype = _RESTYPE.get(name, C.c_int)
+        if lib.hs_version() != ABI_VERSION:
+            raise HsError(f"{LIB_PATH} speaks ABI {lib.hs_version()}, this package ABI {ABI_VERSION} (include/hsenet_hip.h): rebuild it "
+                          "(`python -m hsenet_amd.build`)")
         _lib = lib
         _warn_if_stale(lib)
     return _lib

@@ -126,7 +126,7 @@ class ClipStage1Engine(_ClipEngine):
         entries, self.chunks, bounds = _clip_flat(self.u, model, n_buckets)
         self._finish(entries, bounds, lr=lr, weight_decay=weight_decay, max_grad_norm=max_grad_norm, group=group,
                      grad_wire=grad_wire, grad_algo=grad_algo)
-        self.u.bind()
+        self.u.bind(self.params)
         self.head = _Head(self.u, model.mm_vision_proj, True)
         d, n = self.u.d, batch * self.world
         f32 = dict(dtype=torch.float32, device=self.dev)
@@ -160,7 +160,7 @@ class ClipStage1Engine(_ClipEngine):
     def backward_from_all(self, all_feats: torch.Tensor, row_stride: int, col_txt: int) -> None:
         """self.dlog -> every gradient of this model (flat gradient zeroed here), bucketed all-reduce launched and awaited."""
         s, d, B, n = Fn._s(), self.u.d, self.B, self.dlog.shape[0]
-        self.grad.zero_()
+        self._begin_backward()
         ls = self.model.logit_scale
         L.call("hs_dot", self.dlog.data_ptr(), self.raw.data_ptr(), ls.grad.data_ptr(), 1.0, n * n, s)              # d/d logit_scale
         L.call("hs_scale_dev", self.dlog.data_ptr(), self.draw.data_ptr(), ls.data_ptr(), 1.0, n * n, s)
@@ -238,7 +238,7 @@ class ClipStage2Engine(_ClipEngine):
         entries, self.chunks, bounds = _clip_flat(self.u2, model, n_buckets)
         self._finish(entries, bounds, lr=lr, weight_decay=weight_decay, max_grad_norm=max_grad_norm, group=group,
                      grad_wire=grad_wire, grad_algo=grad_algo)
-        self.u2.bind()
+        self.u2.bind(self.params)
         if self.s1 is None:
             self.u1.bind()
             self.h1 = _Head(self.u1, model.stage1_pretrained_CLIP.mm_vision_proj, False)
@@ -312,7 +312,7 @@ class ClipStage2Engine(_ClipEngine):
 
     def backward(self) -> None:
         s, d, B, n = Fn._s(), self.u2.d, self.B, self.all.shape[0]
-        self.grad.zero_()
+        self._begin_backward()
         ls = self.model.logit_scale
         L.call("hs_dot", self.dlog.data_ptr(), self.raw2.data_ptr(), ls.grad.data_ptr(), 1.0, n * n, s)            # d/d logit_scale
         L.call("hs_scale_dev", self.dlog.data_ptr(), self.draw.data_ptr(), ls.data_ptr(), 1.0, n * n, s)

@@ -7,8 +7,9 @@ int hs_gemm_group_prec(const hs_gemm_args* args, int count, int prec, void* stre
 int hs_cast_bf16_multi(const float* const* src, void* const* dst, const int64_t* n, int count, void* stream, int f16 = 0);   // small.hip (f16: fp16 instead of bf16)
 int hs_layernorm_fwd16(const float* x, const float* resid, const float* gamma, const float* beta, float* y_f32, void* y_16, float* mean,
                        float* rstd, int rows, int d, float eps, int f16, void* stream);                                        // norm.hip
-// fp32 [R][C] -> bf16 [C][R] for up to `count` matrices in one launch per 64 (R, C multiples of 64)               // small.hip
-int hs_cast_bf16_transpose_multi(const float* const* src, void* const* dst, const int* R, const int* C, int count, void* stream, int f16 = 0);
+// [R][C] -> 16-bit [C][R] for up to `count` matrices in one launch per 64 (R, C multiples of 64); the sources are fp32 (cast to bf16, or
+// fp16 with f16 != 0) or, with src_is_16, already 16-bit (bits pass through)                                      // small.hip
+int hs_transpose16_multi(const void* const* src, int src_is_16, void* const* dst, const int* R, const int* C, int count, void* stream, int f16 = 0);
 
 namespace hsdrv {
 

@@ -159,6 +159,7 @@ EmbedLayout embed_layout(const hs_embed_desc& c) {
 
 int embed_check(const hs_embed_desc* c) {
     if (!c) return HS_ERR_ARG;
+    if (c->struct_size != sizeof(hs_embed_desc)) return HS_ERR_ARG;   // a caller compiled against another header (ABI 2)
     if (c->B < 1 || c->Np < 1 || c->Pd < 8 || (c->Pd & 7) || c->d < 8 || (c->d & 7) || c->d > 1024) return HS_ERR_SHAPE;
     if (!(c->drop_p >= 0.f && c->drop_p < 1.f)) return HS_ERR_ARG;
     RC(prec_check(c->prec));
@@ -330,6 +331,7 @@ PackLayout pack_layout(const hs_packer_desc& c) {
 
 int pack_check(const hs_packer_desc* c) {
     if (!c) return HS_ERR_ARG;
+    if (c->struct_size != sizeof(hs_packer_desc)) return HS_ERR_ARG;  // a caller compiled against another header (ABI 2)
     if (c->B < 1 || c->gd < 1 || c->gh < 1 || c->gw < 1 || c->kd < 1 || c->kh < 1 || c->kw < 1) return HS_ERR_SHAPE;
     if (c->kd > c->gd || c->kh > c->gh || c->kw > c->gw || c->kd * c->kh * c->kw > 64) return HS_ERR_SHAPE;
     if (c->d < 8 || (c->d & 7) || c->d > 1024 || c->out_dim < 8 || (c->out_dim & 7)) return HS_ERR_SHAPE;
@@ -575,6 +577,89 @@ extern "C" int hs_adamw_masked(float* p, const float* g, float* m, float* v, con
     ProfScope prof(HS_PROF_ADAMW, stream, 0, (double)n * 28);
     hipLaunchKernelGGL(adamw_masked_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, decay_mask,
                        (long)n, lr, beta1, beta2, eps, weight_decay, grad_scale, grad_sumsq, max_grad_norm, bc1, bc2s);
+    HS_CHECK_LAUNCH();
+    return HS_OK;
+}
+
+// hs_adamw_fused: the same update as hs_adamw_masked as ONE sweep that also (a) zeroes the gradient behind the read, (b) writes
+// the 16-bit copy of every updated weight chunk to the address its 64-element chunk is mapped to (the operand copies of the next
+// forward: no cast pass over the fp32 masters), (c) keeps the step / skipped-step counters on the device.
+// state (int32 x 8): [0] steps applied, [1] steps skipped, [2] this call skips; as float: [4] gradient scale incl. clip, [5] bc1, [6] bc2s
+__global__ void adamw_prep_kernel(int32_t* __restrict__ st, const float* __restrict__ gsq, float gs, float max_norm, float b1, float b2) {
+    if (threadIdx.x) return;
+    float scale = gs;
+    if (gsq) {
+        const float q = gsq[0];
+        if (!(q < 3.0e38f)) { st[1] += 1; st[2] = 1; return; }    // inf / NaN gradient norm: the step is skipped and does not count
+        if (max_norm > 0.f) {     // clip_grad_norm_: coef = max_norm / (||g|| + 1e-6), applied when < 1
+            const float coef = max_norm / (sqrtf(q) * gs + 1e-6f);
+            if (coef < 1.0f) scale *= coef;
+        }
+    }
+    const int step = st[0] + 1;
+    st[0] = step; st[2] = 0;
+    float* f = (float*)st;
+    f[4] = scale;
+    f[5] = 1.0f - powf(b1, (float)step);
+    f[6] = sqrtf(1.0f - powf(b2, (float)step));
+}
+template <bool F16>
+__global__ __launch_bounds__(256) void adamw_fused_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                          float* __restrict__ v, const unsigned char* __restrict__ decay, long n, float lr,
+                                                          float b1, float b2, float eps, float wd, int zero_grad,
+                                                          const uint64_t* __restrict__ table, const int32_t* __restrict__ st) {
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    if (st[2]) {                  // skipped step: parameters, moments and 16-bit copies stay; the overflowed gradient is discarded
+        if (zero_grad) *(f32x4*)(g + i) = z4;
+        return;
+    }
+    const float* sf = (const float*)st;
+    const float scale = sf[4], lr1 = lr / sf[5], bc2s = sf[6];
+    const float wde = (decay && !decay[i >> 6]) ? 0.f : wd;
+    f32x4 P = *(const f32x4*)(p + i), M = *(const f32x4*)(m + i), V = *(const f32x4*)(v + i);
+    const f32x4 G = *(const f32x4*)(g + i);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float gr = G[e] * scale;
+        float pv = P[e] * (1.0f - lr * wde);
+        const float mv = b1 * M[e] + (1.0f - b1) * gr;
+        const float vv = b2 * V[e] + (1.0f - b2) * gr * gr;
+        M[e] = mv;
+        V[e] = vv;
+        pv -= lr1 * mv / (sqrtf(vv) / bc2s + eps);
+        P[e] = pv;
+    }
+    *(f32x4*)(p + i) = P;
+    *(f32x4*)(m + i) = M;
+    *(f32x4*)(v + i) = V;
+    if (zero_grad) *(f32x4*)(g + i) = z4;
+    if (table) {
+        const uint64_t dst = table[i >> 6];
+        if (dst) {
+            u32x2 pk;
+            pk[0] = pack2h<F16>(P[0], P[1]); pk[1] = pack2h<F16>(P[2], P[3]);
+            *(u32x2*)(uintptr_t)(dst + (uint64_t)((i & 63) * 2)) = pk;
+        }
+    }
+}
+extern "C" int hs_adamw_fused(float* p, float* g, float* m, float* v, const unsigned char* decay_mask, int64_t n, float lr, float beta1,
+                              float beta2, float eps, float weight_decay, float grad_scale, const float* grad_sumsq, float max_grad_norm,
+                              int zero_grad, const uint64_t* w16_table, int w16_is_f16, int32_t* state, void* stream) {
+    if (!p || !g || !m || !v || !state) return HS_ERR_ARG;
+    if (n < 64 || (n & 63)) return HS_ERR_SHAPE;
+    if ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) || ((uintptr_t)state & 3) || ((uintptr_t)w16_table & 7)) return HS_ERR_SHAPE;
+    if (max_grad_norm > 0.f && !grad_sumsq) return HS_ERR_ARG;
+    if (!(grad_scale > 0.f)) return HS_ERR_ARG;
+    ProfScope prof(HS_PROF_ADAMW, stream, 0, (double)n * (28 + (zero_grad ? 4 : 0)));
+    hipLaunchKernelGGL(adamw_prep_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state, grad_sumsq, grad_scale,
+                       max_grad_norm > 0.f ? max_grad_norm : 0.f, beta1, beta2);
+    const dim3 grid((unsigned)((n + 1023) / 1024)), blk(256);
+    if (w16_is_f16) hipLaunchKernelGGL(adamw_fused_kernel<true>, grid, blk, 0, (hipStream_t)stream, p, g, m, v, decay_mask, (long)n, lr, beta1,
+                                       beta2, eps, weight_decay, zero_grad, w16_table, (const int32_t*)state);
+    else hipLaunchKernelGGL(adamw_fused_kernel<false>, grid, blk, 0, (hipStream_t)stream, p, g, m, v, decay_mask, (long)n, lr, beta1, beta2,
+                            eps, weight_decay, zero_grad, w16_table, (const int32_t*)state);
     HS_CHECK_LAUNCH();
     return HS_OK;
 }

@@ -718,8 +718,9 @@ int hs_cast_bf16_multi(const float* const* src, void* const* dst, const int64_t*
 // dX = dY W reads W [out][in] with the reduction index (out) as the memory row -- the NN layout, transposed LDS reads, the slower
 // GEMM kernel; against W^T [in][out] the same product is an NT GEMM and runs on the forward's kernel.  Up to 64 matrices per
 // launch, 64 x 64 tiles through LDS, R and C multiples of 64.  Internal to the library (vit.hip); rounding = hs_cast_bf16's.
-struct CastTSegs { const float* src[64]; bf16_t* dst[64]; int R[64], C[64]; int first[65]; };
-template <bool F16>
+struct CastTSegs { const void* src[64]; bf16_t* dst[64]; int R[64], C[64]; int first[65]; };
+// SRC16: the source matrices are already 16-bit (the straight copies an optimizer pass wrote): bits pass through, 4 B per element moved
+template <bool F16, bool SRC16>
 __global__ __launch_bounds__(256) void cast_bf16_transpose_multi_kernel(CastTSegs g) {
     __shared__ __attribute__((aligned(16))) bf16_t t[64][64 + 8];          // 144-B rows: 16-B aligned reads
     int b = blockIdx.x, sgm = 0;
@@ -727,21 +728,34 @@ __global__ __launch_bounds__(256) void cast_bf16_transpose_multi_kernel(CastTSeg
     b -= g.first[sgm];
     const int R = g.R[sgm], C = g.C[sgm], tc = C >> 6;
     const int r0 = (b / tc) << 6, c0 = (b % tc) << 6;
-    const float* __restrict__ x = g.src[sgm];
     bf16_t* __restrict__ y = g.dst[sgm];
     const int tr = threadIdx.x >> 2, tb = (threadIdx.x & 3) << 4;
+    if (SRC16) {
+        const bf16_t* __restrict__ x = (const bf16_t*)g.src[sgm];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const f32x4 v = *(const f32x4*)(x + (long)(r0 + tr) * C + c0 + tb + 4 * k);
+        for (int k = 0; k < 2; ++k) {
+            const u32x4 v = *(const u32x4*)(x + (long)(r0 + tr) * C + c0 + tb + 8 * k);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) t[tb + 4 * k + e][tr] = f2h<F16>(v[e]);
+            for (int e = 0; e < 4; ++e) {
+                t[tb + 8 * k + 2 * e][tr] = (bf16_t)(v[e] & 0xffffu);
+                t[tb + 8 * k + 2 * e + 1][tr] = (bf16_t)(v[e] >> 16);
+            }
+        }
+    } else {
+        const float* __restrict__ x = (const float*)g.src[sgm];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const f32x4 v = *(const f32x4*)(x + (long)(r0 + tr) * C + c0 + tb + 4 * k);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t[tb + 4 * k + e][tr] = f2h<F16>(v[e]);
+        }
     }
     __syncthreads();
     const u32x4 lo = *(const u32x4*)&t[tr][tb], hi = *(const u32x4*)&t[tr][tb + 8];
     *(u32x4*)(y + (long)(c0 + tr) * R + r0 + tb) = lo;
     *(u32x4*)(y + (long)(c0 + tr) * R + r0 + tb + 8) = hi;
 }
-int hs_cast_bf16_transpose_multi(const float* const* src, void* const* dst, const int* R, const int* C, int count, void* stream, int f16) {
+int hs_transpose16_multi(const void* const* src, int src_is_16, void* const* dst, const int* R, const int* C, int count, void* stream, int f16) {
     if (!src || !dst || !R || !C || count < 1) return HS_ERR_ARG;
     for (int c0 = 0; c0 < count; c0 += 64) {
         CastTSegs g;
@@ -754,12 +768,14 @@ int hs_cast_bf16_transpose_multi(const float* const* src, void* const* dst, cons
             if (((uintptr_t)src[c0 + i] | (uintptr_t)dst[c0 + i]) & 15) return HS_ERR_SHAPE;
             g.src[i] = src[c0 + i]; g.dst[i] = (bf16_t*)dst[c0 + i]; g.R[i] = r; g.C[i] = c;
             g.first[i + 1] = g.first[i] + (r >> 6) * (c >> 6);
-            bytes += (double)r * c * 6;
+            bytes += (double)r * c * (src_is_16 ? 4 : 6);
         }
         for (int i = cnt; i < 64; ++i) { g.src[i] = nullptr; g.dst[i] = nullptr; g.R[i] = 0; g.C[i] = 0; g.first[i + 1] = g.first[cnt]; }
         ProfScope prof(HS_PROF_CAST, stream, 0, bytes);
-        if (f16) hipLaunchKernelGGL(cast_bf16_transpose_multi_kernel<true>, dim3((unsigned)g.first[cnt]), dim3(256), 0, (hipStream_t)stream, g);
-        else hipLaunchKernelGGL(cast_bf16_transpose_multi_kernel<false>, dim3((unsigned)g.first[cnt]), dim3(256), 0, (hipStream_t)stream, g);
+        const dim3 grid((unsigned)g.first[cnt]), blk(256);
+        if (src_is_16) hipLaunchKernelGGL((cast_bf16_transpose_multi_kernel<false, true>), grid, blk, 0, (hipStream_t)stream, g);
+        else if (f16) hipLaunchKernelGGL((cast_bf16_transpose_multi_kernel<true, false>), grid, blk, 0, (hipStream_t)stream, g);
+        else hipLaunchKernelGGL((cast_bf16_transpose_multi_kernel<false, false>), grid, blk, 0, (hipStream_t)stream, g);
         HS_CHECK_LAUNCH();
     }
     return HS_OK;
@@ -928,7 +944,7 @@ extern "C" int hs_scale(const float* x, float* y, float alpha, int64_t n, void* 
 }
 extern "C" int hs_prof_count(void) { return HS_PROF_COUNT; }
 
-extern "C" int hs_version(void) { return 1; }
+extern "C" int hs_version(void) { return HS_ABI_VERSION; }
 extern "C" int hs_device_check(int dev) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return HS_ERR_ARCH;

@@ -44,9 +44,10 @@ Layout make_layout(const hs_vit_desc& c) {
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += al256(bytes); return o; };
     L.per_w = 3 * d * d + d * d + mlp * d + d * mlp;
-    L.wbf = take(c.prec != HS_PREC_F32 ? (size_t)c.L * L.per_w * 2 : 0);      // 16-bit (bf16 / fp16) weight copies
+    // 16-bit (bf16 / fp16) weight copies: in the workspace, re-made per call -- unless the caller owns them (hs_vit_desc.w16 / .w16t)
+    L.wbf = take(c.prec != HS_PREC_F32 && !c.w16 ? (size_t)c.L * L.per_w * 2 : 0);
     // TRANSPOSED bf16 weight copies for the backward pass' dgrads (see dgrad_nt below): same per-layer order [Wqkv^T | Wo^T | W1^T | W2^T]
-    L.wbft = take(c.prec != HS_PREC_F32 && c.save_for_bwd && dgrad_nt(c) ? (size_t)c.L * L.per_w * 2 : 0);
+    L.wbft = take(c.prec != HS_PREC_F32 && c.save_for_bwd && dgrad_nt(c) && !c.w16t ? (size_t)c.L * L.per_w * 2 : 0);
     L.xmid = take(Ls * M * d * 4);
     L.h1 = take(Ls * M * d * es);
     L.h2 = take(Ls * M * d * es);
@@ -75,6 +76,10 @@ Layout make_layout(const hs_vit_desc& c) {
 
 int check_desc(const hs_vit_desc* c) {
     if (!c) return HS_ERR_ARG;
+    if (c->struct_size != sizeof(hs_vit_desc)) return HS_ERR_ARG;     // a caller compiled against another header (ABI 2)
+    if ((c->w16 || c->w16t) && c->prec == HS_PREC_F32) return HS_ERR_ARG;
+    if (((uintptr_t)c->w16 | (uintptr_t)c->w16t) & 15) return HS_ERR_SHAPE;
+    if (c->w16t && ((c->d & 63) || (c->mlp & 63))) return HS_ERR_SHAPE;
     if (c->B < 1 || c->N < 1 || c->L < 1 || c->H < 1) return HS_ERR_SHAPE;
     if (c->d != c->H * 64) return HS_ERR_SHAPE;  // attention kernels are specialised for head_dim 64
     if ((c->d & 7) || (c->mlp & 7) || c->d > 1024) return HS_ERR_SHAPE;
@@ -98,6 +103,60 @@ extern "C" size_t hs_vit_workspace_bytes(const hs_vit_desc* desc) {
     return make_layout(*desc).total;
 }
 
+extern "C" size_t hs_vit_weights_elems(const hs_vit_desc* desc) {
+    if (check_desc(desc) != HS_OK || desc->prec == HS_PREC_F32) return 0;
+    return (size_t)desc->L * make_layout(*desc).per_w;
+}
+
+namespace {
+// the straight / transposed 16-bit copies of layers [l_lo, l_hi) into copy sets laid out like L.wbf (layer l at l * per_w)
+int cast_weights(const hs_vit_desc& c, const float* const* lp, void* w16, int l_lo, int l_hi, void* stream) {
+    const size_t d = c.d, mlp = c.mlp, per_w = 4 * d * d + 2 * d * mlp;
+    std::vector<const float*> src;
+    std::vector<void*> dst;
+    std::vector<int64_t> cnt;
+    for (int l = l_lo; l < l_hi; ++l) {
+        bf16_t* wl = (bf16_t*)w16 + (size_t)l * per_w;
+        const float* const* p = lp + (size_t)l * P_COUNT;
+        src.push_back(p[P_WQKV]); dst.push_back(wl); cnt.push_back((int64_t)3 * d * d);
+        src.push_back(p[P_WO]); dst.push_back(wl + 3 * d * d); cnt.push_back((int64_t)d * d);
+        src.push_back(p[P_W1]); dst.push_back(wl + 4 * d * d); cnt.push_back((int64_t)mlp * d);
+        src.push_back(p[P_W2]); dst.push_back(wl + 4 * d * d + mlp * d); cnt.push_back((int64_t)d * mlp);
+    }
+    return hs_cast_bf16_multi(src.data(), dst.data(), cnt.data(), (int)src.size(), stream, c.prec == HS_PREC_F16);
+}
+// src16 == nullptr: from the fp32 parameters; else from the straight 16-bit copy set src16
+int transpose_weights(const hs_vit_desc& c, const float* const* lp, const void* src16, void* w16t, int l_lo, int l_hi, void* stream) {
+    const size_t d = c.d, mlp = c.mlp, per_w = 4 * d * d + 2 * d * mlp;
+    std::vector<const void*> src;
+    std::vector<void*> dst;
+    std::vector<int> R, Cc;
+    for (int l = l_lo; l < l_hi; ++l) {
+        bf16_t* wl = (bf16_t*)w16t + (size_t)l * per_w;
+        const size_t off[4] = {0, 3 * d * d, 4 * d * d, 4 * d * d + mlp * d};
+        const int idx[4] = {P_WQKV, P_WO, P_W1, P_W2};
+        const int rc[4][2] = {{3 * c.d, c.d}, {c.d, c.d}, {c.mlp, c.d}, {c.d, c.mlp}};
+        for (int i = 0; i < 4; ++i) {
+            src.push_back(src16 ? (const void*)((const bf16_t*)src16 + (size_t)l * per_w + off[i]) : (const void*)lp[(size_t)l * P_COUNT + idx[i]]);
+            dst.push_back(wl + off[i]); R.push_back(rc[i][0]); Cc.push_back(rc[i][1]);
+        }
+    }
+    return hs_transpose16_multi(src.data(), src16 != nullptr, dst.data(), R.data(), Cc.data(), (int)src.size(), stream, c.prec == HS_PREC_F16);
+}
+}  // namespace
+
+extern "C" int hs_vit_cast_weights(const hs_vit_desc* desc, const float* const* lp, void* w16, void* w16t, void* stream) {
+    RC(check_desc(desc));
+    const hs_vit_desc& c = *desc;
+    if (c.prec == HS_PREC_F32 || (!w16 && !w16t)) return HS_ERR_ARG;
+    if (!lp && !(w16 && w16t)) return HS_ERR_ARG;                  // without the fp32 parameters: w16 -> w16t only
+    if (((uintptr_t)w16 | (uintptr_t)w16t) & 15) return HS_ERR_SHAPE;
+    if (w16t && ((c.d & 63) || (c.mlp & 63))) return HS_ERR_SHAPE;
+    if (lp && w16) RC(cast_weights(c, lp, w16, 0, c.L, stream));
+    if (w16t) RC(transpose_weights(c, lp, lp ? nullptr : w16, w16t, 0, c.L, stream));
+    return HS_OK;
+}
+
 extern "C" int hs_vit_blocks_fwd(const hs_vit_desc* desc, const float* x0, const float* const* lp, const float* const* np,
                                  float* y, float* hidden, void* ws, size_t ws_bytes, void* stream) {
     RC(check_desc(desc));
@@ -113,20 +172,9 @@ extern "C" int hs_vit_blocks_fwd(const hs_vit_desc* desc, const float* x0, const
     const size_t es = bf ? 2 : 4;
     const float eps = c.ln_eps > 0.f ? c.ln_eps : 1e-5f;
 
-    if (bf) {   // bf16 copies of the four weight matrices of every layer: one multi-segment launch per 16 layers
-        std::vector<const float*> src;
-        std::vector<void*> dst;
-        std::vector<int64_t> cnt;
-        for (int l = 0; l < c.L; ++l) {
-            bf16_t* wl = (bf16_t*)(w + L.wbf) + (size_t)l * L.per_w;
-            const float* const* p = lp + (size_t)l * P_COUNT;
-            src.push_back(p[P_WQKV]); dst.push_back(wl); cnt.push_back((int64_t)3 * d * d);
-            src.push_back(p[P_WO]); dst.push_back(wl + 3 * d * d); cnt.push_back((int64_t)d * d);
-            src.push_back(p[P_W1]); dst.push_back(wl + 4 * d * d); cnt.push_back((int64_t)mlp * d);
-            src.push_back(p[P_W2]); dst.push_back(wl + 4 * d * d + (size_t)mlp * d); cnt.push_back((int64_t)d * mlp);
-        }
-        RC(hs_cast_bf16_multi(src.data(), dst.data(), cnt.data(), (int)src.size(), stream, f16));
-    }
+    // 16-bit copies of the four weight matrices of every layer: the caller's (desc.w16), or re-made here in one multi-segment launch
+    const bf16_t* wcopy = bf ? (c.w16 ? (const bf16_t*)c.w16 : (const bf16_t*)(w + L.wbf)) : nullptr;
+    if (bf && !c.w16) RC(cast_weights(c, lp, w + L.wbf, 0, c.L, stream));
     for (int l = 0; l < c.L; ++l) {
         const size_t ls = c.save_for_bwd ? l : 0;
         const float* const* p = lp + (size_t)l * P_COUNT;
@@ -144,7 +192,7 @@ extern "C" int hs_vit_blocks_fwd(const hs_vit_desc* desc, const float* x0, const
         float* st = (float*)(w + L.stats) + ls * 4 * (size_t)M;
         const void *wqkv, *wo, *w1, *w2;
         if (bf) {
-            const bf16_t* wl = (const bf16_t*)(w + L.wbf) + (size_t)l * L.per_w;
+            const bf16_t* wl = wcopy + (size_t)l * L.per_w;
             wqkv = wl; wo = wl + 3 * d * d; w1 = wl + 4 * d * d; w2 = wl + 4 * d * d + (size_t)mlp * d;
         } else {
             wqkv = p[P_WQKV]; wo = p[P_WO]; w1 = p[P_W1]; w2 = p[P_W2];
@@ -208,20 +256,9 @@ extern "C" int hs_vit_blocks_bwd(const hs_vit_desc* desc, const float* x0, const
     float* delta = (float*)(w + L.delta);
 
     const bool nt = bf && dgrad_nt(c);
-    if (nt) {   // W^T copies of this call's layers: one multi-segment launch
-        std::vector<const float*> src;
-        std::vector<void*> dst;
-        std::vector<int> R, Cc;
-        for (int l = l_lo; l < l_hi; ++l) {
-            bf16_t* wl = (bf16_t*)(w + L.wbft) + (size_t)l * L.per_w;
-            const float* const* p = lp + (size_t)l * P_COUNT;
-            src.push_back(p[P_WQKV]); dst.push_back(wl); R.push_back(3 * d); Cc.push_back(d);
-            src.push_back(p[P_WO]); dst.push_back(wl + 3 * d * d); R.push_back(d); Cc.push_back(d);
-            src.push_back(p[P_W1]); dst.push_back(wl + 4 * d * d); R.push_back(mlp); Cc.push_back(d);
-            src.push_back(p[P_W2]); dst.push_back(wl + 4 * d * d + (size_t)mlp * d); R.push_back(d); Cc.push_back(mlp);
-        }
-        RC(hs_cast_bf16_transpose_multi(src.data(), dst.data(), R.data(), Cc.data(), (int)src.size(), stream, f16));
-    }
+    const bf16_t* wcopy = bf ? (c.w16 ? (const bf16_t*)c.w16 : (const bf16_t*)(w + L.wbf)) : nullptr;     // (the forward left it there)
+    const bf16_t* wcopyt = nt ? (c.w16t ? (const bf16_t*)c.w16t : (const bf16_t*)(w + L.wbft)) : nullptr;
+    if (nt && !c.w16t) RC(transpose_weights(c, lp, nullptr, w + L.wbft, l_lo, l_hi, stream));   // W^T copies of this call's layers: one launch
     if (l_hi == c.L) {
         const float* fs = (const float*)(w + L.fstats);
         // (each LN backward also emits the column sums of the dx it produces = the bias gradient of the Linear below it)
@@ -244,7 +281,7 @@ extern "C" int hs_vit_blocks_bwd(const hs_vit_desc* desc, const float* x0, const
         const float* st = (const float*)(w + L.stats) + (size_t)l * 4 * M;
         const void *wqkv, *wo, *w1, *w2;
         if (bf) {
-            const bf16_t* wl = (const bf16_t*)(w + L.wbf) + (size_t)l * L.per_w;
+            const bf16_t* wl = wcopy + (size_t)l * L.per_w;
             wqkv = wl; wo = wl + 3 * d * d; w1 = wl + 4 * d * d; w2 = wl + 4 * d * d + (size_t)mlp * d;
         } else {
             wqkv = p[P_WQKV]; wo = p[P_WO]; w1 = p[P_W1]; w2 = p[P_W2];
@@ -252,7 +289,7 @@ extern "C" int hs_vit_blocks_bwd(const hs_vit_desc* desc, const float* x0, const
 
         if (bf) {
             // bf16: dgrad chain first, the four weight gradients as one grouped launch at the end of the layer
-            const bf16_t* wlt = (const bf16_t*)(w + L.wbft) + (size_t)l * L.per_w;        // (valid when nt)
+            const bf16_t* wlt = wcopyt + (size_t)l * L.per_w;        // (valid when nt)
             const bf16_t *wqkvt = wlt, *wot = wlt + 3 * d * d, *w1t = wlt + 4 * d * d, *w2t = wlt + 4 * d * d + (size_t)mlp * d;
             const int j = 2 * (c.L - 1 - l);
             const size_t dxs = al256(Md * 2);

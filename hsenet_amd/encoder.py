@@ -17,6 +17,7 @@ the parity fixtures pin.  A frozen tower that must be deterministic needs ``.eva
 """
 from __future__ import annotations
 
+import os
 from collections.abc import Sequence
 
 import numpy as np
@@ -30,6 +31,12 @@ from ._lib import PREC_BF16, PREC_F16, PREC_F32
 def _prec(module) -> int:
     p = getattr(module, "precision", None) or Fn.get_precision()
     return {"bf16": PREC_BF16, "f32": PREC_F32, "f16": PREC_F16}[p]
+
+
+def _unfused() -> bool:
+    """HS_MODULE_UNFUSED=1: the module API runs one autograd Function per reference operator (the form the exact-f32 parity mode and the
+    'conv' patch embedding always use) instead of the fused embedding / packer drivers -- A/B runs and the equivalence tests."""
+    return os.environ.get("HS_MODULE_UNFUSED") == "1"
 
 
 class _Rearrange(nn.Module):
@@ -189,10 +196,38 @@ class _ViTBase(nn.Module):
         w, b = pe.linear_weight_bias()
         return Fn.PatchEmbedFn.apply(x, w, b, pe.patch_size, prec)
 
+    def _fused_ok(self, prec, *inputs) -> bool:
+        """the fused embedding driver (one autograd node for P1 + token assembly + the 2E3 scorer) serves the 16-bit precisions of the
+        shipped 'perceptron' embedding; inputs that ask for a gradient (never the case for volumes / slice features) take the
+        per-operator Functions."""
+        return (prec != PREC_F32 and self.patch_embedding.pos_embed == "perceptron" and not _unfused()
+                and not any(isinstance(t, torch.Tensor) and t.requires_grad for t in inputs))
+
+    def _head16(self):
+        """the embedding driver's 16 parameter slots (hs_embed_*): [cls, pos, pe.w, pe.b, score.w, score.b, Wq, Wk, Wv, Wo (w, b each), norm.w, norm.b]."""
+        pe = self.patch_embedding
+        head = [getattr(self, "cls_token", None), pe.position_embeddings, pe.patch_embeddings[1].weight, pe.patch_embeddings[1].bias]
+        sga = getattr(self, "slice_guided_attention", None)
+        if sga is not None:
+            head += [self.patch_score_proj.weight, self.patch_score_proj.bias]
+            for lin in (sga.Wq, sga.Wk, sga.Wv, sga.output_linear):
+                head += [lin.weight, lin.bias]
+            head += [sga.norm.weight, sga.norm.bias]
+        return head + [None] * (16 - len(head))
+
+    def _run_fused(self, x, image_2d, prec):
+        """this encoder alone through the fused node chain (hsenet_amd/fused.py)."""
+        from . import fused
+        (y, hidden), = fused.run_encoders([fused.EncJob(self, x, image_2d, prec)])
+        return y, hidden
+
     def _stack(self, tokens, prec):
         params = [p for blk in self.blocks for p in blk.ordered_params()] + [self.norm.weight, self.norm.bias]
         need_grad = torch.is_grad_enabled() and (tokens.requires_grad or any(p.requires_grad for p in params))
-        y, hidden = Fn.BlocksFn.apply(tokens, self.num_heads, self.mlp_dim, prec, need_grad, *params)
+        cache = self.__dict__.get("_w16cache")
+        if cache is None:
+            cache = self.__dict__["_w16cache"] = Fn.W16Cache()
+        y, hidden = Fn.BlocksFn.apply(tokens, self.num_heads, self.mlp_dim, prec, need_grad, cache, *params)
         return y, [hidden[i] for i in range(hidden.shape[0])]
 
 
@@ -212,6 +247,8 @@ class ViT_stage1(_ViTBase):
 
     def forward(self, x, k=None, visual_encoder_2D=None, text_features=None, image_path=None):
         prec = _prec(self)
+        if self._fused_ok(prec, x):
+            return self._run_fused(x, None, prec)
         pe = self._embed(x, prec)
         cls = self.cls_token if hasattr(self, "cls_token") else None
         tokens, _ = Fn.AssembleFn.apply(pe, self.patch_embedding.position_embeddings, cls, None)
@@ -239,6 +276,9 @@ class ViT_stage2(_ViTBase):
     def forward(self, x, image_2d, k=None, visual_encoder_2D=None, text_features=None, image_path=None):
         prec = _prec(self)
         batch = x.size(0)
+        if self._fused_ok(prec, x, image_2d):
+            self.slice_guided_attention.attn = None       # (the attention map stays inside the fused driver's workspace)
+            return self._run_fused(x, image_2d, prec)
         pe = self._embed(x, prec)
         pos = self.patch_embedding.position_embeddings
         cls = self.cls_token if hasattr(self, "cls_token") else None
@@ -284,9 +324,33 @@ class ViT3DTower_dual_encoders(nn.Module):
         self.vision_tower_stage1 = ViT_stage1(**kw)
         self.vision_tower_stage2 = ViT_stage2(**kw)
 
+    # two_streams: None = the engines' rule (the 2E3 encoder's kernels on a side HIP stream below 16 volumes per GPU, joined inside every
+    # autograd node: see hsenet_amd/fused.py), True / False force it
+    two_streams = None
+
+    def _encode_both(self, images, images_2d):
+        """both encoders as ONE chain of fused autograd nodes (16-bit precisions; hsenet_amd/fused.py) -- or, when that form does not
+        apply (exact-f32 mode, 'conv' embedding, forward hooks on the encoders, inputs that want gradients), one after the other as
+        the reference writes it (vit.py:928-929)."""
+        s1, s2 = self.vision_tower_stage1, self.vision_tower_stage2
+        prec = _prec(s1)
+        hooked = any(m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or m._backward_pre_hooks for m in (s1, s2))
+        if (not hooked and prec == _prec(s2) and s1._fused_ok(prec, images) and s2._fused_ok(prec, images, images_2d)
+                and len(s1.blocks) == len(s2.blocks)):
+            from . import fused
+            with Fn.shared_patches():          # both encoders embed the same volume: it is patchified once
+                jobs = [fused.EncJob(s1, images, None, prec), fused.EncJob(s2, images, images_2d, prec)]
+            s2.slice_guided_attention.attn = None
+            ts = self.two_streams if self.two_streams is not None else fused.dual_streams_default(images.shape[0])
+            (f1, _), (f2, _) = fused.run_encoders(jobs, two_streams=ts)
+            return f1, f2
+        with Fn.shared_patches():
+            f1, _ = s1(images)
+            f2, _ = s2(images, images_2d)
+        return f1, f2
+
     def forward(self, images, images_2d):
-        f1, _ = self.vision_tower_stage1(images)
-        f2, _ = self.vision_tower_stage2(images, images_2d)
+        f1, f2 = self._encode_both(images, images_2d)
         if self.select_feature == "patch":
             f1, f2 = f1[:, 1:], f2[:, 1:]
         elif self.select_feature == "cls_patch":

@@ -19,6 +19,7 @@ from __future__ import annotations
 
 import contextlib
 import ctypes as C
+import os
 from typing import Callable, List, Optional, Sequence, Tuple
 
 import torch
@@ -92,23 +93,59 @@ class FlatParams:
         self.decay_mask = mask.to(device)
         self.gsq = torch.zeros(1, dtype=torch.float32, device=device)
         self._gsq_scratch = torch.zeros(1024, dtype=torch.float32, device=device)
-        self.step_no = 0
+        # hs_adamw_fused's device state: [0] steps applied, [1] steps skipped (non-finite gradient norm), rest scratch
+        self.state = torch.zeros(8, dtype=torch.int32, device=device)
+        self._param_offset = {id(p): o for (_, p, _), o in zip(entries, offs)}
+        self._w16_host = torch.zeros(off // 64, dtype=torch.int64)
+        self._w16_dev: Optional[torch.Tensor] = None
+        self.w16_is_f16 = False
+        self.check_finite = False          # fp16 engines: compute the gradient norm (and arm the skip) even without clipping
+        self.grad_dirty = False            # the flat gradient holds a backward pass' values (the next backward must start from zero)
 
     def offset(self, name: str) -> int:
         return self.offsets[self.names.index(name)]
 
+    def map_w16(self, param: nn.Parameter, dst_ptr: int) -> None:
+        """have the optimizer pass write the 16-bit copy of `param` (a weight matrix adopted into this flat buffer) to device address
+        `dst_ptr` while it updates it (hs_adamw_fused's w16_table: one destination per 64-element chunk)."""
+        o, n = self._param_offset[id(param)], param.numel()
+        if n % 64 or dst_ptr % 16:
+            raise L.HsError("a 16-bit weight copy needs a 64-element multiple and a 16-byte aligned destination")
+        self._w16_host[o // 64:(o + n) // 64] = dst_ptr + 128 * torch.arange(n // 64, dtype=torch.int64)
+        self._w16_dev = None
+
+    @property
+    def step_no(self) -> int:
+        """optimizer steps APPLIED (a step skipped for a non-finite fp16 gradient does not count); reads the device counter."""
+        return int(self.state[0].item())
+
+    @property
+    def skipped_steps(self) -> int:
+        return int(self.state[1].item())
+
+    def zero_grad(self) -> None:
+        if self.grad_dirty:
+            self.grad.zero_()
+            self.grad_dirty = False
+
     def step(self, *, lr: float, weight_decay: float, grad_scale: float, max_grad_norm: Optional[float], betas=(0.9, 0.999),
-             eps: float = 1e-8) -> None:
-        """one fused AdamW pass (decay mask, global-norm clip on the device)."""
-        self.step_no += 1
+             eps: float = 1e-8, zero_grad: bool = True) -> None:
+        """the optimizer pass as ONE sweep (hs_adamw_fused): decay mask, global-norm clip on the device, the gradient zeroed behind
+        the read (zero_grad), the registered 16-bit weight copies written beside the fp32 masters, step / skip counters on the device."""
         s = Fn._s()
         gsq = None
-        if max_grad_norm is not None and max_grad_norm > 0:
+        clip = max_grad_norm is not None and max_grad_norm > 0
+        if clip or self.check_finite:
             L.call("hs_sumsq", self.grad.data_ptr(), self.gsq.data_ptr(), self._gsq_scratch.data_ptr(), self.total, s)
             gsq = self.gsq.data_ptr()
-        L.call("hs_adamw_masked", self.flat.data_ptr(), self.grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
+        if self._w16_dev is None and bool(self._w16_host.any()):
+            self._w16_dev = self._w16_host.to(self.flat.device)
+        L.call("hs_adamw_fused", self.flat.data_ptr(), self.grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
                self.decay_mask.data_ptr(), self.total, lr, betas[0], betas[1], eps, weight_decay, grad_scale, gsq,
-               float(max_grad_norm or 0.0), self.step_no, s)
+               float(max_grad_norm) if clip else 0.0, int(zero_grad), Fn._p(self._w16_dev), int(self.w16_is_f16),
+               self.state.data_ptr(), s)
+        if zero_grad:
+            self.grad_dirty = False
 
 
 def _seeds(desc, train: bool) -> None:
@@ -184,6 +221,19 @@ class EncoderUnit:
         self.edesc = L.EmbedDesc(batch, self.Np, self.Pd, self.d, int(self.has_cls), int(self.scorer), 32, int(trainable), 0.0)
         self.edesc.prec = prec
         lib = L.load()
+        # the 16-bit copies of the block weights live OUTSIDE the per-call workspace (hs_vit_desc.w16 / .w16t): made once, re-made only when
+        # a parameter changes behind the engine's back (sync_weights), and kept current by the optimizer pass itself (FlatParams.map_w16:
+        # hs_adamw_fused writes the straight copy as it updates; after_step() re-makes the transposed one from it)
+        self.w_elems = lib.hs_vit_weights_elems(C.byref(self.desc))
+        if self.w_elems == 0:
+            raise L.HsError("unsupported encoder geometry")
+        dt16 = torch.float16 if prec == L.PREC_F16 else torch.bfloat16
+        self.w16 = torch.empty(self.w_elems, dtype=dt16, device=self.dev)
+        nt = trainable and self.d % 64 == 0 and model.mlp_dim % 64 == 0
+        self.w16t = torch.empty(self.w_elems, dtype=dt16, device=self.dev) if nt else None
+        self.desc.w16, self.desc.w16t = self.w16.data_ptr(), Fn._p(self.w16t)
+        self._wmats = [w for blk in model.blocks for w in (blk.attn.qkv.weight, blk.attn.out_proj.weight, blk.mlp.linear1.weight, blk.mlp.linear2.weight)]
+        self._wkey, self._flat, self._w16_mapped = None, None, False
         self.ws_bytes = lib.hs_vit_workspace_bytes(C.byref(self.desc))
         if self.ws_bytes == 0:
             raise L.HsError("unsupported encoder geometry")
@@ -210,9 +260,24 @@ class EncoderUnit:
     def flat_order(self) -> List[Tuple[str, nn.Parameter]]:
         return encoder_flat_order(self.model)
 
-    def bind(self) -> None:
-        """(re)build the device-pointer tables after the parameters were adopted into flat buffers."""
+    def bind(self, params: Optional["FlatParams"] = None) -> None:
+        """(re)build the device-pointer tables after the parameters were adopted into flat buffers.  params (a trainable unit): the
+        flat buffers that own this encoder's weights -- their optimizer pass then writes the 16-bit copies of the block weights."""
         m = self.model
+        if params is not None:
+            self._flat = params.flat
+            if self.trainable:
+                d, mlp, per = self.d, m.mlp_dim, self.w_elems // self.Ln
+                base = self.w16.data_ptr()
+                for l, blk in enumerate(m.blocks):
+                    o = 2 * l * per
+                    params.map_w16(blk.attn.qkv.weight, base + o)
+                    params.map_w16(blk.attn.out_proj.weight, base + o + 2 * 3 * d * d)
+                    params.map_w16(blk.mlp.linear1.weight, base + o + 2 * 4 * d * d)
+                    params.map_w16(blk.mlp.linear2.weight, base + o + 2 * (4 * d * d + mlp * d))
+                params.w16_is_f16 = self.prec == L.PREC_F16
+                self._w16_mapped = True
+        self._wkey = None
         blocks = [p for blk in m.blocks for p in blk.ordered_params()]
         self._lp = Fn._ptr_array(blocks)
         self._np = Fn._ptr_array([m.norm.weight, m.norm.bias])
@@ -225,6 +290,23 @@ class EncoderUnit:
             self._lg = Fn._ptr_array([p.grad for p in blocks])
             self._ng = Fn._ptr_array([m.norm.weight.grad, m.norm.bias.grad])
             self._eg = (C.c_void_p * 16)(*[None if p is None else p.grad.data_ptr() for p in head])
+
+    # ---- 16-bit weight copies --------------------------------------------------------------------------------------------------
+    def _weights_key(self):
+        """changes whenever torch has written one of the block weights: in place through the parameter (load_state_dict, p.mul_) or
+        through the flat buffer it views; the optimizer pass writes through raw pointers and keeps the copies current itself."""
+        return Fn.weights_stamp(self._wmats) + (-1 if self._flat is None else self._flat._version,)
+
+    def sync_weights(self) -> None:
+        key = self._weights_key()
+        if key != self._wkey:
+            L.call("hs_vit_cast_weights", C.byref(self.desc), self._lp, self.w16.data_ptr(), Fn._p(self.w16t), Fn._s())
+            self._wkey = key
+
+    def after_step(self) -> None:
+        """after an optimizer pass that wrote the straight copies (map_w16): the transposed ones from them (one launch, 16-bit source)."""
+        if self._w16_mapped and self.w16t is not None and self._wkey is not None:
+            L.call("hs_vit_cast_weights", C.byref(self.desc), None, self.w16.data_ptr(), self.w16t.data_ptr(), Fn._s())
 
     # ---- passes -----------------------------------------------------------------------------------------------------------
     def _embed_ws(self):
@@ -247,6 +329,7 @@ class EncoderUnit:
             Fn._need(image_2d)                                          # (vit.py:332 views it as (B, 32, -1))
             Fn._need_as(image_2d.view(self.B, 32, -1), "image_2d", (self.B, 32, self.d))
             _seeds(self.edesc, self.model.training)
+        self.sync_weights()
         ews, ewb = self._embed_ws()
         L.call("hs_embed_fwd", C.byref(self.edesc), patches.data_ptr(), Fn._p(image_2d) if self.scorer else None, self._ep,
                self.x0.data_ptr(), ews, ewb, s)
@@ -297,7 +380,7 @@ class PackerUnit:
     def flat_order(self) -> List[Tuple[str, nn.Parameter]]:
         return list(self.packer.named_parameters())
 
-    def bind(self) -> None:
+    def bind(self, params: Optional["FlatParams"] = None) -> None:
         pk, ra = self.packer, self.packer.resolution_attention
         ps = [pk.proj_mpls[0].weight, pk.proj_mpls[0].bias, pk.proj_mpls[2].weight, pk.proj_mpls[2].bias,
               ra.Wq.weight, ra.Wq.bias, ra.Wk.weight, ra.Wk.bias, ra.Wv.weight, ra.Wv.bias, ra.output_linear.weight,
@@ -356,21 +439,46 @@ class _Engine:
 
     loss_scale = 1.0
     prec = L.PREC_BF16
+    # keep_grads: leave the flat gradient (the parameters' .grad views) in place after optimizer_step() instead of zeroing it inside the
+    # optimizer sweep -- what a test or a notebook that inspects gradients after a full step wants.  Default: off (HF Trainer calls
+    # model.zero_grad() after every optimizer step too); HS_KEEP_GRADS=1 turns it on for every engine of the process (tests/conftest.py).
+    keep_grads = False
 
-    def _finish(self, entries, bounds, *, lr, weight_decay, max_grad_norm, group, grad_wire="fp32", grad_algo="allreduce"):
+    def _finish(self, entries, bounds, *, lr, weight_decay, max_grad_norm, group, grad_wire="fp32", grad_algo="allreduce",
+                keep_grads: Optional[bool] = None):
         self.params = FlatParams(entries, self.dev)
         self.flat, self.grad = self.params.flat, self.params.grad
         self.buckets = GradBuckets(self.grad, bounds, group, wire=grad_wire, algo=grad_algo)
         self.lr, self.wd, self.max_grad_norm = lr, weight_decay, max_grad_norm
         self.loss = torch.zeros(1, dtype=torch.float32, device=self.dev)
+        self.params.check_finite = self.prec == L.PREC_F16
+        self.keep_grads = bool(keep_grads) if keep_grads is not None else os.environ.get("HS_KEEP_GRADS") == "1"
 
     @property
     def step_no(self) -> int:
+        """optimizer steps applied (device counter: a synchronising read)."""
         return self.params.step_no
+
+    @property
+    def skipped_steps(self) -> int:
+        """fp16 steps whose gradient norm was not finite: the update was skipped on the device and the step does not count
+        (torch.cuda.amp.GradScaler semantics; a persistently overflowing loss_scale shows up HERE, not as silent non-training)."""
+        return self.params.skipped_steps
+
+    def _trained_units(self):
+        return [u for u in self.__dict__.values() if isinstance(u, EncoderUnit) and u.trainable and u._flat is self.params.flat]
+
+    def _begin_backward(self) -> None:
+        """the flat gradient must be zero when a backward starts accumulating into it: it is after an optimizer pass (zeroed inside
+        the sweep) and at construction; after a backward that was NOT followed by one (optimizer=False, keep_grads) it is cleared here."""
+        self.params.zero_grad()
+        self.params.grad_dirty = True
 
     def optimizer_step(self) -> None:
         self.params.step(lr=self.lr, weight_decay=self.wd, grad_scale=self.buckets.grad_scale / self.loss_scale,
-                         max_grad_norm=self.max_grad_norm)
+                         max_grad_norm=self.max_grad_norm, zero_grad=not self.keep_grads)
+        for u in self._trained_units():
+            u.after_step()
 
     def unscaled_grad(self) -> torch.Tensor:
         """the flat gradient without the loss scale (a copy when the scale is not 1)."""
@@ -423,7 +531,7 @@ class FlatEncoder(_Engine):
 
     def __init__(self, model, batch: int, *, lr=1e-4, weight_decay=0.1, max_grad_norm: Optional[float] = 1.0, n_buckets=4, group=None,
                  grad_wire="fp32", grad_algo="allreduce", recompute_mlp: bool = False, precision: str = "bf16",
-                 loss_scale: Optional[float] = None):
+                 loss_scale: Optional[float] = None, keep_grads: Optional[bool] = None):
         self.prec = _engine_prec(precision)
         self.unit = EncoderUnit(model, batch, trainable=True, recompute_mlp=recompute_mlp, prec=self.prec)
         self.model, self.dev, self.B = model, self.unit.dev, batch
@@ -435,8 +543,8 @@ class FlatEncoder(_Engine):
             off += _al(p.numel())
         self.layer_chunks, bounds = _encoder_bounds(self.unit, probe_names, offs, "", 0, off, n_buckets)
         self._finish(entries, bounds, lr=lr, weight_decay=weight_decay, max_grad_norm=max_grad_norm, group=group,
-                     grad_wire=grad_wire, grad_algo=grad_algo)
-        self.unit.bind()
+                     grad_wire=grad_wire, grad_algo=grad_algo, keep_grads=keep_grads)
+        self.unit.bind(self.params)
         u = self.unit
         self.patches = torch.empty(batch * u.Np, u.Pd, dtype=self.dtype16, device=self.dev)
         self.y, self.dy, self.hidden = u.y, u.dy, u.hidden
@@ -452,7 +560,7 @@ class FlatEncoder(_Engine):
     def backward(self, dy: torch.Tensor) -> None:
         """dy = d(loss)/dy x self.loss_scale (1 unless precision 'f16'): the flat gradient comes out with the same factor."""
         Fn._need_as(dy, "dy", self.y.shape)
-        self.grad.zero_()
+        self._begin_backward()
         self.unit.backward(self.patches, dy, self.layer_chunks, self.buckets.reduce)
         self.buckets.wait()
 
@@ -476,7 +584,7 @@ class DualEngine(_Engine):
     def __init__(self, tower: ViT3DTower_dual_encoders, packer1: VisualPacker_3d_phi_v3, packer2: VisualPacker_3d_phi_v3, batch: int, *,
                  lr=1e-4, weight_decay=0.1, max_grad_norm: Optional[float] = 1.0, n_buckets=4, group=None,
                  two_streams: Optional[bool] = None, grad_wire="fp32", grad_algo="allreduce", recompute_mlp: bool = False,
-                 precision: str = "bf16", loss_scale: Optional[float] = None):
+                 precision: str = "bf16", loss_scale: Optional[float] = None, keep_grads: Optional[bool] = None):
         """recompute_mlp: see EncoderUnit (activation memory 3.7 -> 2.5 GB per 256^3 volume for one more GEMM per layer in the backward).
         precision / loss_scale: see _Engine."""
         self.prec = _engine_prec(precision)
@@ -508,9 +616,9 @@ class DualEngine(_Engine):
         # bucket ids: 0 = packer 2, 1 = packer 1, then the 2E3 chunks, then the 3D-ViT chunks (each in backward-completion order)
         bounds = [(sp2, off), (sp, sp2)] + b2 + b1
         self._finish(entries, bounds, lr=lr, weight_decay=weight_decay, max_grad_norm=max_grad_norm, group=group,
-                     grad_wire=grad_wire, grad_algo=grad_algo)
+                     grad_wire=grad_wire, grad_algo=grad_algo, keep_grads=keep_grads)
         for u in (self.u1, self.u2, self.p1, self.p2):
-            u.bind()
+            u.bind(self.params)
         self.patches = torch.empty(batch * self.u1.Np, self.u1.Pd, dtype=self.dtype16, device=self.dev)
         self.out = torch.empty(batch, 2 * self.p1.cells, packer1.out_dim, dtype=torch.float32, device=self.dev)
         self.dout = torch.empty_like(self.out)
@@ -550,7 +658,7 @@ class DualEngine(_Engine):
     def backward(self, dout: torch.Tensor) -> None:
         """dout = d(loss)/d(out) x self.loss_scale (1 unless precision 'f16'): the flat gradient comes out with the same factor."""
         Fn._need_as(dout, "dout", self.out.shape)
-        self.grad.zero_()
+        self._begin_backward()
         n2 = len(self.chunks2)
         with self._fork():
             self.p2.backward(dout, self.u2.dy)

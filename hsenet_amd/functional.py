@@ -6,6 +6,7 @@ Every entry point requires CUDA(ROCm) tensors and raises otherwise — there is 
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional, Sequence
 
 import torch
@@ -576,15 +577,111 @@ def blocks_forward_inference(x0, H, mlp, prec, params, ln_eps=0.0, qkv_bias=None
     return y
 
 
+def _aligned_bytes(nbytes: int, device) -> "tuple[torch.Tensor, int]":
+    """a byte workspace whose used range starts on a 256-byte boundary (the drivers' requirement): (tensor, offset)."""
+    ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=device)
+    return ws, (-ws.data_ptr()) % 256
+
+
+def _flat_grads(tensors: Sequence[Optional[torch.Tensor]]):
+    """ONE zeroed fp32 buffer holding a gradient per tensor (each on a 64-element boundary) and the views of it in the tensors' shapes
+    (None stays None): one memset instead of one torch.zeros_like launch per parameter -- 134 per block stack.  autograd's AccumulateGrad
+    adopts such a view as the parameter's .grad as it stands (dense, matching strides) when .grad is None, and adds it in place otherwise."""
+    offs, off = [], 0
+    for t in tensors:
+        offs.append(off)
+        if t is not None:
+            off += (t.numel() + 63) // 64 * 64
+    dev = next(t.device for t in tensors if t is not None)
+    flat = torch.zeros(max(off, 64), dtype=torch.float32, device=dev)
+    return [None if t is None else flat[o:o + t.numel()].view(t.shape) for t, o in zip(tensors, offs)]
+
+
+# ---- when do 16-bit weight copies go stale?  Three witnesses, all cheap to read at every forward:
+#  (1) torch's version counters: in-place writes through the parameter or a detach()ed alias (load_state_dict, state_dict()[k].copy_(),
+#      p.mul_(), foreach optimizers);
+#  (2) optimizer steps: torch.optim's FUSED kernels (fused=True) update parameters WITHOUT touching the version counter, so a global
+#      optimizer post-step hook stamps every parameter the optimizer owns with a generation number;
+#  (3) invalidate_weight_copies(): for writes neither of them sees (`p.data.copy_()`-style edits through an alias with its own version
+#      counter, raw-pointer writes); HS_WEIGHT_CACHE=0 turns the caching off altogether (every forward re-casts, as before round 6).
+_step_gen = 0
+_forced_gen = 0
+_param_gen: dict = {}
+
+
+def _optimizer_stepped(opt, args, kwargs) -> None:
+    global _step_gen
+    _step_gen += 1
+    for g in opt.param_groups:
+        for p in g["params"]:
+            _param_gen[id(p)] = _step_gen
+
+
+from torch.optim.optimizer import register_optimizer_step_post_hook as _reg_post_hook  # noqa: E402
+
+_reg_post_hook(_optimizer_stepped)
+
+
+def invalidate_weight_copies() -> None:
+    """call after changing encoder weights in a way torch does not record (``p.data.mul_()``, a raw-pointer write): every cached 16-bit
+    weight copy of the module API and of the engines is re-made at its next forward."""
+    global _forced_gen
+    _forced_gen += 1
+
+
+def weights_stamp(mats: Sequence[torch.Tensor]):
+    """changes whenever one of `mats` may have changed (see above)."""
+    return (sum(w._version for w in mats), sum(_param_gen.get(id(w), 0) for w in mats), _forced_gen, mats[0].data_ptr(), mats[-1].data_ptr())
+
+
+class W16Cache:
+    """Per-module 16-bit copies of the block-stack weights for the MODULE API (hs_vit_desc.w16 / .w16t): made when a forward finds the
+    fp32 parameters changed (weights_stamp: version counters, optimizer steps, explicit invalidation), not on every call, and shared by
+    every forward in between (eval loops, the frozen towers of the MLLM finetune, gradient accumulation).  One set per operand format.
+    A backward pass can never meet copies newer than its forward's: the fp32 parameters are saved tensors of the same node, and torch
+    refuses to run a backward whose saved tensors were modified in place (an optimizer step between forward and backward is not a
+    thing)."""
+
+    def __init__(self):
+        self._sets = {}
+
+    def get(self, desc, mats: Sequence[torch.Tensor], lp, prec: int, want_t: bool):
+        """-> (w16, w16t or None) current for `mats` (the 4 weight matrices per layer; `lp` is the driver's pointer table of the L*11
+        block parameters)."""
+        key = weights_stamp(mats)
+        if os.environ.get("HS_WEIGHT_CACHE") == "0":
+            key = object()                                     # never equal: re-cast on every call
+        ent = self._sets.get(prec)
+        if ent is None or ent[0].device != mats[0].device:
+            n = L.load().hs_vit_weights_elems(C.byref(desc))
+            if n == 0:
+                raise L.HsError("unsupported encoder geometry")
+            ent = [torch.empty(n, dtype=_DT16[prec], device=mats[0].device), None, None, None]       # w16, w16t, key of w16, key of w16t
+            self._sets[prec] = ent
+        want_t = want_t and desc.d % 64 == 0 and desc.mlp % 64 == 0
+        if want_t and ent[1] is None:
+            ent[1] = torch.empty_like(ent[0])
+        need_s, need_t = ent[2] != key, want_t and ent[3] != key
+        if need_s or need_t:
+            if need_s:          # (the transposed set is re-made along with the straight one whenever it exists: one call)
+                L.call("hs_vit_cast_weights", C.byref(desc), lp, ent[0].data_ptr(), _p(ent[1]), _s())
+                ent[2] = key
+                ent[3] = key if ent[1] is not None else None
+            else:
+                L.call("hs_vit_cast_weights", C.byref(desc), None, ent[0].data_ptr(), ent[1].data_ptr(), _s())
+                ent[3] = key
+        return ent[0], (ent[1] if want_t else None)
+
+
 class BlocksFn(torch.autograd.Function):
     """The 12 x TransformerBlock hot loop + final norm (vit.py:464-467 / 352-355) as ONE fused enqueue.
 
     inputs: x0 [B,N,d] fp32, then L*11 block params in MONAI state-dict order, then norm.weight, norm.bias.
     returns (y [B,N,d], hidden [L,B,N,d]).  Gradients flow through y only (the reference's callers never
-    differentiate the hidden-state list)."""
+    differentiate the hidden-state list).  cache: the module's W16Cache (16-bit precisions) or None."""
 
     @staticmethod
-    def forward(ctx, x0, H, mlp, prec, need_grad, *params):
+    def forward(ctx, x0, H, mlp, prec, need_grad, cache, *params):
         x0 = _f32(x0).contiguous()
         params = tuple(p.contiguous() for p in params)
         _need(x0, *params)
@@ -593,19 +690,24 @@ class BlocksFn(torch.autograd.Function):
         # need_grad is decided by the caller (grad mode is off inside Function.forward, and
         # ctx.needs_input_grad ignores torch.no_grad())
         desc = L.VitDesc(B, N, d, H, mlp, Ln, prec, int(need_grad), 0.0, None)
+        lp, npar = _ptr_array(params[:-2]), _ptr_array(params[-2:])
+        w16 = w16t = None
+        if cache is not None and prec != L.PREC_F32:
+            mats = [params[l * 11 + i] for l in range(Ln) for i in (8, 6, 0, 2)]           # qkv, out_proj, linear1, linear2
+            w16, w16t = cache.get(desc, mats, lp, prec, bool(need_grad))
+            desc.w16, desc.w16t = w16.data_ptr(), _p(w16t)
         nbytes = L.load().hs_vit_workspace_bytes(C.byref(desc))
         if nbytes == 0:
             raise L.HsError(f"unsupported encoder geometry B={B} N={N} d={d} H={H} mlp={mlp} L={Ln}")
-        ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=x0.device)
-        off = (-ws.data_ptr()) % 256
+        ws, off = _aligned_bytes(nbytes, x0.device)
         y = torch.empty_like(x0)
         hidden = torch.empty(Ln, B, N, d, dtype=torch.float32, device=x0.device)
-        lp, npar = _ptr_array(params[:-2]), _ptr_array(params[-2:])
         L.call("hs_vit_blocks_fwd", C.byref(desc), x0.data_ptr(), lp, npar, y.data_ptr(), hidden.data_ptr(), ws.data_ptr() + off,
                nbytes, _s())
         if need_grad:
             ctx.save_for_backward(x0, hidden, ws, *params)
             ctx.desc, ctx.ws_off, ctx.nbytes = desc, off, nbytes
+            ctx.w16 = (w16, w16t)            # keeps the copies this graph was built on alive (a later precision switch makes new sets)
         ctx.mark_non_differentiable(hidden)
         return y, hidden
 
@@ -615,9 +717,123 @@ class BlocksFn(torch.autograd.Function):
         desc = ctx.desc
         dy = _f32(dy).contiguous()
         dx0 = torch.empty_like(x0)
-        grads = [torch.zeros_like(p) for p in params]
+        grads = _flat_grads(params)
         lp, npar = _ptr_array(params[:-2]), _ptr_array(params[-2:])
         lg, ng = _ptr_array(grads[:-2]), _ptr_array(grads[-2:])
         L.call("hs_vit_blocks_bwd", C.byref(desc), x0.data_ptr(), lp, npar, dy.data_ptr(), dx0.data_ptr(), lg, ng, hidden.data_ptr(),
                ws.data_ptr() + ctx.ws_off, ctx.nbytes, desc.L, 0, _s())
-        return (dx0, None, None, None, None, *grads)
+        return (dx0, None, None, None, None, None, *grads)
+
+
+def _opt_ptr_array(tensors: Sequence[Optional[torch.Tensor]], n: int):
+    arr = (C.c_void_p * n)()
+    for i, t in enumerate(tensors):
+        arr[i] = None if t is None else t.data_ptr()
+    return arr
+
+
+def _set_dropout(desc, train: bool) -> None:
+    """the two hard-coded Dropout(0.1) sites of regular_attention / resolution_attention_v3 (vit.py:46-47, spatial_pooling_projector.py:
+    58-59): in train() fresh Philox (seed, offset) pairs -- [0] the probabilities, [1] the pre-residual output, drawn in that order like
+    the unfused Functions do; eval(): off."""
+    if train:
+        desc.drop_p = 0.1
+        for i in range(2):
+            sd, of = draw_dropout_seed()
+            desc.seed[i], desc.offset[i] = sd, of
+    else:
+        desc.drop_p = 0.0
+
+
+def patchify16(vol: torch.Tensor, patch_size, prec: int) -> torch.Tensor:
+    """the rearranged patch matrix [B*Np, Pd] in the 16-bit operand format (hs_patchify): the A operand of the patch-embed Linear."""
+    vol = _f32(vol).contiguous()
+    _need(vol)
+    B, Cc, D, H, W = vol.shape
+    p1, p2, p3 = patch_size
+    Np, Pd = (D // p1) * (H // p2) * (W // p3), Cc * p1 * p2 * p3
+    patches = torch.empty(B * Np, Pd, dtype=_DT16[prec], device=vol.device)
+    L.call("hs_patchify", vol.data_ptr(), patches.data_ptr(), B, Cc, D, H, W, p1, p2, p3, prec, _s())
+    return patches
+
+
+class shared_patches:
+    """``with shared_patches(): ...`` -- inside the block every encoder that embeds the SAME volume tensor (the dual tower runs the 3D-ViT
+    and the 2E3-ViT on one volume, vit.py:926-930) reads one patch matrix: the volume is patchified once.  Keyed by the identity of the
+    volume tensor object + patch size + precision; nothing outlives the block."""
+    _active = None
+
+    def __enter__(self):
+        self._prev, shared_patches._active = shared_patches._active, {}
+        return self
+
+    def __exit__(self, *exc):
+        shared_patches._active = self._prev
+        return False
+
+    @staticmethod
+    def get(vol: torch.Tensor, patch_size, prec: int) -> torch.Tensor:
+        tab = shared_patches._active
+        if tab is None:
+            return patchify16(vol, patch_size, prec)
+        key = (id(vol), vol._version, tuple(patch_size), prec)
+        hit = tab.get(key)
+        if hit is None or hit[0] is not vol:
+            hit = (vol, patchify16(vol, patch_size, prec))
+            tab[key] = hit
+        return hit[1]
+
+
+class PackerFn(torch.autograd.Function):
+    """P2 VisualPacker_3d_phi_v3.forward (spatial_pooling_projector.py:138-146, incl. resolution_attention_v3 :62-83 and proj_mpls) as ONE
+    node over the fused packer driver: x [B, T, d] fp32 -> [B, cells, out_dim] fp32.  x may be the reference's `features[:, 1:]` view of an
+    encoder output (vit.py:934-936): the driver reads it in place (row offset + batch stride), no copy.  params: the 14 state-dict-order
+    tensors [proj_mpls.0.w, .0.b, proj_mpls.2.w, .2.b, Wq.w, .b, Wk.w, .b, Wv.w, .b, output_linear.w, .b, norm.w, .b].  16-bit precisions."""
+
+    @staticmethod
+    def forward(ctx, x, meta, *params):
+        grid, kernel, out_dim, prec, train, need_grad = meta
+        x = _f32(x)
+        B, T, d = x.shape
+        gd, gh, gw = grid
+        kd, kh, kw = kernel
+        if T != gd * gh * gw:
+            raise L.HsError(f"packer grid {tuple(grid)} does not match {T} input tokens")
+        off = 0
+        if not x.is_contiguous():
+            # rows [off, off + T) of a dense [B, off + T, d] tensor (the `[:, 1:]` patch selection)?  then read it where it lies
+            s0, s1, s2 = x.stride()
+            if s2 == 1 and s1 == d and s0 > T * d and (s0 - T * d) % d == 0 and x.storage_offset() >= s0 - T * d:
+                off = (s0 - T * d) // d
+            else:
+                x = x.contiguous()
+        params = tuple(p.contiguous() for p in params)
+        _need(*params)
+        if not x.is_cuda:
+            raise L.HsError("hsenet_amd kernels need tensors on an MI355X ('cuda') device; there is no CPU fallback")
+        cells = (gd // kd) * (gh // kh) * (gw // kw)
+        desc = L.PackerDesc(B, gd, gh, gw, kd, kh, kw, d, out_dim, off, (off + T) * d, cells * out_dim, int(need_grad), 0.0)
+        desc.prec = prec
+        _set_dropout(desc, train)
+        nbytes = L.load().hs_packer_workspace_bytes(C.byref(desc))
+        if nbytes == 0:
+            raise L.HsError("unsupported packer geometry")
+        ws, wo = _aligned_bytes(nbytes, x.device)
+        out = torch.empty(B, cells, out_dim, dtype=torch.float32, device=x.device)
+        L.call("hs_packer_fwd", C.byref(desc), x.data_ptr() - 4 * off * d, _ptr_array(params), out.data_ptr(), ws.data_ptr() + wo, nbytes, _s())
+        if need_grad:
+            ctx.save_for_backward(ws, *params)
+            ctx.desc, ctx.ws_off, ctx.nbytes, ctx.geom = desc, wo, nbytes, (B, T, d, off)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        ws, *params = ctx.saved_tensors
+        B, T, d, off = ctx.geom
+        dout = _f32(dout).contiguous()
+        _need(dout)
+        grads = _flat_grads(params)
+        dfeat = torch.empty(B, off + T, d, dtype=torch.float32, device=dout.device) if ctx.needs_input_grad[0] else None
+        L.call("hs_packer_bwd", C.byref(ctx.desc), dout.data_ptr(), _ptr_array(params), _ptr_array(grads), _p(dfeat),
+               ws.data_ptr() + ctx.ws_off, ctx.nbytes, _s())
+        return (None if dfeat is None else dfeat[:, off:], None, *grads)

@@ -82,7 +82,7 @@ class MRGStepEngine(_Engine):
             raise L.HsError("llm_loss(emb) must depend on the spliced image features (no gradient reached them)")
         dout = feats.grad.contiguous()
         Fn._need_as(dout, "d(image features)", self.out.shape)
-        self.grad.zero_()
+        self._begin_backward()
         self.p2.backward(dout, None)                  # towers frozen: no gradient w.r.t. the encoder outputs
         self.buckets.reduce(0)
         self.p1.backward(dout, None)

@@ -13,8 +13,8 @@ import torch
 import torch.nn as nn
 
 from . import functional as Fn
-from ._lib import HsError
-from .encoder import _prec
+from ._lib import HsError, PREC_F32
+from .encoder import _prec, _unfused
 
 
 class resolution_attention_v3(nn.Module):
@@ -73,9 +73,21 @@ class VisualPacker_3d_phi_v3(nn.Module):
         self.grid = tuple(grid) if grid is not None else (8, 16, 16)
         self.resolution_attention = resolution_attention_v3()
 
+    def _params14(self):
+        ra = self.resolution_attention
+        return [self.proj_mpls[0].weight, self.proj_mpls[0].bias, self.proj_mpls[2].weight, self.proj_mpls[2].bias,
+                ra.Wq.weight, ra.Wq.bias, ra.Wk.weight, ra.Wk.bias, ra.Wv.weight, ra.Wv.bias, ra.output_linear.weight,
+                ra.output_linear.bias, ra.norm.weight, ra.norm.bias]
+
     def forward(self, visual_inputs):
         prec = _prec(self)
         batch = visual_inputs.size(0)
+        if prec != PREC_F32 and not _unfused() and visual_inputs.dim() == 3 and visual_inputs.shape[-1] == self.in_dim:
+            # 16-bit precisions: the whole packer as ONE autograd node over the fused driver (hs_packer_fwd / hs_packer_bwd)
+            ps = self._params14()
+            need_grad = torch.is_grad_enabled() and (visual_inputs.requires_grad or any(p.requires_grad for p in ps))
+            meta = (self.grid, self.kernel_size, self.out_dim, prec, self.training, need_grad)
+            return Fn.PackerFn.apply(visual_inputs, meta, *ps)
         HR = visual_inputs.contiguous().view(batch, *self.grid, 768)                    # :140
         LR = Fn.Pool3dFn.apply(HR, self.kernel_size)                                    # :141 avg_pool3d
         cd, ch, cw = (g // k for g, k in zip(self.grid, self.kernel_size))
@@ -112,10 +124,10 @@ def encode_images(vision_tower, mm_projector, mm_projector2, images, images_2d):
     image_features = vision_tower(images, images_2d)
     if isinstance(image_features, tuple):
         f1, f2 = image_features
-        a = mm_projector(f1.contiguous())
-        b = (mm_projector2 if mm_projector2 is not None else mm_projector)(f2.contiguous())
+        a = mm_projector(f1)
+        b = (mm_projector2 if mm_projector2 is not None else mm_projector)(f2)
         return torch.cat([a, b], dim=1)
-    return mm_projector(image_features.contiguous())
+    return mm_projector(image_features)
 
 
 class LamedMetaForCausalLM:
@@ -143,18 +155,18 @@ class LamedMetaForCausalLM:
             n = image_features[-1].shape[1]
             if n in self.dual_token_counts:
                 ori, sec = image_features[0], image_features[1]
-                ori = model.mm_projector(ori.contiguous())
+                ori = model.mm_projector(ori)
                 try:
-                    sec = model.mm_projector2(sec.contiguous())
+                    sec = model.mm_projector2(sec)
                 except HsError:            # a HIP launch / shape / dtype failure is an error, not "no second projector"
                     raise
                 except Exception:          # (the reference's bare except, :130: no second projector -> the shared one)
-                    sec = model.mm_projector(sec.contiguous())
+                    sec = model.mm_projector(sec)
                 image_features = torch.cat([ori, sec], dim=1)
             elif n == 32:
                 image_features = model.mm_projector(image_features[0], image_features[1], text_feature)
         else:
-            image_features = model.mm_projector(image_features.contiguous())
+            image_features = model.mm_projector(image_features)
         return image_features
 
     def prepare_inputs_for_multimodal(self, input_ids, position_ids, attention_mask, past_key_values, labels, images, images_2d):

@@ -79,6 +79,13 @@ typedef struct hs_gemm_args {
 } hs_gemm_args;
 
 /* ---- library ------------------------------------------------------------------------------------------ */
+/* ABI version.  2 (round 6): every descriptor struct starts with `struct_size` (= sizeof of the struct the CALLER was compiled
+ * against; a library built from a different header refuses the call with HS_ERR_ARG instead of reading past a shorter struct);
+ * hs_vit_desc gained w16 / w16t (caller-owned 16-bit weight copies), hs_embed_desc / hs_packer_desc carry `prec` since round 5;
+ * hs_attn_bwd2, hs_attn_bwd_ws_bytes and hs_attn_bwd_ws_error (round 4) are gone, hs_attn_bwd's flag bits 4 and 8 are retired;
+ * new: hs_vit_weights_elems, hs_vit_cast_weights, hs_adamw_fused.  A consumer checks hs_version() == HS_ABI_VERSION at load time
+ * (hsenet_amd/_lib.py does). */
+#define HS_ABI_VERSION 2
 int hs_version(void);
 /* 16 hex digits: content hash of every source, header and compiler flag the loaded library was built from
  * (hsenet_amd/build.py:source_id).  __graft_entry__.build() and smoke() compare it with the tree: a stale .so is an error. */
@@ -242,6 +249,7 @@ int hs_prof_count(void);
  * norm_params: [norm.weight, norm.bias].  x0: tokens [B][N][d] fp32.  y: [B][N][d] fp32 (post-norm).
  * hidden: [L][B][N][d] fp32 (the 12 hidden states the reference returns).  ws: workspace. */
 typedef struct hs_vit_desc {
+    uint32_t struct_size; /* sizeof(hs_vit_desc) of the caller's header (ABI 2) */
     int B, N, d, H, mlp, L;
     int prec;            /* HS_PREC_* */
     int save_for_bwd;    /* 1: keep per-layer activations in ws for hs_vit_blocks_bwd; 2 (HS_PREC_BF16): the same WITHOUT the MLP's two
@@ -249,9 +257,22 @@ typedef struct hs_vit_desc {
     float ln_eps;        /* LayerNorm epsilon; 0 = 1e-5 (MONAI / nn.LayerNorm default).  timm's ViT (the 2-D branch) uses 1e-6 */
     const float* const* qkv_bias;   /* NULL (MONAI SABlock, qkv_bias=False), or L device pointers to the [3d] bias of each
                                        layer's qkv Linear (timm ViT, forward only: hs_vit_blocks_bwd rejects it) */
+    /* 16-bit precisions only: CALLER-OWNED 16-bit copies of the four weight matrices of every layer, hs_vit_weights_elems(desc)
+     * elements each, layer l at l * (elems / L) in the order [Wqkv | Wo | W1 | W2]; w16 = the matrices as stored ([out][in]), w16t =
+     * their transposes ([in][out]: the dgrads' NT operand).  NULL (either): the driver re-makes that copy inside `ws` on every call
+     * (forward: w16; backward: w16t of the layers it runs).  Non-NULL: the driver reads it and casts nothing -- the caller keeps it
+     * equal to the fp32 parameters (hs_vit_cast_weights after a parameter change; hs_adamw_fused writes w16 as it updates). */
+    const void* w16;
+    const void* w16t;
 } hs_vit_desc;
 
 size_t hs_vit_workspace_bytes(const hs_vit_desc* desc);
+/* elements of ONE 16-bit weight-copy set (L * (4 d^2 + 2 d mlp)); 0 for a bad descriptor or HS_PREC_F32 */
+size_t hs_vit_weights_elems(const hs_vit_desc* desc);
+/* fill caller-owned weight copies in the descriptor's 16-bit format: w16 (straight) and / or w16t (transposed; d and mlp multiples
+ * of 64) from the fp32 layer_params (MONAI order, as hs_vit_blocks_fwd takes them).  layer_params == NULL with both w16 and w16t
+ * given: w16t is made from w16 (16-bit source: what an optimizer that already wrote w16 needs).  One or two launches. */
+int hs_vit_cast_weights(const hs_vit_desc* desc, const float* const* layer_params, void* w16, void* w16t, void* stream);
 int hs_vit_blocks_fwd(const hs_vit_desc* desc, const float* x0, const float* const* layer_params,
                       const float* const* norm_params, float* y, float* hidden, void* ws, size_t ws_bytes, void* stream);
 /* backward of the above (either precision; the save_for_bwd=1 forward must have run on the same ws).
@@ -280,6 +301,7 @@ int hs_vit_blocks_bwd(const hs_vit_desc* desc, const float* x0, const float* con
  * seed/offset: Philox streams of the two dropout sites [probabilities, pre-residual output]; the backward call must get the
  * same descriptor as the forward call it differentiates. */
 typedef struct hs_embed_desc {
+    uint32_t struct_size; /* sizeof(hs_embed_desc) of the caller's header (ABI 2) */
     int B, Np, Pd, d;
     int has_cls;          /* classification=True: row 0 of every volume's tokens is cls_token */
     int scorer;           /* 0 = ViT_stage1, 1 = ViT_stage2 (slice-guided scorer) */
@@ -309,6 +331,7 @@ int hs_embed_bwd(const hs_embed_desc* desc, const void* patches, const float* dt
  *   gradients accumulate (caller zeroes).  dfeat (optional): gradient w.r.t. feat, same layout as feat, rows below
  *   in_row_offset zeroed (dense [B][in_row_offset + T][d]: requires in_batch_stride == (in_row_offset + T)*d). */
 typedef struct hs_packer_desc {
+    uint32_t struct_size; /* sizeof(hs_packer_desc) of the caller's header (ABI 2) */
     int B, gd, gh, gw, kd, kh, kw, d, out_dim;
     int in_row_offset;
     int64_t in_batch_stride, out_batch_stride;
@@ -340,6 +363,21 @@ int hs_sumsq(const float* x, float* out, float* scratch, int64_t n, void* stream
 int hs_adamw_masked(float* p, const float* g, float* m, float* v, const unsigned char* decay_mask, int64_t n, float lr, float beta1,
                     float beta2, float eps, float weight_decay, float grad_scale, const float* grad_sumsq, float max_grad_norm,
                     int step, void* stream);
+
+/* hs_adamw_fused (round 6): the optimizer pass of a train step as ONE sweep over the flat buffers -- hs_adamw_masked plus
+ *  (a) zero_grad != 0: g is zeroed behind the read (the next backward accumulates into it: no separate memset);
+ *  (b) w16_table (device, optional): one destination ADDRESS per 64-element chunk of the flat buffer (0 = none); the updated
+ *      parameters of a listed chunk are also written there as 64 bf16 (w16_is_f16 = 0) or fp16 (1) values -- the 16-bit weight
+ *      copies the next forward multiplies with (hs_vit_desc.w16), so that no cast pass re-reads the fp32 masters;
+ *  (c) state (device, REQUIRED, 8 x 4 bytes, caller zeroes it once): [0] int32 steps applied, [1] int32 steps SKIPPED, [2..7]
+ *      scratch.  The step number of the bias corrections is state[0] + 1 -- kept on the device, so that a skipped step (grad_sumsq
+ *      not finite: an fp16 backward that overflowed its loss scale) does not advance it (torch.cuda.amp.GradScaler semantics) and
+ *      the host can read both counters whenever it likes without a sync inside the step.
+ *  grad_sumsq (device): squared norm of the summed gradient; required when max_grad_norm > 0, optional otherwise (given without
+ *  clipping it only arms the non-finite skip).  n must be a multiple of 64. */
+int hs_adamw_fused(float* p, float* g, float* m, float* v, const unsigned char* decay_mask, int64_t n, float lr, float beta1,
+                   float beta2, float eps, float weight_decay, float grad_scale, const float* grad_sumsq, float max_grad_norm,
+                   int zero_grad, const uint64_t* w16_table, int w16_is_f16, int32_t* state, void* stream);
 
 /* dst[b*dst_batch_stride + r*d + :] = src[b*src_batch_stride + r*d + :] for r < R, as fp32 and/or bf16: a block of R rows per batch
  * entry between two strided [B][.][d] tensors (the cls row of every volume: R = 1, src stride N*d = `[:, 0]`, CLIP_stage1.py:117;

@@ -36,7 +36,7 @@ def _zeros(name):
 def test_null_arguments_are_refused(name):
     """every compute entry point: all pointers NULL, all sizes 0 -> negative status (or 0 bytes for the workspace queries)."""
     rc = getattr(L.load(), name)(*_zeros(name))
-    if name.endswith("_workspace_bytes") or name.endswith("_ws_bytes"):
+    if name.endswith("_workspace_bytes") or name.endswith("_ws_bytes") or name.endswith("_elems"):
         assert rc == 0
     else:
         assert rc in (L.HS_ERR_ARG, L.HS_ERR_SHAPE), (name, rc)
@@ -145,6 +145,57 @@ def test_driver_descriptor_checks():
     assert lib.hs_mse_grad_scaled(FAKE, FAKE, None, 64, 0.0, None) == L.HS_ERR_ARG                       # the loss scale must be positive
     assert lib.hs_layernorm_bwd(FAKE, 3, FAKE, None, FAKE, FAKE, FAKE, None, FAKE, None, None, None, None, 8, 64, None) == L.HS_ERR_ARG
     assert lib.hs_colsum(FAKE, 3, FAKE, 8, 64, 64, None) == L.HS_ERR_ARG
+
+
+@no_gpu_only
+def test_abi2_struct_size_weight_copies_and_fused_adamw_checks():
+    """ABI 2 (round 6): descriptors carry the size of the struct their caller was compiled against; a mismatch is refused before
+    any field is read.  Caller-owned 16-bit weight copies and the fused optimizer sweep validate their arguments."""
+    lib = L.load()
+    assert lib.hs_version() == L.ABI_VERSION == 2
+    tbl = (C.c_void_p * 64)(*([FAKE] * 64))
+    for mk, query in ((lambda: L.VitDesc(1, 33, 768, 12, 3072, 2, L.PREC_BF16, 1, 0.0, None), lib.hs_vit_workspace_bytes),
+                      (lambda: L.EmbedDesc(1, 32, 1024, 768, 1, 1, 32, 1, 0.0), lib.hs_embed_workspace_bytes),
+                      (lambda: L.PackerDesc(2, 2, 4, 4, 1, 2, 2, 768, 256, 1, 33 * 768, 2 * 8 * 256, 1, 0.0), lib.hs_packer_workspace_bytes)):
+        d = mk()
+        assert d.struct_size == C.sizeof(d) and query(C.byref(d)) > 0
+        for wrong in (0, C.sizeof(d) - 4, C.sizeof(d) + 8):        # an older / newer header's struct
+            d.struct_size = wrong
+            assert query(C.byref(d)) == 0
+    v = L.VitDesc(1, 33, 768, 12, 3072, 2, L.PREC_BF16, 1, 0.0, None)
+    v.struct_size -= 16                                            # the round-5 layout (no w16 / w16t): refused, not read past
+    assert lib.hs_vit_blocks_fwd(C.byref(v), FAKE, tbl, tbl, FAKE, FAKE, 1 << 20, 1 << 40, None) == L.HS_ERR_ARG
+    # caller-owned weight copies: 16-bit precisions only, 16-byte aligned, transposed copies need 64-multiples; they shrink the workspace
+    ok = L.VitDesc(1, 33, 768, 12, 3072, 2, L.PREC_BF16, 1, 0.0, None)
+    need = lib.hs_vit_workspace_bytes(C.byref(ok))
+    n = lib.hs_vit_weights_elems(C.byref(ok))
+    assert n == 2 * (4 * 768 * 768 + 2 * 768 * 3072)
+    ok.w16, ok.w16t = FAKE, FAKE
+    assert lib.hs_vit_workspace_bytes(C.byref(ok)) == need - 2 * (2 * n)
+    ok.w16 = FAKE + 8
+    assert lib.hs_vit_workspace_bytes(C.byref(ok)) == 0
+    f32 = L.VitDesc(1, 33, 768, 12, 3072, 2, L.PREC_F32, 1, 0.0, None)
+    assert lib.hs_vit_weights_elems(C.byref(f32)) == 0
+    f32.w16 = FAKE
+    assert lib.hs_vit_workspace_bytes(C.byref(f32)) == 0
+    odd = L.VitDesc(1, 33, 64, 1, 72, 2, L.PREC_BF16, 1, 0.0, None)                      # mlp not a multiple of 64: no transposed copies
+    assert lib.hs_vit_workspace_bytes(C.byref(odd)) > 0
+    assert lib.hs_vit_cast_weights(C.byref(odd), tbl, FAKE, FAKE, None) == L.HS_ERR_SHAPE
+    plain = L.VitDesc(1, 33, 768, 12, 3072, 2, L.PREC_BF16, 1, 0.0, None)
+    assert lib.hs_vit_cast_weights(C.byref(plain), tbl, None, None, None) == L.HS_ERR_ARG           # nothing to make
+    assert lib.hs_vit_cast_weights(C.byref(plain), None, FAKE, None, None) == L.HS_ERR_ARG          # no source for the straight copy
+    assert lib.hs_vit_cast_weights(C.byref(plain), None, None, FAKE, None) == L.HS_ERR_ARG
+    assert lib.hs_vit_cast_weights(C.byref(f32), tbl, FAKE, None, None) < 0
+    # hs_adamw_fused: whole 64-element chunks, a state block, a norm when clipping, a positive gradient scale
+    P = FAKE
+    args = lambda **k: [k.get("p", P), P, P, P, None, k.get("n", 128), 1e-3, 0.9, 0.999, 1e-8, 0.1, k.get("gs", 1.0), k.get("gsq", None),
+                        k.get("mx", 0.0), 1, None, 0, k.get("st", P), None]
+    assert lib.hs_adamw_fused(*args(n=100)) == L.HS_ERR_SHAPE
+    assert lib.hs_adamw_fused(*args(n=0)) == L.HS_ERR_SHAPE
+    assert lib.hs_adamw_fused(*args(st=None)) == L.HS_ERR_ARG
+    assert lib.hs_adamw_fused(*args(mx=1.0)) == L.HS_ERR_ARG                             # clipping without the gradient norm
+    assert lib.hs_adamw_fused(*args(gs=0.0)) == L.HS_ERR_ARG
+    assert lib.hs_adamw_fused(*args(p=P + 4)) == L.HS_ERR_SHAPE
 
 
 def test_debug_selector_is_inert_in_the_product_build(capfd):
