@@ -755,6 +755,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     finite = bool(torch.isfinite(eng.flat).all().item())
+    replicas_equal = None
+    if world > 1:        # data-parallel replicas must hold the SAME parameters after the timed steps: a checksum's max and min over ranks
+        chk = eng.flat.double().sum().reshape(1)
+        lo_, hi_ = chk.clone(), chk.clone()
+        dist.all_reduce(lo_, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi_, op=dist.ReduceOp.MAX)
+        replicas_equal = bool((lo_ == hi_).item())
 
     # ---- instrumented pass: per-kernel-class HIP-event timing on the launch stream, same steps --------------
     # EVERY rank runs these steps (they contain the gradient all-reduces); only rank 0 records and reads the timers.
@@ -880,6 +887,7 @@ def main():
         "model_tflops": round(vols_per_s * fb / 1e12, 2),
         "mfma_roofline_frac_end_to_end": round(vols_per_s * fb / 1e12 / (PEAK_BF16_TFLOPS * world), 4),
         "outputs_finite": finite,
+        **({"replicas_equal": replicas_equal} if replicas_equal is not None else {}),
         "peak_hbm_gb": round((torch.cuda.max_memory_allocated(dev) - (reserved.numel() if reserved is not None else 0)) / 1e9, 2),
     }
     if os.environ.get("HS_RECOMPUTE_MLP") and a.workload in ("dual256", "native_dual"):

@@ -22,7 +22,7 @@ class GradBuckets:
     * ``wire="fp32"`` (default, the reference's DDP setting) or ``"bf16"``: the bucket is cast to bf16, summed across the ranks in
       bf16 and written back to the fp32 gradient — half the bytes on every xGMI link (824 -> 412 MB per dual-encoder step).  Every
       rank receives the same summed values, so replicas stay identical; the sum differs from the fp32 exchange by bf16 rounding
-      (relative L2 error ~2e-3 of the gradient, tests/test_dp_gloo.py).
+      (relative L2 error of the gradient ~2e-3 at 2 ranks, 4e-3 at 8: the bf16 sum rounds after every addition; tests/test_dp_gloo.py).
     * ``algo="allreduce"`` (default: one ``all_reduce`` per bucket, RCCL picks ring / tree), ``"rs_ag"`` (an explicit
       ``reduce_scatter_tensor`` + ``all_gather_into_tensor`` pair: on 8 fully connected MI355X every rank then talks to its 7 peers
       at once, SURVEY.md section 5: ~1.2 ms instead of ~8 ms of ring time for 824 MB), or ``"auto"`` (``rs_ag`` for buckets of at

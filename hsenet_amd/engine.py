@@ -135,6 +135,14 @@ class FlatParams:
         s = Fn._s()
         gsq = None
         clip = max_grad_norm is not None and max_grad_norm > 0
+        if os.environ.get("HS_LEGACY_STEP") == "1":            # (A/B runs only: round 5's optimizer pass, host-side step counter)
+            self._legacy_step = getattr(self, "_legacy_step", 0) + 1
+            if clip:
+                L.call("hs_sumsq", self.grad.data_ptr(), self.gsq.data_ptr(), self._gsq_scratch.data_ptr(), self.total, s)
+            L.call("hs_adamw_masked", self.flat.data_ptr(), self.grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
+                   self.decay_mask.data_ptr(), self.total, lr, betas[0], betas[1], eps, weight_decay, grad_scale,
+                   self.gsq.data_ptr() if clip else None, float(max_grad_norm) if clip else 0.0, self._legacy_step, s)
+            return
         if clip or self.check_finite:
             L.call("hs_sumsq", self.grad.data_ptr(), self.gsq.data_ptr(), self._gsq_scratch.data_ptr(), self.total, s)
             gsq = self.gsq.data_ptr()
@@ -231,7 +239,12 @@ class EncoderUnit:
         self.w16 = torch.empty(self.w_elems, dtype=dt16, device=self.dev)
         nt = trainable and self.d % 64 == 0 and model.mlp_dim % 64 == 0
         self.w16t = torch.empty(self.w_elems, dtype=dt16, device=self.dev) if nt else None
-        self.desc.w16, self.desc.w16t = self.w16.data_ptr(), Fn._p(self.w16t)
+        # HS_LEGACY_STEP=1 (A/B runs only): the round-5 step -- weight copies re-made inside the workspace by every forward / backward call,
+        # gradient zeroed by a memset, hs_adamw_masked
+        self.legacy = os.environ.get("HS_LEGACY_STEP") == "1"
+        if self.legacy:
+            self.w16 = self.w16t = None
+        self.desc.w16, self.desc.w16t = Fn._p(self.w16), Fn._p(self.w16t)
         self._wmats = [w for blk in model.blocks for w in (blk.attn.qkv.weight, blk.attn.out_proj.weight, blk.mlp.linear1.weight, blk.mlp.linear2.weight)]
         self._wkey, self._flat, self._w16_mapped = None, None, False
         self.ws_bytes = lib.hs_vit_workspace_bytes(C.byref(self.desc))
@@ -266,7 +279,7 @@ class EncoderUnit:
         m = self.model
         if params is not None:
             self._flat = params.flat
-            if self.trainable:
+            if self.trainable and not self.legacy:
                 d, mlp, per = self.d, m.mlp_dim, self.w_elems // self.Ln
                 base = self.w16.data_ptr()
                 for l, blk in enumerate(m.blocks):
@@ -298,6 +311,8 @@ class EncoderUnit:
         return Fn.weights_stamp(self._wmats) + (-1 if self._flat is None else self._flat._version,)
 
     def sync_weights(self) -> None:
+        if self.legacy:
+            return
         key = self._weights_key()
         if key != self._wkey:
             L.call("hs_vit_cast_weights", C.byref(self.desc), self._lp, self.w16.data_ptr(), Fn._p(self.w16t), Fn._s())

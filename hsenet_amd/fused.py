@@ -110,46 +110,50 @@ class EncJob:
                self.ws.data_ptr() + self.ws_off, self.ws_bytes, s)
 
     def owned(self, lo: int, hi: int) -> List[Optional[torch.Tensor]]:
-        """the parameters whose gradients the backward of layers [lo, hi) COMPLETES, as a list in a fixed order: the layers' tensors
-        without linear2.bias of layer hi - 1 (unless hi == L: then the final norm and that bias too) plus linear2.bias of layer lo - 1;
-        for lo == 0 also the 16 embedding-driver slots (None where the module has none)."""
-        out = []
-        for l in range(lo, hi):
-            for i in range(11):
-                if i == 3 and l == hi - 1 and hi < self.Ln:
-                    continue
-                out.append(self.blocks[l * 11 + i])
-        if hi == self.Ln:
-            out += self.norm
-        if lo > 0:
-            out.append(self.blocks[(lo - 1) * 11 + 3])
-        else:
-            out += self.head
-        return out
+        """the parameters whose gradients the backward of layers [lo, hi) COMPLETES, in owned_slots' order (None = an embedding-driver
+        slot this module does not have)."""
+        src = {"b": lambda l, i: self.blocks[l * 11 + i], "n": lambda _, i: self.norm[i], "h": lambda _, i: self.head[i]}
+        return [src[kind](l, i) for kind, l, i in owned_slots(self.Ln, lo, hi)]
 
     def backward(self, lo: int, hi: int, dy: Optional[torch.Tensor], grads: Sequence[Optional[torch.Tensor]]) -> None:
         """layers [lo, hi) (+ the final norm for hi == L, the embedding for lo == 0); grads: zeroed tensors in owned(lo, hi)'s order."""
-        it = iter(grads)
-        lg = (C.c_void_p * (self.Ln * 11))()
-        for l in range(lo, hi):
-            for i in range(11):
-                if i == 3 and l == hi - 1 and hi < self.Ln:
-                    continue
-                lg[l * 11 + i] = next(it).data_ptr()
-        ng = (C.c_void_p * 2)()
-        if hi == self.Ln:
-            ng[0], ng[1] = next(it).data_ptr(), next(it).data_ptr()
-        eg = None
-        if lo > 0:
-            lg[(lo - 1) * 11 + 3] = next(it).data_ptr()
-        else:
-            eg = Fn._opt_ptr_array(list(it), 16)
+        lg, ng, eg = (C.c_void_p * (self.Ln * 11))(), (C.c_void_p * 2)(), (C.c_void_p * 16)()
+        for (kind, l, i), g in zip(owned_slots(self.Ln, lo, hi), grads):
+            if g is None:
+                continue
+            if kind == "b":
+                lg[l * 11 + i] = g.data_ptr()
+            elif kind == "n":
+                ng[i] = g.data_ptr()
+            else:
+                eg[i] = g.data_ptr()
         s = Fn._s()
         L.call("hs_vit_blocks_bwd", C.byref(self.desc), self.x0.data_ptr(), self.lp, self.np_, Fn._p(dy), Fn._p(self.dx0), lg, ng,
                self.hidden.data_ptr(), self.ws.data_ptr() + self.ws_off, self.ws_bytes, hi, lo, s)
         if lo == 0:
             L.call("hs_embed_bwd", C.byref(self.edesc), self.patches.data_ptr(), self.dx0.data_ptr(), self.ep, eg,
                    self.ews.data_ptr() + self.ews_off, self.ews_bytes, s)
+
+
+def owned_slots(n_layers: int, lo: int, hi: int):
+    """[(kind, layer, index)] of the parameter gradients that the backward of layers [lo, hi) completes, in a fixed order:
+    ('b', l, i) block parameter i (MONAI order, TransformerBlock.ordered_params) of layer l; ('n', 0, i) the final norm's weight / bias;
+    ('h', 0, i) slot i of the embedding driver's 16.  A layer's linear2.bias (i = 3) belongs to the chunk ABOVE it: its gradient is the
+    column sum of the residual-stream gradient entering the layer, which the driver emits from the LayerNorm backward of layer l + 1 (the
+    final norm's for the top layer)."""
+    out = []
+    for l in range(lo, hi):
+        for i in range(11):
+            if i == 3 and l == hi - 1 and hi < n_layers:
+                continue
+            out.append(("b", l, i))
+    if hi == n_layers:
+        out += [("n", 0, 0), ("n", 0, 1)]
+    if lo > 0:
+        out.append(("b", lo - 1, 3))
+    else:
+        out += [("h", 0, i) for i in range(16)]
+    return out
 
 
 def _fork(jobs: Sequence[EncJob], fn, two_streams: bool) -> None:

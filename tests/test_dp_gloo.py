@@ -92,7 +92,8 @@ def _wire_and_algo(rank, world):
             assert all(torch.equal(o, flat) for o in others), (wire, algo)           # replica-identical
             err = float((flat.double() - ref).norm() / ref.norm())
             worst[(wire, algo)] = err
-            assert err < (1e-6 if wire == "fp32" else 4e-3), (wire, algo, err)
+            # (a bf16 SUM over the ranks rounds after every addition: ~2e-3 at 2 ranks, 4.1e-3 at the reference's 8)
+            assert err < (1e-6 if wire == "fp32" else 1e-3 + 2e-3 * world ** 0.5), (wire, algo, err)
     if rank == 0:
         print("GradBuckets relative error vs the exact sum:", {f"{k[0]}/{k[1]}": f"{v:.1e}" for k, v in worst.items()})
     # auto at two ranks or for small buckets falls back to one all-reduce; a muted instance launches nothing
@@ -112,9 +113,14 @@ def test_grad_buckets_allreduce_gloo():
     _run(_buckets)
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])      # 8 = the reference's node (README.md:78-105): 1003 elements pad to 1008 for rs_ag
 def test_grad_buckets_wire_formats_and_algorithms_gloo(world):
     _run(_wire_and_algo, world)
+
+
+def test_gather_features_world8_gloo():
+    """C2 at the reference's world size: one fused all-gather of 8 x [3, 16] features, backward = this rank's slice of the summed gradient."""
+    _run(_gather, 8)
 
 
 def test_gather_features_gloo():
