@@ -956,8 +956,8 @@ def main():
                 continue
             engs, _, _ = build_engine(a.workload, geom, bsmall, dev, precision=a.precision)
             vs_, ss_ = inputs(bsmall)
-            ns = max(5, a.steps)
-            dts = timed_run(engs, needs_2d, vs_, ss_, ns, max(2, a.warmup), sync)[0]
+            ns = max(5, a.steps, 36 // bsmall)                    # ~0.5 s of timed work: a one-volume step is 15 ms
+            dts = timed_run(engs, needs_2d, vs_, ss_, ns, max(3, a.warmup), sync)[0]
             out[f"batch{bsmall}"] = {"value": round(bsmall * ns / dts, 3), "unit": "CT-volumes/sec", "ms_per_step": round(1e3 * dts / ns, 3), "steps": ns,
                                      "batch_per_gpu": bsmall, "what": what[bsmall],
                                      "mfma_roofline_frac_end_to_end": round(bsmall * ns / dts * fb / 1e12 / PEAK_BF16_TFLOPS, 4)}
@@ -970,7 +970,7 @@ def main():
         eng = vols = slices = step = None
         torch.cuda.empty_cache()
         from bench_module_api import module_api_train
-        mat = module_api_train(dev, batches=(1, 3, 13), precisions=("bf16", "f16"), steps=5, warmup=2, geom=geom, engine_rates=engine_rates)
+        mat = module_api_train(dev, batches=(1, 3, 13), precisions=("bf16", "f16"), steps=6, warmup=3, geom=geom, engine_rates=engine_rates)
         out["module_api_train"] = mat
         # the batch sweep as one object (volumes/s of the ENGINE step at each per-GPU batch; 13 from the leg above, the headline batch last)
         sweep = {str(b): out[f"batch{b}"]["value"] for b in (1, 2, 3) if f"batch{b}" in out}

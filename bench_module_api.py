@@ -143,10 +143,16 @@ def module_rate(geom, batch, dev, precision, steps, warmup, vols, slices):
     return batch * steps / dt, fin
 
 
-def module_api_train(dev, batches=(1, 3, 13), precisions=("bf16", "f16"), steps=6, warmup=2, geom=GEOM, engine_rates=None):
+def steps_for(batch, steps):
+    """timed steps at this per-GPU batch: at least `steps`, and enough of them for ~0.5 s of timed work (a one-volume step is 15 ms:
+    five of them are inside the run-to-run noise)."""
+    return max(steps, int(round(36.0 / batch)))
+
+
+def module_api_train(dev, batches=(1, 3, 13), precisions=("bf16", "f16"), steps=6, warmup=3, geom=GEOM, engine_rates=None):
     """the bench leg: {"b<batch>": {"bf16": {module, engine, vs_engine}, "f16": {...}}}.  engine_rates: {(batch, precision): volumes/s}
     already measured by the caller on this box (bench.py's batch legs) are reused instead of being timed again."""
-    res = {"unit": "CT-volumes/sec", "steps": steps, "warmup": warmup,
+    res = {"unit": "CT-volumes/sec", "steps": {f"b{b}": steps_for(b, steps) for b in batches}, "warmup": warmup,
            "what": "BASELINE configs[2] step through the DROP-IN module API the reference's scripts call: hsenet_amd.encode_images(tower, "
                    "packer, packer2, vol, slices) in train(), loss = out.square().mean(), loss.backward() (torch autograd over the C-ABI "
                    "Functions), torch.nn.utils.clip_grad_norm_(1.0), torch.optim.AdamW(fused=True, HF Trainer's decay / no-decay groups), "
@@ -157,11 +163,11 @@ def module_api_train(dev, batches=(1, 3, 13), precisions=("bf16", "f16"), steps=
         row = {}
         for prec in precisions:
             torch.cuda.empty_cache()
-            mod, fin = module_rate(geom, b, dev, prec, steps, warmup, vols, slices)
+            mod, fin = module_rate(geom, b, dev, prec, steps_for(b, steps), warmup, vols, slices)
             torch.cuda.empty_cache()
             eng = (engine_rates or {}).get((b, prec))
             if eng is None:
-                eng, _ = engine_rate(geom, b, dev, prec, steps, warmup, vols, slices)
+                eng, _ = engine_rate(geom, b, dev, prec, steps_for(b, steps), warmup, vols, slices)
             row[prec] = {"module": round(mod, 3), "engine": round(eng, 3), "vs_engine": round(mod / eng, 4), "finite": fin}
             print(f"[module_api_train] batch {b} {prec}: module {mod:.2f} engine {eng:.2f} volumes/s ({mod / eng:.3f})", file=sys.stderr, flush=True)
         res[f"b{b}"] = row
@@ -175,7 +181,7 @@ def main():
     ap.add_argument("--batch", type=int, nargs="+", default=[1, 3, 13])
     ap.add_argument("--precision", nargs="+", default=["bf16", "f16"], choices=["bf16", "f16"])
     ap.add_argument("--steps", type=int, default=6)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=3)
     a = ap.parse_args()
     if not torch.cuda.is_available():
         sys.exit("bench_module_api.py needs an MI355X: no GPU visible (the HIP path has no CPU fallback)")
