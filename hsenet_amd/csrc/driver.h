@@ -11,6 +11,9 @@ int hs_layernorm_fwd16(const float* x, const float* resid, const float* gamma, c
 // fp16 with f16 != 0) or, with src_is_16, already 16-bit (bits pass through)                                      // small.hip
 int hs_transpose16_multi(const void* const* src, int src_is_16, void* const* dst, const int* R, const int* C, int count, void* stream, int f16 = 0);
 
+// y16 = cast16(a (+ b)) [M][N] and column sums of the rounded values: columns [0, nsplit) += into cs_lo, [nsplit, N) into cs_hi   // small.hip
+int hs_addcast_colsum(const float* a, const float* b, void* y16, float* cs_lo, float* cs_hi, int M, int N, int nsplit, int f16, void* stream);
+
 namespace hsdrv {
 
 inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }

@@ -55,29 +55,6 @@ __global__ __launch_bounds__(256) void rows_scatter_kernel(const float* __restri
     if (r >= r0 && r < r0 + R) v = *(const f32x4*)(src + (b * R + (r - r0)) * d + ch * 4);
     *(f32x4*)(dst + row * d + ch * 4) = v;
 }
-// out = a (+ b) as fp32 and/or bf16
-template <bool F16>
-__global__ __launch_bounds__(256) void add_cast_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ of,
-                                                       bf16_t* __restrict__ ob, long n4) {
-    const long g = (long)blockIdx.x * 256 + threadIdx.x;
-    if (g >= n4) return;
-    f32x4 v = *(const f32x4*)(a + g * 4);
-    if (b) v += *(const f32x4*)(b + g * 4);
-    if (of) *(f32x4*)(of + g * 4) = v;
-    if (ob) {
-        u32x2 pk;
-        pk[0] = pack2h<F16>(v[0], v[1]); pk[1] = pack2h<F16>(v[2], v[3]);
-        *(u32x2*)(ob + g * 4) = pk;
-    }
-}
-static int add_cast(const float* a, const float* b, float* of, void* ob, long n, void* stream, int f16 = 0) {
-    if (n & 3) return HS_ERR_SHAPE;
-    ProfScope prof(HS_PROF_OTHER, stream, 0, (double)n * (4 + (b ? 4 : 0) + (of ? 4 : 0) + (ob ? 2 : 0)));
-    if (f16) hipLaunchKernelGGL(add_cast_kernel<true>, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, b, of, (bf16_t*)ob, n / 4);
-    else hipLaunchKernelGGL(add_cast_kernel<false>, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, b, of, (bf16_t*)ob, n / 4);
-    HS_CHECK_LAUNCH();
-    return HS_OK;
-}
 static int rows_gather(const float* src, float* dst, void* dstb, long src_bstride, int B, int R, int d, void* stream, long dst_bstride = -1,
                        int f16 = 0) {
     const long total = (long)B * R * (d / 4);
@@ -265,30 +242,25 @@ extern "C" int hs_embed_bwd(const hs_embed_desc* desc, const void* patches, cons
         if (drop) {                         // d(dropout_2(x)) : same Philox mask as the forward
             float* dxo = (float*)(w + L.dxo);
             RC(hs_dropout(dsum, dxo, (int64_t)Md, c.drop_p, c.seed[1], c.offset[1], stream));
-            RC(cast16(dxo, w + L.dxo_b, (int64_t)Md, stream, f16));
-            RC(hs_colsum(w + L.dxo_b, 1 + f16, eg[E_BO], M, d, d, stream));
+            RC(hs_addcast_colsum(dxo, nullptr, w + L.dxo_b, eg[E_BO], nullptr, M, d, d, f16, stream));       // 16-bit copy + bias gradient
             dxo_b = w + L.dxo_b;
         }
         RC(wgrad(dxo_b, d, w + L.ao_b, d, eg[E_WO], d, d, M, stream, P));
         RC(gemm(P, HS_GEMM_NN, dxo_b, w + L.w_o, M, d, d, d, d, dao, nullptr, d, nullptr, nullptr, nullptr, nullptr, 0, 1, stream));
         RC(hs_cross_attn_bwd(q, k, v, p, pd, dao, dq2, dk, dv, pws, c.B, c.Np, c.ns, d, c.drop_p, c.seed[0], c.offset[0], stream));
-        RC(add_cast(dsum, dq2, nullptr, w + L.dq_b, (long)Md, stream, f16));                 // dq = residual branch + attention branch
+        RC(hs_addcast_colsum(dsum, dq2, w + L.dq_b, eg[E_BQ], nullptr, M, d, d, f16, stream));   // dq = residual branch + attention branch; + its column sums
         RC(wgrad(w + L.dq_b, d, w + L.xe_b, d, eg[E_WQ], d, d, M, stream, P));
-        RC(hs_colsum(w + L.dq_b, 1 + f16, eg[E_BQ], M, d, d, stream));
         // dx total = token path + Query path
         RC(gemm(P, HS_GEMM_NN, w + L.dq_b, w + L.w_q, M, d, d, d, d, dpe2, nullptr, d, nullptr, dpe, nullptr, nullptr, HS_EPI_RESID, 1, stream));
         dpe_tot = dpe2;
         RC(hs_assemble_tokens_bwd(dpe2, nullptr, nullptr, nullptr, eg[E_POS], nullptr, nullptr, c.B, c.Np, d, stream));   // dpos += sum_b dx
-        RC(cast16(dk, w + L.dk_b, (int64_t)Ms * d, stream, f16));
-        RC(cast16(dv, w + L.dv_b, (int64_t)Ms * d, stream, f16));
+        RC(hs_addcast_colsum(dk, nullptr, w + L.dk_b, eg[E_BK], nullptr, Ms, d, d, f16, stream));
+        RC(hs_addcast_colsum(dv, nullptr, w + L.dv_b, eg[E_BV], nullptr, Ms, d, d, f16, stream));
         RC(wgrad(w + L.dk_b, d, w + L.sem_b, d, eg[E_WK], d, d, Ms, stream, P));
         RC(wgrad(w + L.dv_b, d, w + L.sem_b, d, eg[E_WV], d, d, Ms, stream, P));
-        RC(hs_colsum(w + L.dk_b, 1 + f16, eg[E_BK], Ms, d, d, stream));
-        RC(hs_colsum(w + L.dv_b, 1 + f16, eg[E_BV], Ms, d, d, stream));
     }
-    RC(cast16(dpe_tot, w + L.dpe_b, (int64_t)Md, stream, f16));
-    RC(wgrad(w + L.dpe_b, d, patches, c.Pd, eg[E_WPE], d, c.Pd, M, stream, P));
-    return hs_colsum(w + L.dpe_b, 1 + f16, eg[E_BPE], M, d, d, stream);
+    RC(hs_addcast_colsum(dpe_tot, nullptr, w + L.dpe_b, eg[E_BPE], nullptr, M, d, d, f16, stream));
+    return wgrad(w + L.dpe_b, d, patches, c.Pd, eg[E_WPE], d, c.Pd, M, stream, P);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -433,8 +405,7 @@ extern "C" int hs_packer_bwd(const hs_packer_desc* desc, const float* dout, cons
     if (drop) {
         float* dxl = (float*)(w + L.dxl);
         RC(hs_dropout(dsum, dxl, (int64_t)Mc * d, c.drop_p, c.seed[1], c.offset[1], stream));
-        RC(cast16(dxl, w + L.dxl_b, (int64_t)Mc * d, stream, f16));
-        RC(hs_colsum(w + L.dxl_b, 1 + f16, pg[K_BO], Mc, d, d, stream));
+        RC(hs_addcast_colsum(dxl, nullptr, w + L.dxl_b, pg[K_BO], nullptr, Mc, d, d, f16, stream));
         dxl_b = w + L.dxl_b;
     }
     RC(wgrad(dxl_b, d, w + L.xo_b, d, pg[K_WO], d, d, Mc, stream, P));
@@ -444,16 +415,13 @@ extern "C" int hs_packer_bwd(const hs_packer_desc* desc, const float* dout, cons
         if (hipMemsetAsync(dkv, 0, (size_t)Mt * 2 * d * 4, (hipStream_t)stream) != hipSuccess) return HS_ERR_LAUNCH;
     }
     RC(hs_window_attn_bwd(q, kv, dxo, dq2, dkv, c.B, c.gd, c.gh, c.gw, c.kd, c.kh, c.kw, d, c.drop_p, c.seed[0], c.offset[0], stream));
-    RC(add_cast(dsum, dq2, nullptr, w + L.dq_b, (long)Mc * d, stream, f16));
+    RC(hs_addcast_colsum(dsum, dq2, w + L.dq_b, pg[K_BQ], nullptr, Mc, d, d, f16, stream));
     RC(wgrad(w + L.dq_b, d, w + L.lr_b, d, pg[K_WQ], d, d, Mc, stream, P));
-    RC(hs_colsum(w + L.dq_b, 1 + f16, pg[K_BQ], Mc, d, d, stream));
     RC(gemm(P, HS_GEMM_NN, w + L.dq_b, w + L.wq, Mc, d, d, d, d, dlr, nullptr, d, nullptr, nullptr, nullptr, nullptr, 0, 1, stream));
-    RC(cast16(dkv, w + L.dkv_b, (int64_t)Mt * 2 * d, stream, f16));
+    RC(hs_addcast_colsum(dkv, nullptr, w + L.dkv_b, pg[K_BK], pg[K_BV], Mt, 2 * d, d, f16, stream));   // [dk | dv] 16-bit + both bias gradients
     const char* dkv_b = w + L.dkv_b;
     RC(wgrad(dkv_b, 2 * d, w + L.hr_b, d, pg[K_WK], d, d, Mt, stream, P));
     RC(wgrad(dkv_b + (size_t)d * 2, 2 * d, w + L.hr_b, d, pg[K_WV], d, d, Mt, stream, P));
-    RC(hs_colsum(dkv_b, 1 + f16, pg[K_BK], Mt, d, 2 * d, stream));
-    RC(hs_colsum(dkv_b + (size_t)d * 2, 1 + f16, pg[K_BV], Mt, d, 2 * d, stream));
     if (!dfeat) return HS_OK;                 // input features not differentiated (frozen towers: lamed_arch.py:66)
     RC(gemm(P, HS_GEMM_NN, dkv_b, w + L.wkv, Mt, d, 2 * d, 2 * d, d, dhr, nullptr, d, nullptr, nullptr, nullptr, nullptr, 0, 1, stream));
     RC(hs_pool3d_bwd(dlr, dhr, c.B, c.gd, c.gh, c.gw, c.kd, c.kh, c.kw, d, 1, stream));

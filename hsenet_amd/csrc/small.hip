@@ -617,12 +617,67 @@ extern "C" int hs_colsum(const void* x, int is_bf16, float* out, int M, int N, i
     if (is_bf16 < 0 || is_bf16 > 2) return HS_ERR_ARG;        // 0 fp32, 1 bf16, 2 fp16
     const int V = is_bf16 ? 8 : 4;
     if (M < 1 || N < V || (N % V) || (ldx % V) || ((uintptr_t)x & 15)) return HS_ERR_SHAPE;
-    const int rpb = 512;
+    // rows per block: 512 for the long matrices (81 940+ rows: hundreds of blocks either way); a one-volume matrix (4096 rows) had 8 row
+    // blocks x 3 column blocks = 24 blocks on 256 CUs and took 15-40 us of pure latency -- at least ~64 row blocks now
+    int rpb = M / 64;
+    rpb = rpb < 32 ? 32 : rpb > 512 ? 512 : (rpb + 7) & ~7;
     dim3 grid((N + 32 * V - 1) / (32 * V), (M + rpb - 1) / rpb);
     ProfScope prof(HS_PROF_COLSUM, stream, 0, (double)M * N * (is_bf16 ? 2 : 4));
     if (is_bf16 == 2) hipLaunchKernelGGL(colsum_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, x, out, M, N, (long)ldx, rpb);
     else if (is_bf16) hipLaunchKernelGGL(colsum_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, x, out, M, N, (long)ldx, rpb);
     else hipLaunchKernelGGL(colsum_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, x, out, M, N, (long)ldx, rpb);
+    HS_CHECK_LAUNCH();
+    return HS_OK;
+}
+
+// out16 = cast(a (+ b)) and column sums of the ROUNDED values in one pass: the backward of an nn.Linear wants its output gradient as a
+// 16-bit GEMM operand AND its column sums (the bias gradient) -- as two kernels (cast, then hs_colsum re-reading the copy) that was two
+// dependent launches per Linear, 16 per step in the embedding / packer backward (1.6 % of a one-volume step).  Columns [0, nsplit) add
+// into cs_lo, columns [nsplit, N) into cs_hi - nsplit (the packer's fused [Wk; Wv] projection has two bias vectors).  Internal (path.hip).
+template <bool F16>
+__global__ __launch_bounds__(256) void addcast_colsum_kernel(const float* __restrict__ a, const float* __restrict__ b, bf16_t* __restrict__ y,
+                                                             float* __restrict__ cs_lo, float* __restrict__ cs_hi, int M, int N, int nsplit,
+                                                             int rows_per_block) {
+    __shared__ float red[8][256];
+    const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int col0 = (blockIdx.x * 32 + cg) * 8;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    if (col0 < N) {
+        for (int r = r0 + rl; r < r1; r += 8) {
+            const long ix = (long)r * N + col0;
+            f32x4 v0 = *(const f32x4*)(a + ix), v1 = *(const f32x4*)(a + ix + 4);
+            if (b) { v0 += *(const f32x4*)(b + ix); v1 += *(const f32x4*)(b + ix + 4); }
+            u32x4 pk;
+            pk[0] = pack2h<F16>(v0[0], v0[1]); pk[1] = pack2h<F16>(v0[2], v0[3]); pk[2] = pack2h<F16>(v1[0], v1[1]); pk[3] = pack2h<F16>(v1[2], v1[3]);
+            *(u32x4*)(y + ix) = pk;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { acc[2 * i] += unpack_lo<F16>(pk[i]); acc[2 * i + 1] += unpack_hi<F16>(pk[i]); }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[rl][cg * 8 + e] = acc[e];
+    __syncthreads();
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col < N) {
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) s += red[r][threadIdx.x];
+        atomicAdd(col < nsplit ? &cs_lo[col] : &cs_hi[col - nsplit], s);
+    }
+}
+int hs_addcast_colsum(const float* a, const float* b, void* y16, float* cs_lo, float* cs_hi, int M, int N, int nsplit, int f16, void* stream) {
+    if (!a || !y16 || !cs_lo) return HS_ERR_ARG;
+    if (M < 1 || N < 8 || (N & 7) || nsplit < 0 || nsplit > N || (nsplit < N && !cs_hi)) return HS_ERR_SHAPE;
+    if (((uintptr_t)a | (uintptr_t)b | (uintptr_t)y16) & 15) return HS_ERR_SHAPE;
+    int rpb = M / 64;
+    rpb = rpb < 32 ? 32 : rpb > 512 ? 512 : (rpb + 7) & ~7;
+    dim3 grid((N + 255) / 256, (M + rpb - 1) / rpb);
+    ProfScope prof(HS_PROF_CAST, stream, 0, (double)M * N * (b ? 10 : 6));
+    if (f16) hipLaunchKernelGGL(addcast_colsum_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a, b, (bf16_t*)y16, cs_lo, cs_hi, M, N, nsplit, rpb);
+    else hipLaunchKernelGGL(addcast_colsum_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a, b, (bf16_t*)y16, cs_lo, cs_hi, M, N, nsplit, rpb);
     HS_CHECK_LAUNCH();
     return HS_OK;
 }

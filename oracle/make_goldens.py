@@ -55,6 +55,21 @@ def load_reference():
     return vit, spp
 
 
+def check_rearrange_witness():
+    """the reference records MONAI's patch rearrangement as a pasted module repr behind every PatchEmbeddingBlock call (vit.py:144, 299,
+    437, 508, 788: `# Rearrange('b c (h p1) (w p2) (d p3) -> b (h w d) (p1 p2 p3 c)', p1=4, p2=16, p3=16) + Linear(in_features=1024, ...)`).
+    Every one of them must be the string the oracle rearranges with, and the Linear's in_features must be p1*p2*p3*c: the layout of the
+    hot path's first operand is then machine-checked against the only witness of MONAI's behaviour that exists in the reference tree."""
+    import re
+    text = open(os.path.join(REF, "multimodal_encoder", "vit.py")).read()
+    hits = re.findall(r"#\s*Rearrange\('([^']+)',\s*p1=(\d+),\s*p2=(\d+),\s*p3=(\d+)\)\s*\+\s*Linear\(in_features=(\d+),\s*out_features=(\d+)", text)
+    assert len(hits) >= 5, f"expected the pasted Rearrange repr behind every PatchEmbeddingBlock call, found {len(hits)}"
+    for pat, p1, p2, p3, fin, fout in hits:
+        assert pat == R.REARRANGE_PATTERN, f"reference comment records {pat!r}, the oracle rearranges with {R.REARRANGE_PATTERN!r}"
+        assert int(p1) * int(p2) * int(p3) == int(fin) and int(fout) == 768, (p1, p2, p3, fin, fout)
+    return len(hits)
+
+
 def _eq(a, b, what, tol=1e-6):
     err = float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
     assert err <= tol, f"restatement != reference for {what}: {err}"
@@ -729,6 +744,7 @@ def main():
     a = ap.parse_args()
     if not os.path.isdir(REF):
         sys.exit("reference not present (this script only runs in the build container)")
+    print(f"[make_goldens] rearrange pattern witnessed by {check_rearrange_witness()} reference comments", flush=True)
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(os.cpu_count())
     vit, spp = load_reference()

@@ -64,6 +64,12 @@ def _matmul(a, b):
 # --------------------------------------------------------------------------------------
 # MONAI 1.3.0 blocks (restated).  Call sites: multimodal_encoder/vit.py:428-443
 # --------------------------------------------------------------------------------------
+# MONAI PatchEmbeddingBlock's 'perceptron' rearrangement.  The one in-tree witness of MONAI's layout is the repr the reference's
+# authors pasted as a comment behind every PatchEmbeddingBlock call (vit.py:144, 299, 437, 508, 788): oracle/make_goldens.py reads those
+# comments and asserts that each of them carries exactly this string (check_rearrange_witness).
+REARRANGE_PATTERN = "b c (h p1) (w p2) (d p3) -> b (h w d) (p1 p2 p3 c)"
+
+
 class _Rearrange(nn.Module):
     """Stand-in for einops.layers.torch.Rearrange at index 0 of ``patch_embeddings`` (no params)."""
 
@@ -74,7 +80,7 @@ class _Rearrange(nn.Module):
     def forward(self, x):
         p1, p2, p3 = self.patch_size
         # pattern recorded in the reference at vit.py:437
-        return rearrange(x, "b c (h p1) (w p2) (d p3) -> b (h w d) (p1 p2 p3 c)", p1=p1, p2=p2, p3=p3)
+        return rearrange(x, REARRANGE_PATTERN, p1=p1, p2=p2, p3=p3)
 
 
 class PatchEmbeddingBlock(nn.Module):
