@@ -1,10 +1,10 @@
 #!/bin/bash
-# round-5 profile set of the final code: rocprofv3 kernel stats, the default bench line as the driver runs it, the three PMC passes merged
-# into profiles/r05_pmc.json (stamped with the library's hs_build_id and the bench value), and the other workloads' bench lines.
-# Run on the GPU box from the repo root; results under gpurun_out/r05 (copy to profiles/ afterwards).
+# round-6 profile set of the final code: rocprofv3 kernel stats, the default bench line as the driver runs it, the three PMC passes merged
+# into profiles/r06_pmc.json (stamped with the library's hs_build_id and the bench value), and the other workloads' bench lines.
+# Run on the GPU box from the repo root; results under gpurun_out/r06 (copy to profiles/ afterwards).
 set -o pipefail
 cd "$(dirname "$0")/.."
-TAG=${1:-r05}
+TAG=${1:-r06}
 mkdir -p gpurun_out/$TAG
 bash tools/profile_bench.sh 53 gpurun_out/$TAG/stats &&
 cp $(find gpurun_out/$TAG/stats -name "*kernel_stats.csv" | head -1) gpurun_out/$TAG/${TAG}_kernel_stats_dual_batch53.csv &&

@@ -29,7 +29,7 @@ CLASS = [("attn_fwd_fast_kernel", "attn_fwd"), ("attn_bwd_dkdv16_w4_kernel", "at
          ("gemm_bf16_kernel<false, false, true, 67, true", "gemm_nt16_bias_gelu"), ("gemm_bf16_kernel<false, false, true, 68, true", "gemm_nt16_dgelu"),
          ("gemm_bf16_group_kernel<true, true", "gemm_tn_group"), ("gemm_bf16_kernel<false, false", "gemm_nt"), ("gemm_bf16_kernel<false, true", "gemm_nn"),
          ("gemm_bf16_kernel<true, true", "gemm_tn"), ("layernorm_bwd_kernel", "layernorm_bwd"), ("layernorm_fwd_kernel", "layernorm_fwd"),
-         ("adamw_masked_kernel", "adamw"), ("patchify_kernel", "patchify")]
+         ("adamw_masked_kernel", "adamw"), ("adamw_fused_kernel", "adamw"), ("patchify_kernel", "patchify")]
 
 
 def mfma_flops(name):
