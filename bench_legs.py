@@ -301,7 +301,8 @@ def pcie_inclusive_rate(eng, needs_2d, vols, slices, dev, sync, steps):
     vols[0].copy_(host[0], non_blocking=True)
     torch.cuda.synchronize()
     h2d_gbs = host[0].numel() * 4 / (time.perf_counter() - t0) / 1e9
-    copy = torch.cuda.Stream(device=dev)
+    from hsenet_amd.fused import _pick_concurrent_stream
+    copy = _pick_concurrent_stream(dev)            # (a stream on another hardware queue than the compute stream's: see fused.py)
     main = torch.cuda.current_stream()
     ready = [torch.cuda.Event(), torch.cuda.Event()]
     freed = [torch.cuda.Event(), torch.cuda.Event()]

@@ -28,6 +28,7 @@ from . import _lib as L
 from . import functional as Fn
 from .clip import M3DCLIPVision_stage1, M3DCLIPVision_stage2, relation_loss_weight
 from .engine import EncoderUnit, _Engine, _al, _encoder_bounds, _encoder_entries, _engine_prec, decays
+from .fused import side_stream
 
 
 def make_clip_stage2(img_size, patch_size, **kw) -> M3DCLIPVision_stage2:
@@ -260,7 +261,7 @@ class ClipStage2Engine(_ClipEngine):
         self.acc = torch.zeros(4, **f32)                           # [CE loss, sum(dlogits*logits), relation MSE, -]
         self.global_step = 0
         self._txt1 = self._txt2 = None
-        self.side = torch.cuda.Stream(device=self.dev)
+        self.side = side_stream(self.dev)            # (a stream that really runs beside this one: fused._pick_concurrent_stream)
 
     # ------------------------------------------------------------------------------------------------------------------------
     def _logits(self, col_img: int, col_txt: int, raw: torch.Tensor, logits: torch.Tensor) -> None:

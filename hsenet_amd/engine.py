@@ -29,6 +29,7 @@ from . import _lib as L
 from . import functional as Fn
 from .dp import GradBuckets
 from .encoder import ViT_stage1, ViT_stage2, ViT3DTower_dual_encoders
+from .fused import side_stream
 from .projector import VisualPacker_3d_phi_v3
 
 
@@ -650,7 +651,7 @@ class DualEngine(_Engine):
         if two_streams is None:
             two_streams = batch < 16
         self.two_streams = two_streams
-        self.side = torch.cuda.Stream(device=self.dev) if two_streams else None
+        self.side = side_stream(self.dev) if two_streams else None      # (a stream that really runs beside this one: fused._pick_concurrent_stream)
 
     def _fork(self):
         if self.side is not None:

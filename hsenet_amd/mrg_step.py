@@ -23,6 +23,7 @@ from . import functional as Fn
 from .clip import splice_image_features
 from .encoder import ViT3DTower_dual_encoders
 from .engine import EncoderUnit, PackerUnit, _Engine, _al, _engine_prec, decays
+from .fused import side_stream
 from .projector import VisualPacker_3d_phi_v3
 
 
@@ -56,7 +57,7 @@ class MRGStepEngine(_Engine):
             u.bind()
         self.patches = torch.empty(batch * self.u1.Np, self.u1.Pd, dtype=self.dtype16, device=self.dev)
         self.out = torch.empty(batch, 2 * self.p1.cells, packer1.out_dim, dtype=torch.float32, device=self.dev)
-        self.side = torch.cuda.Stream(device=self.dev)
+        self.side = side_stream(self.dev)            # (a stream that really runs beside this one: fused._pick_concurrent_stream)
         self.last_loss = None
 
     def encode_images(self, vol: torch.Tensor, image_2d: torch.Tensor) -> torch.Tensor:
