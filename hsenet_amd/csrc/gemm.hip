@@ -1277,8 +1277,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmP p) {
     const int wm = wave >> 1, wn = wave & 1;
     const int tm = blockIdx.x % p.tiles_m, tn = blockIdx.x / p.tiles_m;
     const int m0 = tm * 64, n0 = tn * 64;
+    // grid.z = batch x split_k (exact-f32 kernel only: the scorer's dK / dV = P^T dOut are 32 x 768 outputs over 4096 rows PER VOLUME --
+    // 12 tiles of 128 K-steps each at one volume per GPU, ~100 us of latency; split over K they fill the chip)
     const int z = blockIdx.z;
-    const int bz = p.split_k > 1 ? 0 : z;
+    const int sk = p.split_k > 1 ? p.split_k : 1;
+    const int bz = z / sk, ks = z - bz * sk;
     const float* A = (const float*)p.A + bz * p.sA;
     const float* B = (const float*)p.B + bz * p.sB;
     const long cz = bz * p.sC;
@@ -1288,7 +1291,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmP p) {
     int kt0 = 0, kt1 = kt_total;
     if (p.split_k > 1) {
         const int per = (kt_total + p.split_k - 1) / p.split_k;
-        kt0 = z * per;
+        kt0 = ks * per;
         kt1 = min(kt_total, kt0 + per);
     }
 #define AS(c) (smem + (c) * 16384)
@@ -1444,7 +1447,8 @@ extern "C" int hs_gemm(const hs_gemm_args* a, int prec, void* stream) {
     if ((a->flags & HS_EPI_BIAS) && !a->bias) return HS_ERR_ARG;
     if ((a->flags & HS_EPI_RESID) && !a->resid) return HS_ERR_ARG;
     if ((a->flags & HS_EPI_GELU_BWD) && !a->aux) return HS_ERR_ARG;
-    if (a->split_k > 1 && (!(a->flags & HS_EPI_ATOMIC) || a->batch != 1 || !a->out_f32 || a->out_bf16)) return HS_ERR_SHAPE;
+    // (split-K: atomic fp32 output; one batch entry -- except in the exact-f32 kernel, whose grid.z carries batch x split)
+    if (a->split_k > 1 && (!(a->flags & HS_EPI_ATOMIC) || (a->batch != 1 && prec != HS_PREC_F32) || !a->out_f32 || a->out_bf16)) return HS_ERR_SHAPE;
     if (prec != HS_PREC_BF16 && prec != HS_PREC_F32 && prec != HS_PREC_F16) return HS_ERR_ARG;
     const bool h16 = prec == HS_PREC_F16;          // fp16 operands: every layout and epilogue the bf16 path has (round 5)
     if (a->scale_cols < 0 || (a->scale_cols & 3) || (a->scale_cols && (a->flags & HS_EPI_ATOMIC))) return HS_ERR_SHAPE;
@@ -1529,7 +1533,7 @@ extern "C" int hs_gemm(const hs_gemm_args* a, int prec, void* stream) {
     } else {
         ProfScope prof(HS_PROF_GEMM_NT + a->layout, stream, 2.0 * mnk, prof_bytes);
         p.tiles_m = (a->M + 63) / 64;
-        dim3 grid(p.tiles_m * ((a->N + 63) / 64), 1, zdim);
+        dim3 grid(p.tiles_m * ((a->N + 63) / 64), 1, a->split_k > 1 ? a->split_k * a->batch : a->batch);
         if (a->layout == HS_GEMM_NT) hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(256), 0, s, p);
         else if (a->layout == HS_GEMM_NN) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, dim3(256), 0, s, p);
         else hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(256), 0, s, p);

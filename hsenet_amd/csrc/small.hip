@@ -272,8 +272,20 @@ extern "C" int hs_cross_attn_bwd(const float* q, const float* k, const float* v,
     HS_CHECK_LAUNCH();
     // dQ = dS K * alpha ;  dK = dS^T Q * alpha ; dV = P^T dOut
     if ((rc = launch_f32_gemm(HS_GEMM_NN, ws, k, dq, nq, d, nk, nk, d, d, B, sp, sk, sq, alpha, 0, 1, stream))) return rc;
-    if ((rc = launch_f32_gemm(HS_GEMM_TN, ws, q, dk, nk, d, nq, nk, d, d, B, sp, sq, sk, alpha, 0, 1, stream))) return rc;
-    return launch_f32_gemm(HS_GEMM_TN, drop_p > 0.f ? pd : p, dout, dv, nk, d, nq, nk, d, d, B, sp, sq, sk, 1.0f, 0, 1, stream);
+    // dK, dV: [nk][d] outputs (32 x 768: 12 tiles per volume) reduced over the nq = 4096 queries.  With few volumes the tiles cannot fill
+    // the chip and each walks 128 K-steps (~100 us of latency at one volume): split the reduction, accumulate atomically into zeroed outputs
+    const long tiles = (long)B * ((nk + 63) / 64) * ((d + 63) / 64);
+    int split = (int)(256 / tiles);
+    split = split < 2 ? 1 : split > 16 ? 16 : split;
+    if (split > 1 && (nq >> 5) / split < 4) split = 1;
+    int fl = 0;
+    if (split > 1) {
+        fl = HS_EPI_ATOMIC;
+        if (hipMemsetAsync(dk, 0, (size_t)B * sk * 4, (hipStream_t)stream) != hipSuccess) return HS_ERR_LAUNCH;
+        if (hipMemsetAsync(dv, 0, (size_t)B * sk * 4, (hipStream_t)stream) != hipSuccess) return HS_ERR_LAUNCH;
+    }
+    if ((rc = launch_f32_gemm(HS_GEMM_TN, ws, q, dk, nk, d, nq, nk, d, d, B, sp, sq, sk, alpha, fl, split, stream))) return rc;
+    return launch_f32_gemm(HS_GEMM_TN, drop_p > 0.f ? pd : p, dout, dv, nk, d, nq, nk, d, d, B, sp, sq, sk, 1.0f, fl, split, stream);
 }
 
 // patch_score_proj + Sigmoid (vit.py:338-339): one wave per row
@@ -430,24 +442,35 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const float* __restric
     }
     const float* kvb = kv + (long)b * w.tokens * 2 * d;
     float sc = -__builtin_inff(), dpl = 0.f;
-    for (int j = 0; j < w.nwin; ++j) {
-        const float* kr = kvb + (long)child_token(w, cell, j) * 2 * d;
-        float s = 0.f, t = 0.f;
+    // children four at a time: the 4 x (K row [+ V row]) loads are issued together and the four wave reductions interleave -- one child
+    // per iteration was a chain of nwin dependent (load -> reduce) steps, ~95 us for the 32 children of a (2,4,4) window on the 32 blocks
+    // a single volume launches (pure latency)
+    for (int j0 = 0; j0 < w.nwin; j0 += 4) {
+        float s4[4] = {0.f, 0.f, 0.f, 0.f}, t4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < WA_MAXCH; ++i) {
-            const int ch = lane + 64 * i;
-            if (ch < nch) {
-                const f32x4 kk = *(const f32x4*)(kr + ch * 4);
-                s += qv[i][0] * kk[0] + qv[i][1] * kk[1] + qv[i][2] * kk[2] + qv[i][3] * kk[3];
-                if (BWD) {
-                    const f32x4 vv = *(const f32x4*)(kr + d + ch * 4);
-                    t += gv[i][0] * vv[0] + gv[i][1] * vv[1] + gv[i][2] * vv[2] + gv[i][3] * vv[3];
+        for (int u = 0; u < 4; ++u) {
+            if (j0 + u < w.nwin) {
+                const float* kr = kvb + (long)child_token(w, cell, j0 + u) * 2 * d;
+#pragma unroll
+                for (int i = 0; i < WA_MAXCH; ++i) {
+                    const int ch = lane + 64 * i;
+                    if (ch < nch) {
+                        const f32x4 kk = *(const f32x4*)(kr + ch * 4);
+                        s4[u] += qv[i][0] * kk[0] + qv[i][1] * kk[1] + qv[i][2] * kk[2] + qv[i][3] * kk[3];
+                        if (BWD) {
+                            const f32x4 vv = *(const f32x4*)(kr + d + ch * 4);
+                            t4[u] += gv[i][0] * vv[0] + gv[i][1] * vv[1] + gv[i][2] * vv[2] + gv[i][3] * vv[3];
+                        }
+                    }
                 }
             }
         }
-        s = wave_sum(s) * alpha;
-        if (BWD) t = wave_sum(t);
-        if (lane == j) { sc = s; dpl = t; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float s = wave_sum(s4[u]) * alpha;
+            const float t = BWD ? wave_sum(t4[u]) : 0.f;
+            if (lane == j0 + u) { sc = s; dpl = t; }
+        }
     }
     const float m = wave_max(sc);
     const float e = lane < w.nwin ? __expf(sc - m) : 0.f;
@@ -461,6 +484,7 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const float* __restric
         for (int i = 0; i < WA_MAXCH; ++i)
 #pragma unroll
             for (int e2 = 0; e2 < 4; ++e2) acc[i][e2] = 0.f;
+#pragma unroll 4
         for (int j = 0; j < w.nwin; ++j) {
             const float pj = __shfl(p * mk, j, 64);
             const float* vr = kvb + (long)child_token(w, cell, j) * 2 * d + d;
@@ -484,6 +508,7 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const float* __restric
 #pragma unroll
             for (int e2 = 0; e2 < 4; ++e2) acc[i][e2] = 0.f;
         float* dkvb = dkv + (long)b * w.tokens * 2 * d;
+#pragma unroll 4
         for (int j = 0; j < w.nwin; ++j) {
             const float dsj = __shfl(ds, j, 64) * alpha, pj = __shfl(p * mk, j, 64);
             const long tok = child_token(w, cell, j);

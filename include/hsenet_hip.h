@@ -72,7 +72,7 @@ typedef struct hs_gemm_args {
     float alpha;
     int flags;
     int layout;             /* HS_GEMM_* */
-    int split_k;            /* >=1; >1 requires HS_EPI_ATOMIC and batch==1 */
+    int split_k;            /* >=1; >1 requires HS_EPI_ATOMIC and batch==1 (HS_PREC_F32: any batch, the grid carries batch x split_k) */
     int scale_cols;         /* 0, or a multiple of 4: output columns n < scale_cols get the extra factor           */
     float scale_cols_alpha; /*   scale_cols_alpha on top of alpha (before bias).  The ViT driver uses it to emit the q  */
                             /*   third of a qkv projection pre-multiplied by dh^-0.5 * log2(e): HS_ATTN_Q_PRESCALED      */
