@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("HS_LIB_PATH") or os.path.join(HERE, "lib", "libhsenet
 
 HS_OK, HS_ERR_SHAPE, HS_ERR_ARCH, HS_ERR_LAUNCH, HS_ERR_ARG = 0, -1, -2, -3, -4
 PREC_BF16, PREC_F32, PREC_F16 = 0, 1, 2
+ADAMW_STEP, ADAMW_PREPARE, ADAMW_SWEEP = 0, 1, 2
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 EPI_BIAS, EPI_GELU, EPI_GELU_BWD, EPI_RESID, EPI_ATOMIC, EPI_BIAS_M, EPI_SAVE_DGELU = 1, 2, 4, 8, 16, 32, 64
 ATTN_Q_PRESCALED, ATTN_F32, ATTN_F16 = 1, 2, 16
@@ -117,6 +118,7 @@ SIGNATURES = {
     "hs_vit_weights_elems": [C.POINTER(VitDesc)],
     "hs_vit_cast_weights": [C.POINTER(VitDesc), _vp, _vp, _vp, _vp],
     "hs_vit_blocks_fwd": [C.POINTER(VitDesc), _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
+    "hs_vit_blocks_fwd_range": [C.POINTER(VitDesc), _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _vp],
     "hs_vit_blocks_bwd": [C.POINTER(VitDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _vp],
     "hs_embed_workspace_bytes": [C.POINTER(EmbedDesc)],
     "hs_embed_fwd": [C.POINTER(EmbedDesc), _vp, _vp, _vp, _vp, _vp, _sz, _vp],
@@ -128,7 +130,7 @@ SIGNATURES = {
     "hs_mse_grad_scaled": [_vp, _vp, _vp, _i64, _f, _vp],
     "hs_sumsq": [_vp, _vp, _vp, _i64, _vp],
     "hs_adamw_masked": [_vp, _vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _f, _vp, _f, _i, _vp],
-    "hs_adamw_fused": [_vp, _vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _f, _vp, _f, _i, _vp, _i, _vp, _vp],
+    "hs_adamw_fused": [_vp, _vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _f, _vp, _f, _i, _vp, _i, _vp, _i, _vp],
     "hs_rows_copy": [_vp, _i64, _vp, _vp, _i64, _i, _i, _i, _vp],
     "hs_rows_scatter": [_vp, _vp, _i, _i, _i, _i, _i, _vp],
     "hs_scale_dev": [_vp, _vp, _vp, _f, _i64, _vp],

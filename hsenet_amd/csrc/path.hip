@@ -619,20 +619,29 @@ __global__ __launch_bounds__(256) void adamw_fused_kernel(float* __restrict__ p,
 }
 extern "C" int hs_adamw_fused(float* p, float* g, float* m, float* v, const unsigned char* decay_mask, int64_t n, float lr, float beta1,
                               float beta2, float eps, float weight_decay, float grad_scale, const float* grad_sumsq, float max_grad_norm,
-                              int zero_grad, const uint64_t* w16_table, int w16_is_f16, int32_t* state, void* stream) {
-    if (!p || !g || !m || !v || !state) return HS_ERR_ARG;
-    if (n < 64 || (n & 63)) return HS_ERR_SHAPE;
-    if ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) || ((uintptr_t)state & 3) || ((uintptr_t)w16_table & 7)) return HS_ERR_SHAPE;
-    if (max_grad_norm > 0.f && !grad_sumsq) return HS_ERR_ARG;
-    if (!(grad_scale > 0.f)) return HS_ERR_ARG;
-    ProfScope prof(HS_PROF_ADAMW, stream, 0, (double)n * (28 + (zero_grad ? 4 : 0)));
-    hipLaunchKernelGGL(adamw_prep_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state, grad_sumsq, grad_scale,
-                       max_grad_norm > 0.f ? max_grad_norm : 0.f, beta1, beta2);
-    const dim3 grid((unsigned)((n + 1023) / 1024)), blk(256);
-    if (w16_is_f16) hipLaunchKernelGGL(adamw_fused_kernel<true>, grid, blk, 0, (hipStream_t)stream, p, g, m, v, decay_mask, (long)n, lr, beta1,
-                                       beta2, eps, weight_decay, zero_grad, w16_table, (const int32_t*)state);
-    else hipLaunchKernelGGL(adamw_fused_kernel<false>, grid, blk, 0, (hipStream_t)stream, p, g, m, v, decay_mask, (long)n, lr, beta1, beta2,
-                            eps, weight_decay, zero_grad, w16_table, (const int32_t*)state);
+                              int zero_grad, const uint64_t* w16_table, int w16_is_f16, int32_t* state, int phase, void* stream) {
+    if (!state || phase < HS_ADAMW_STEP || phase > HS_ADAMW_SWEEP) return HS_ERR_ARG;
+    if ((uintptr_t)state & 3) return HS_ERR_SHAPE;
+    if (phase != HS_ADAMW_SWEEP) {           // the one-thread prologue: skip decision, step counter, clip coefficient, bias corrections
+        if (max_grad_norm > 0.f && !grad_sumsq) return HS_ERR_ARG;
+        if (!(grad_scale > 0.f)) return HS_ERR_ARG;
+    }
+    if (phase != HS_ADAMW_PREPARE) {
+        if (!p || !g || !m || !v) return HS_ERR_ARG;
+        if (n < 64 || (n & 63)) return HS_ERR_SHAPE;
+        if ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) || ((uintptr_t)w16_table & 7)) return HS_ERR_SHAPE;
+    }
+    if (phase != HS_ADAMW_SWEEP)
+        hipLaunchKernelGGL(adamw_prep_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state, grad_sumsq, grad_scale,
+                           max_grad_norm > 0.f ? max_grad_norm : 0.f, beta1, beta2);
+    if (phase != HS_ADAMW_PREPARE) {
+        ProfScope prof(HS_PROF_ADAMW, stream, 0, (double)n * (28 + (zero_grad ? 4 : 0)));
+        const dim3 grid((unsigned)((n + 1023) / 1024)), blk(256);
+        if (w16_is_f16) hipLaunchKernelGGL(adamw_fused_kernel<true>, grid, blk, 0, (hipStream_t)stream, p, g, m, v, decay_mask, (long)n, lr, beta1,
+                                           beta2, eps, weight_decay, zero_grad, w16_table, (const int32_t*)state);
+        else hipLaunchKernelGGL(adamw_fused_kernel<false>, grid, blk, 0, (hipStream_t)stream, p, g, m, v, decay_mask, (long)n, lr, beta1, beta2,
+                                eps, weight_decay, zero_grad, w16_table, (const int32_t*)state);
+    }
     HS_CHECK_LAUNCH();
     return HS_OK;
 }

@@ -160,8 +160,17 @@ extern "C" int hs_vit_cast_weights(const hs_vit_desc* desc, const float* const* 
 extern "C" int hs_vit_blocks_fwd(const hs_vit_desc* desc, const float* x0, const float* const* lp, const float* const* np,
                                  float* y, float* hidden, void* ws, size_t ws_bytes, void* stream) {
     RC(check_desc(desc));
-    if (!x0 || !lp || !np || !y || !hidden || !ws) return HS_ERR_ARG;
+    return hs_vit_blocks_fwd_range(desc, x0, lp, np, y, hidden, ws, ws_bytes, 0, desc->L, stream);
+}
+
+extern "C" int hs_vit_blocks_fwd_range(const hs_vit_desc* desc, const float* x0, const float* const* lp, const float* const* np,
+                                       float* y, float* hidden, void* ws, size_t ws_bytes, int l_lo, int l_hi, void* stream) {
+    RC(check_desc(desc));
+    if (!lp || !np || !hidden || !ws) return HS_ERR_ARG;
     const hs_vit_desc& c = *desc;
+    if (l_lo < 0 || l_hi > c.L || l_lo >= l_hi) return HS_ERR_SHAPE;
+    if ((l_lo == 0 && !x0) || (l_hi == c.L && !y)) return HS_ERR_ARG;
+    if ((l_lo > 0 || l_hi < c.L) && c.prec != HS_PREC_F32 && !c.w16) return HS_ERR_ARG;      // a sub-range cannot cast every layer's weights
     const Layout L = make_layout(c);
     if (ws_bytes < L.total || ((uintptr_t)ws & 255)) return HS_ERR_SHAPE;
     char* w = (char*)ws;
@@ -175,7 +184,7 @@ extern "C" int hs_vit_blocks_fwd(const hs_vit_desc* desc, const float* x0, const
     // 16-bit copies of the four weight matrices of every layer: the caller's (desc.w16), or re-made here in one multi-segment launch
     const bf16_t* wcopy = bf ? (c.w16 ? (const bf16_t*)c.w16 : (const bf16_t*)(w + L.wbf)) : nullptr;
     if (bf && !c.w16) RC(cast_weights(c, lp, w + L.wbf, 0, c.L, stream));
-    for (int l = 0; l < c.L; ++l) {
+    for (int l = l_lo; l < l_hi; ++l) {
         const size_t ls = c.save_for_bwd ? l : 0;
         const float* const* p = lp + (size_t)l * P_COUNT;
         const float* xin = l == 0 ? x0 : hidden + (size_t)(l - 1) * Md;
@@ -219,6 +228,7 @@ extern "C" int hs_vit_blocks_fwd(const hs_vit_desc* desc, const float* x0, const
                 c.save_for_bwd == 1 ? z : nullptr, HS_EPI_BIAS | HS_EPI_GELU | HS_EPI_SAVE_DGELU, 1, stream));   // (2: gelu' is made again in the backward)
         RC(gemm(c.prec, HS_GEMM_NT, a, w2, M, d, mlp, mlp, mlp, xout, nullptr, d, p[P_B2], xmid, nullptr, nullptr, HS_EPI_BIAS | HS_EPI_RESID, 1, stream));
     }
+    if (l_hi < c.L) return HS_OK;
     float* fs = (float*)(w + L.fstats);
     RC(hs_layernorm_fwd(hidden + (size_t)(c.L - 1) * Md, nullptr, np[0], np[1], y, nullptr, fs, fs + M, M, d, eps, stream));
     return HS_OK;

@@ -29,7 +29,7 @@ from . import _lib as L
 from . import functional as Fn
 from .dp import GradBuckets
 from .encoder import ViT_stage1, ViT_stage2, ViT3DTower_dual_encoders
-from .fused import side_stream
+from .fused import chunk_ranges, optimizer_stream, side_stream
 from .projector import VisualPacker_3d_phi_v3
 
 
@@ -133,10 +133,9 @@ class FlatParams:
              eps: float = 1e-8, zero_grad: bool = True) -> None:
         """the optimizer pass as ONE sweep (hs_adamw_fused): decay mask, global-norm clip on the device, the gradient zeroed behind
         the read (zero_grad), the registered 16-bit weight copies written beside the fp32 masters, step / skip counters on the device."""
-        s = Fn._s()
-        gsq = None
-        clip = max_grad_norm is not None and max_grad_norm > 0
         if os.environ.get("HS_LEGACY_STEP") == "1":            # (A/B runs only: round 5's optimizer pass, host-side step counter)
+            s = Fn._s()
+            clip = max_grad_norm is not None and max_grad_norm > 0
             self._legacy_step = getattr(self, "_legacy_step", 0) + 1
             if clip:
                 L.call("hs_sumsq", self.grad.data_ptr(), self.gsq.data_ptr(), self._gsq_scratch.data_ptr(), self.total, s)
@@ -144,17 +143,37 @@ class FlatParams:
                    self.decay_mask.data_ptr(), self.total, lr, betas[0], betas[1], eps, weight_decay, grad_scale,
                    self.gsq.data_ptr() if clip else None, float(max_grad_norm) if clip else 0.0, self._legacy_step, s)
             return
+        self.prepare(lr=lr, weight_decay=weight_decay, grad_scale=grad_scale, max_grad_norm=max_grad_norm, betas=betas, eps=eps,
+                     zero_grad=zero_grad)
+        self.sweep(0, self.total)
+        if zero_grad:
+            self.grad_dirty = False
+
+    def prepare(self, *, lr: float, weight_decay: float, grad_scale: float, max_grad_norm: Optional[float], betas=(0.9, 0.999),
+                eps: float = 1e-8, zero_grad: bool = True) -> None:
+        """the part of the optimizer pass every sweep depends on, on the current stream: the gradient norm (when clipping, or to arm the
+        fp16 skip) and hs_adamw_fused's one-thread prologue (skip decision, step counter, clip coefficient, bias corrections)."""
+        s = Fn._s()
+        clip = max_grad_norm is not None and max_grad_norm > 0
+        gsq = None
         if clip or self.check_finite:
             L.call("hs_sumsq", self.grad.data_ptr(), self.gsq.data_ptr(), self._gsq_scratch.data_ptr(), self.total, s)
             gsq = self.gsq.data_ptr()
         if self._w16_dev is None and bool(self._w16_host.any()):
             self._w16_dev = self._w16_host.to(self.flat.device)
-        L.call("hs_adamw_fused", self.flat.data_ptr(), self.grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
-               self.decay_mask.data_ptr(), self.total, lr, betas[0], betas[1], eps, weight_decay, grad_scale, gsq,
-               float(max_grad_norm) if clip else 0.0, int(zero_grad), Fn._p(self._w16_dev), int(self.w16_is_f16),
-               self.state.data_ptr(), s)
-        if zero_grad:
-            self.grad_dirty = False
+        self._hyper = (lr, betas[0], betas[1], eps, weight_decay, grad_scale, gsq, float(max_grad_norm) if clip else 0.0, int(zero_grad))
+        L.call("hs_adamw_fused", None, None, None, None, None, 0, lr, betas[0], betas[1], eps, weight_decay, grad_scale, gsq,
+               float(max_grad_norm) if clip else 0.0, int(zero_grad), None, int(self.w16_is_f16), self.state.data_ptr(), L.ADAMW_PREPARE, s)
+
+    def sweep(self, a: int, b: int) -> None:
+        """AdamW over the flat range [a, b) (64-element multiples) with the hyper-parameters of the last prepare(), on the current stream."""
+        if a % 64 or b % 64 or not (0 <= a < b <= self.total):
+            raise L.HsError(f"optimizer sweep range [{a}, {b}) must be 64-element aligned inside [0, {self.total})")
+        lr, b1, b2, eps, wd, gs, gsq, mx, zg = self._hyper
+        tab = None if self._w16_dev is None else self._w16_dev.data_ptr() + 8 * (a // 64)
+        L.call("hs_adamw_fused", self.flat.data_ptr() + 4 * a, self.grad.data_ptr() + 4 * a, self.m.data_ptr() + 4 * a, self.v.data_ptr() + 4 * a,
+               self.decay_mask.data_ptr() + a // 64, b - a, lr, b1, b2, eps, wd, gs, gsq, mx, zg, tab, int(self.w16_is_f16),
+               self.state.data_ptr(), L.ADAMW_SWEEP, Fn._s())
 
 
 def _seeds(desc, train: bool) -> None:
@@ -248,6 +267,11 @@ class EncoderUnit:
         self.desc.w16, self.desc.w16t = Fn._p(self.w16), Fn._p(self.w16t)
         self._wmats = [w for blk in model.blocks for w in (blk.attn.qkv.weight, blk.attn.out_proj.weight, blk.mlp.linear1.weight, blk.mlp.linear2.weight)]
         self._wkey, self._flat, self._w16_mapped = None, None, False
+        # forward chunks (layers [lo, hi)) that an overlapped optimizer pass releases one by one: events recorded on the optimizer stream
+        # after the sweep of each chunk's parameters (engine._Engine.optimizer_step), waited for by the next forward on ITS stream
+        self.fwd_chunks = chunk_ranges(self.Ln, 4)
+        self._events = [torch.cuda.Event() for _ in self.fwd_chunks]
+        self._pending, self._opt_done = False, None
         self.ws_bytes = lib.hs_vit_workspace_bytes(C.byref(self.desc))
         if self.ws_bytes == 0:
             raise L.HsError("unsupported encoder geometry")
@@ -311,11 +335,21 @@ class EncoderUnit:
         through the flat buffer it views; the optimizer pass writes through raw pointers and keeps the copies current itself."""
         return Fn.weights_stamp(self._wmats) + (-1 if self._flat is None else self._flat._version,)
 
+    def flat_chunk_ranges(self, params: "FlatParams"):
+        """[(a, b)] flat-buffer ranges of this encoder's parameters per forward chunk (its entries are contiguous in flat order: head..,
+        blocks.0 .. blocks.L-1, norm -- encoder_flat_order): chunk 0 starts at the head, the last chunk ends behind the final norm."""
+        offs = [(params._param_offset[id(p)], p.numel()) for p in self.model.parameters() if id(p) in params._param_offset]
+        seg_a, seg_b = min(o for o, _ in offs), max(o + _al(n) for o, n in offs)
+        starts = [seg_a] + [params._param_offset[id(self.model.blocks[lo].mlp.linear1.weight)] for lo, _ in self.fwd_chunks[1:]]
+        return list(zip(starts, starts[1:] + [seg_b]))
+
     def sync_weights(self) -> None:
         if self.legacy:
             return
         key = self._weights_key()
         if key != self._wkey:
+            if self._opt_done is not None:        # torch changed a weight while an overlapped optimizer pass may still be sweeping: wait for it
+                torch.cuda.current_stream().wait_event(self._opt_done)
             L.call("hs_vit_cast_weights", C.byref(self.desc), self._lp, self.w16.data_ptr(), Fn._p(self.w16t), Fn._s())
             self._wkey = key
 
@@ -347,6 +381,19 @@ class EncoderUnit:
             _seeds(self.edesc, self.model.training)
         self.sync_weights()
         ews, ewb = self._embed_ws()
+        if self._pending:
+            # an overlapped optimizer pass is (or was) updating this encoder chunk by chunk on another stream: every forward chunk waits
+            # for the sweep of ITS parameters only -- the rest of the optimizer pass runs beside the first layers
+            self._pending = False
+            cur = torch.cuda.current_stream()
+            for k, (lo, hi) in enumerate(self.fwd_chunks):
+                cur.wait_event(self._events[k])
+                if k == 0:
+                    L.call("hs_embed_fwd", C.byref(self.edesc), patches.data_ptr(), Fn._p(image_2d) if self.scorer else None, self._ep,
+                           self.x0.data_ptr(), ews, ewb, s)
+                L.call("hs_vit_blocks_fwd_range", C.byref(self.desc), self.x0.data_ptr(), self._lp, self._np, self.y.data_ptr(),
+                       self.hidden.data_ptr(), self.ws_ptr, self.ws_bytes, lo, hi, s)
+            return self.y
         L.call("hs_embed_fwd", C.byref(self.edesc), patches.data_ptr(), Fn._p(image_2d) if self.scorer else None, self._ep,
                self.x0.data_ptr(), ews, ewb, s)
         L.call("hs_vit_blocks_fwd", C.byref(self.desc), self.x0.data_ptr(), self._lp, self._np, self.y.data_ptr(),
@@ -487,14 +534,68 @@ class _Engine:
     def _begin_backward(self) -> None:
         """the flat gradient must be zero when a backward starts accumulating into it: it is after an optimizer pass (zeroed inside
         the sweep) and at construction; after a backward that was NOT followed by one (optimizer=False, keep_grads) it is cleared here."""
+        self.wait_optimizer()                      # (an overlapped optimizer pass zeroes the gradient and re-makes the transposed copies)
         self.params.zero_grad()
         self.params.grad_dirty = True
 
+    # overlap_optimizer (DualEngine / FlatEncoder; default: on unless keep_grads): the optimizer pass does not end the step, it OPENS the
+    # next one.  After the norm and the one-thread prologue on the step's stream, AdamW sweeps the flat buffer range by range on a third
+    # stream in the order the next forward needs the parameters (encoders' layer chunks interleaved, bottom-up; packers and everything
+    # else last) and records an event per chunk; the next forward's chunks wait for their events only, the packers / the backward for the
+    # whole pass.  AdamW is HBM-bound, the forward's first layers MFMA-bound: at one volume per GPU 1.2 of the step's 15 ms leave the
+    # critical path.  Reading parameters from another stream right after train_step() needs wait_optimizer() (or a device synchronize).
+    overlap_optimizer = False
+    _opt_done = None
+
+    def _opt_plan(self):
+        """[(a, b, unit or None, chunk)] partitioning the flat buffer: the trained encoders' forward chunks round-robin, then the rest."""
+        plan = getattr(self, "_opt_plan_cache", None)
+        if plan is None:
+            per_unit = [[(a, b, u, k) for k, (a, b) in enumerate(u.flat_chunk_ranges(self.params))] for u in self._trained_units()]
+            plan = [x[k] for k in range(max((len(x) for x in per_unit), default=0)) for x in per_unit if k < len(x)]
+            pos, rest = 0, []
+            for a, b in sorted((a, b) for a, b, _, _ in plan):
+                if a < pos:
+                    raise L.HsError("optimizer plan: encoder ranges overlap")
+                if a > pos:
+                    rest.append((pos, a, None, -1))
+                pos = b
+            if pos < self.params.total:
+                rest.append((pos, self.params.total, None, -1))
+            plan = self._opt_plan_cache = plan + rest
+        return plan
+
+    def wait_optimizer(self) -> None:
+        """order the current stream behind an overlapped optimizer pass (no-op otherwise)."""
+        if self._opt_done is not None:
+            torch.cuda.current_stream().wait_event(self._opt_done)
+
     def optimizer_step(self) -> None:
-        self.params.step(lr=self.lr, weight_decay=self.wd, grad_scale=self.buckets.grad_scale / self.loss_scale,
-                         max_grad_norm=self.max_grad_norm, zero_grad=not self.keep_grads)
-        for u in self._trained_units():
-            u.after_step()
+        hyper = dict(lr=self.lr, weight_decay=self.wd, grad_scale=self.buckets.grad_scale / self.loss_scale, max_grad_norm=self.max_grad_norm,
+                     zero_grad=not self.keep_grads)
+        units = self._trained_units()
+        if not self.overlap_optimizer or os.environ.get("HS_LEGACY_STEP") == "1" or not units:
+            self.params.step(**hyper)
+            for u in units:
+                u.after_step()
+            return
+        self.params.prepare(**hyper)
+        cur, opt = torch.cuda.current_stream(), optimizer_stream(self.dev)
+        opt.wait_stream(cur)
+        if self._opt_done is None:
+            self._opt_done = torch.cuda.Event()
+        with torch.cuda.stream(opt):
+            for a, b, u, k in self._opt_plan():
+                self.params.sweep(a, b)
+                if u is not None:
+                    u._events[k].record(opt)
+            for u in units:
+                u.after_step()                      # the transposed 16-bit copies (needed by the next BACKWARD)
+            self._opt_done.record(opt)
+        for u in units:
+            u._pending, u._opt_done = True, self._opt_done
+        if not self.keep_grads:
+            self.params.grad_dirty = False
 
     def unscaled_grad(self) -> torch.Tensor:
         """the flat gradient without the loss scale (a copy when the scale is not 1)."""
@@ -547,7 +648,7 @@ class FlatEncoder(_Engine):
 
     def __init__(self, model, batch: int, *, lr=1e-4, weight_decay=0.1, max_grad_norm: Optional[float] = 1.0, n_buckets=4, group=None,
                  grad_wire="fp32", grad_algo="allreduce", recompute_mlp: bool = False, precision: str = "bf16",
-                 loss_scale: Optional[float] = None, keep_grads: Optional[bool] = None):
+                 loss_scale: Optional[float] = None, keep_grads: Optional[bool] = None, overlap_optimizer: Optional[bool] = None):
         self.prec = _engine_prec(precision)
         self.unit = EncoderUnit(model, batch, trainable=True, recompute_mlp=recompute_mlp, prec=self.prec)
         self.model, self.dev, self.B = model, self.unit.dev, batch
@@ -560,6 +661,7 @@ class FlatEncoder(_Engine):
         self.layer_chunks, bounds = _encoder_bounds(self.unit, probe_names, offs, "", 0, off, n_buckets)
         self._finish(entries, bounds, lr=lr, weight_decay=weight_decay, max_grad_norm=max_grad_norm, group=group,
                      grad_wire=grad_wire, grad_algo=grad_algo, keep_grads=keep_grads)
+        self.overlap_optimizer = (not self.keep_grads) if overlap_optimizer is None else bool(overlap_optimizer)
         self.unit.bind(self.params)
         u = self.unit
         self.patches = torch.empty(batch * u.Np, u.Pd, dtype=self.dtype16, device=self.dev)
@@ -600,7 +702,8 @@ class DualEngine(_Engine):
     def __init__(self, tower: ViT3DTower_dual_encoders, packer1: VisualPacker_3d_phi_v3, packer2: VisualPacker_3d_phi_v3, batch: int, *,
                  lr=1e-4, weight_decay=0.1, max_grad_norm: Optional[float] = 1.0, n_buckets=4, group=None,
                  two_streams: Optional[bool] = None, grad_wire="fp32", grad_algo="allreduce", recompute_mlp: bool = False,
-                 precision: str = "bf16", loss_scale: Optional[float] = None, keep_grads: Optional[bool] = None):
+                 precision: str = "bf16", loss_scale: Optional[float] = None, keep_grads: Optional[bool] = None,
+                 overlap_optimizer: Optional[bool] = None):
         """recompute_mlp: see EncoderUnit (activation memory 3.7 -> 2.5 GB per 256^3 volume for one more GEMM per layer in the backward).
         precision / loss_scale: see _Engine."""
         self.prec = _engine_prec(precision)
@@ -633,6 +736,7 @@ class DualEngine(_Engine):
         bounds = [(sp2, off), (sp, sp2)] + b2 + b1
         self._finish(entries, bounds, lr=lr, weight_decay=weight_decay, max_grad_norm=max_grad_norm, group=group,
                      grad_wire=grad_wire, grad_algo=grad_algo, keep_grads=keep_grads)
+        self.overlap_optimizer = (not self.keep_grads) if overlap_optimizer is None else bool(overlap_optimizer)
         for u in (self.u1, self.u2, self.p1, self.p2):
             u.bind(self.params)
         self.patches = torch.empty(batch * self.u1.Np, self.u1.Pd, dtype=self.dtype16, device=self.dev)
@@ -666,8 +770,12 @@ class DualEngine(_Engine):
     def forward(self, vol: torch.Tensor, image_2d: torch.Tensor) -> torch.Tensor:
         self._patchify(vol, self.tower.vision_tower_stage1.patch_embedding, self.patches)
         with self._fork():
-            self.p2.forward(self.u2.forward(self.patches, image_2d), self.out)
-        self.p1.forward(self.u1.forward(self.patches), self.out)
+            y2 = self.u2.forward(self.patches, image_2d)
+            self.wait_optimizer()                  # (the packers' parameters are swept last by an overlapped optimizer pass)
+            self.p2.forward(y2, self.out)
+        y1 = self.u1.forward(self.patches)
+        self.wait_optimizer()
+        self.p1.forward(y1, self.out)
         self._join()
         return self.out
 

@@ -32,12 +32,13 @@ from . import functional as Fn
 _SIDE = {}
 
 
-def _pick_concurrent_stream(device, candidates: int = 4) -> torch.cuda.Stream:
-    """a stream whose kernels really run BESIDE the current stream's.  HIP multiplexes a process' streams onto a few hardware queues
-    (GPU_MAX_HW_QUEUES, 4 by default): a new stream that lands on the queue of the stream it is meant to overlap with runs its kernels
-    strictly after that stream's -- the 2E3 chain then adds nothing (measured in round 6: the same engine at 3 volumes per GPU 87.8 or
-    74.3 volumes/s depending on how many streams the process had created before).  So: try a few consecutive pool streams, time two
-    ~1-ms spin kernels issued to the current stream and to the candidate, keep the first candidate that overlaps them."""
+def _pick_concurrent_stream(device, candidates: int = 4, beside=()) -> torch.cuda.Stream:
+    """a stream whose kernels really run BESIDE the current stream's (and beside those of every stream in `beside`).  HIP multiplexes a
+    process' streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default): a new stream that lands on the queue of the stream it
+    is meant to overlap with runs its kernels strictly after that stream's -- the 2E3 chain then adds nothing (measured in round 6: the
+    same engine at 3 volumes per GPU 87.8 or 74.3 volumes/s depending on how many streams the process had created before).  So: try a few
+    consecutive pool streams, time ~1-ms spin kernels issued to the current stream, to `beside` and to the candidate, keep the first
+    candidate with which they all overlap."""
     cands = [torch.cuda.Stream(device=device) for _ in range(candidates)]
     sleep = getattr(torch.cuda, "_sleep", None)
     if sleep is None:
@@ -45,37 +46,52 @@ def _pick_concurrent_stream(device, candidates: int = 4) -> torch.cuda.Stream:
     import time
     cycles = 2_000_000                                   # ~1 ms at 2 GHz
 
-    def timed(other) -> float:
+    def timed(others) -> float:
         torch.cuda.synchronize(device)
         t0 = time.perf_counter()
         sleep(cycles)
-        if other is not None:
-            with torch.cuda.stream(other):
+        for o in others:                                 # (no dependencies: the spins must be free to overlap)
+            with torch.cuda.stream(o):
                 sleep(cycles)
         torch.cuda.synchronize(device)
         return time.perf_counter() - t0
     with torch.cuda.device(device):
-        timed(None)                                      # warm-up (first launch, lazy init)
-        one = min(timed(None) for _ in range(2))
+        timed(())                                        # warm-up (first launch, lazy init)
+        one = min(timed(()) for _ in range(2))
         best, best_t = cands[0], None
         for c in cands:
-            t = min(timed(c) for _ in range(2))
+            t = min(timed(tuple(beside) + (c,)) for _ in range(2))
             if best_t is None or t < best_t:
                 best, best_t = c, t
-            if t < 1.5 * one:                            # the two spins overlapped
+            if t < 1.5 * one:                            # all spins overlapped
                 return c
     return best
 
 
-def side_stream(device) -> torch.cuda.Stream:
-    """the process-wide side stream of `device` for the stream that is current now (engines and the module API share it)."""
+def _key(device):
     device = torch.device(device) if not isinstance(device, torch.device) else device
     if device.index is None:
         device = torch.device("cuda", torch.cuda.current_device())
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    return device, (device.index, torch.cuda.current_stream(device).cuda_stream)
+
+
+def side_stream(device) -> torch.cuda.Stream:
+    """the process-wide side stream of `device` for the stream that is current now (engines and the module API share it)."""
+    device, key = _key(device)
     s = _SIDE.get(key)
     if s is None:
         s = _SIDE[key] = _pick_concurrent_stream(device)
+    return s
+
+
+def optimizer_stream(device) -> torch.cuda.Stream:
+    """a third stream that runs beside BOTH the current stream and side_stream(device): the engines' optimizer sweeps overlap the next
+    forward's two chains on it."""
+    device, key = _key(device)
+    key = key + ("opt",)
+    s = _SIDE.get(key)
+    if s is None:
+        s = _SIDE[key] = _pick_concurrent_stream(device, beside=(side_stream(device),))
     return s
 
 

@@ -275,6 +275,13 @@ size_t hs_vit_weights_elems(const hs_vit_desc* desc);
 int hs_vit_cast_weights(const hs_vit_desc* desc, const float* const* layer_params, void* w16, void* w16t, void* stream);
 int hs_vit_blocks_fwd(const hs_vit_desc* desc, const float* x0, const float* const* layer_params,
                       const float* const* norm_params, float* y, float* hidden, void* ws, size_t ws_bytes, void* stream);
+/* the same for layers [l_lo, l_hi) only (x0 is read when l_lo == 0; the final norm runs and y is written when l_hi == L): a caller whose
+ * optimizer pass overlaps the forward (hs_adamw_fused, HS_ADAMW_SWEEP) enqueues the stack chunk by chunk, each behind the event of the
+ * sweep that updated its layers.  A proper sub-range needs caller-owned weight copies (desc.w16) in the 16-bit precisions: the
+ * per-call cast of ALL layers' weights cannot run before the later layers' sweeps have. */
+int hs_vit_blocks_fwd_range(const hs_vit_desc* desc, const float* x0, const float* const* layer_params,
+                            const float* const* norm_params, float* y, float* hidden, void* ws, size_t ws_bytes, int l_lo, int l_hi,
+                            void* stream);
 /* backward of the above (either precision; the save_for_bwd=1 forward must have run on the same ws).
  * dy: [B][N][d] fp32.  dx0: [B][N][d] fp32 out.  layer_grads / norm_grads: same order as the params; written
  * (weights) or accumulated atomically (biases, LN): the caller zeroes all gradient buffers before the call.
@@ -374,10 +381,18 @@ int hs_adamw_masked(float* p, const float* g, float* m, float* v, const unsigned
  *      not finite: an fp16 backward that overflowed its loss scale) does not advance it (torch.cuda.amp.GradScaler semantics) and
  *      the host can read both counters whenever it likes without a sync inside the step.
  *  grad_sumsq (device): squared norm of the summed gradient; required when max_grad_norm > 0, optional otherwise (given without
- *  clipping it only arms the non-finite skip).  n must be a multiple of 64. */
+ *  clipping it only arms the non-finite skip).  n must be a multiple of 64.
+ *  phase: HS_ADAMW_STEP = the whole pass over [p, p + n).  A caller that wants the optimizer pass to OVERLAP the next forward splits
+ *  it: one HS_ADAMW_PREPARE call (the one-thread prologue: skip decision, step counter, clip coefficient, bias corrections -> state;
+ *  p / g / m / v / n ignored) and then HS_ADAMW_SWEEP calls over disjoint 64-aligned ranges of the buffers (pointers advanced by the
+ *  range start, decay_mask and w16_table by start / 64) in the order the next forward needs the parameters, on any stream ordered behind
+ *  the prologue -- the engines sweep layer chunk by layer chunk on a side stream and let each forward chunk wait for its event. */
+#define HS_ADAMW_STEP 0
+#define HS_ADAMW_PREPARE 1
+#define HS_ADAMW_SWEEP 2
 int hs_adamw_fused(float* p, float* g, float* m, float* v, const unsigned char* decay_mask, int64_t n, float lr, float beta1,
                    float beta2, float eps, float weight_decay, float grad_scale, const float* grad_sumsq, float max_grad_norm,
-                   int zero_grad, const uint64_t* w16_table, int w16_is_f16, int32_t* state, void* stream);
+                   int zero_grad, const uint64_t* w16_table, int w16_is_f16, int32_t* state, int phase, void* stream);
 
 /* dst[b*dst_batch_stride + r*d + :] = src[b*src_batch_stride + r*d + :] for r < R, as fp32 and/or bf16: a block of R rows per batch
  * entry between two strided [B][.][d] tensors (the cls row of every volume: R = 1, src stride N*d = `[:, 0]`, CLIP_stage1.py:117;

@@ -189,13 +189,24 @@ def test_abi2_struct_size_weight_copies_and_fused_adamw_checks():
     # hs_adamw_fused: whole 64-element chunks, a state block, a norm when clipping, a positive gradient scale
     P = FAKE
     args = lambda **k: [k.get("p", P), P, P, P, None, k.get("n", 128), 1e-3, 0.9, 0.999, 1e-8, 0.1, k.get("gs", 1.0), k.get("gsq", None),
-                        k.get("mx", 0.0), 1, None, 0, k.get("st", P), None]
+                        k.get("mx", 0.0), 1, None, 0, k.get("st", P), k.get("phase", L.ADAMW_STEP), None]
     assert lib.hs_adamw_fused(*args(n=100)) == L.HS_ERR_SHAPE
     assert lib.hs_adamw_fused(*args(n=0)) == L.HS_ERR_SHAPE
     assert lib.hs_adamw_fused(*args(st=None)) == L.HS_ERR_ARG
     assert lib.hs_adamw_fused(*args(mx=1.0)) == L.HS_ERR_ARG                             # clipping without the gradient norm
     assert lib.hs_adamw_fused(*args(gs=0.0)) == L.HS_ERR_ARG
     assert lib.hs_adamw_fused(*args(p=P + 4)) == L.HS_ERR_SHAPE
+    assert lib.hs_adamw_fused(*args(phase=3)) == L.HS_ERR_ARG
+    assert lib.hs_adamw_fused(*args(phase=L.ADAMW_PREPARE, mx=1.0)) == L.HS_ERR_ARG      # the prologue owns the clip arguments ...
+    assert lib.hs_adamw_fused(*args(phase=L.ADAMW_SWEEP, n=100)) == L.HS_ERR_SHAPE       # ... a sweep the range
+    # the ranged forward: a proper sub-range of the 16-bit stack needs caller-owned weight copies
+    tbl2 = (C.c_void_p * 64)(*([FAKE] * 64))
+    v2 = L.VitDesc(1, 33, 768, 12, 3072, 2, L.PREC_BF16, 1, 0.0, None)
+    nb = lib.hs_vit_workspace_bytes(C.byref(v2))
+    assert lib.hs_vit_blocks_fwd_range(C.byref(v2), FAKE, tbl2, tbl2, FAKE, FAKE, 1 << 20, nb, 1, 2, None) == L.HS_ERR_ARG
+    assert lib.hs_vit_blocks_fwd_range(C.byref(v2), FAKE, tbl2, tbl2, FAKE, FAKE, 1 << 20, nb, 0, 3, None) == L.HS_ERR_SHAPE
+    assert lib.hs_vit_blocks_fwd_range(C.byref(v2), FAKE, tbl2, tbl2, FAKE, FAKE, 1 << 20, nb, 1, 1, None) == L.HS_ERR_SHAPE
+    assert lib.hs_vit_blocks_fwd_range(C.byref(v2), None, tbl2, tbl2, FAKE, FAKE, 1 << 20, nb, 0, 2, None) == L.HS_ERR_ARG
 
 
 def test_debug_selector_is_inert_in_the_product_build(capfd):

@@ -96,7 +96,7 @@ def test_adamw_fused_equals_masked_and_writes_the_copies(dev, f16):
     gsq.fill_(float("inf"))
     before = (pb.clone(), mb.clone(), vb.clone(), w16.clone())
     L.call("hs_adamw_fused", pb.data_ptr(), gb.data_ptr(), mb.data_ptr(), vb.data_ptr(), mask.data_ptr(), n, 1e-2, 0.9, 0.999, 1e-8, 0.1, 0.5,
-           gsq.data_ptr(), 1.0, 1, table_d.data_ptr(), f16, state.data_ptr(), s)
+           gsq.data_ptr(), 1.0, 1, table_d.data_ptr(), f16, state.data_ptr(), L.ADAMW_STEP, s)
     assert all(torch.equal(a, b) for a, b in zip(before, (pb, mb, vb, w16))) and float(gb.abs().max()) == 0.0
     assert state[:2].tolist() == [3, 1]
     # the next good step is step 4 (bias corrections from the device counter), zero_grad = 0 leaves g alone, no norm = no clip
@@ -105,8 +105,29 @@ def test_adamw_fused_equals_masked_and_writes_the_copies(dev, f16):
     L.call("hs_adamw_masked", pa.data_ptr(), ga.data_ptr(), ma.data_ptr(), va.data_ptr(), mask.data_ptr(), n, 1e-2, 0.9, 0.999, 1e-8, 0.1, 0.5,
            None, 0.0, 4, s)
     L.call("hs_adamw_fused", pb.data_ptr(), gb.data_ptr(), mb.data_ptr(), vb.data_ptr(), mask.data_ptr(), n, 1e-2, 0.9, 0.999, 1e-8, 0.1, 0.5,
-           None, 0.0, 0, None, f16, state.data_ptr(), s)
+           None, 0.0, 0, None, f16, state.data_ptr(), L.ADAMW_STEP, s)
     assert rel(pb, pa) < 1e-6 and torch.equal(gb, g) and state[:2].tolist() == [4, 1]
+    # the pass split for overlap: ONE prologue, then sweeps over disjoint ranges in any order = the one-call pass, bit for bit
+    pc, mc, vc = pb.clone(), mb.clone(), vb.clone()
+    g = torch.randn(n, device=dev) * 0.01
+    gb, gc = g.clone(), g.clone()
+    st2 = state.clone()
+    L.call("hs_sumsq", gb.data_ptr(), gsq.data_ptr(), scratch.data_ptr(), n, s)
+    wb, wc = w16.clone(), w16.clone()
+    tb = table.clone()
+    tb[mapped] = wb.data_ptr() + 128 * torch.arange(n // 64)[mapped]
+    tc = table.clone()
+    tc[mapped] = wc.data_ptr() + 128 * torch.arange(n // 64)[mapped]
+    tb, tc = tb.to(dev), tc.to(dev)
+    common = (1e-2, 0.9, 0.999, 1e-8, 0.1, 0.5, gsq.data_ptr(), 1.0, 1)
+    L.call("hs_adamw_fused", pb.data_ptr(), gb.data_ptr(), mb.data_ptr(), vb.data_ptr(), mask.data_ptr(), n, *common, tb.data_ptr(), f16,
+           state.data_ptr(), L.ADAMW_STEP, s)
+    L.call("hs_adamw_fused", None, None, None, None, None, 0, *common, None, f16, st2.data_ptr(), L.ADAMW_PREPARE, s)
+    for a, b in ((64 * 600, n), (0, 64 * 200), (64 * 200, 64 * 600)):
+        L.call("hs_adamw_fused", pc.data_ptr() + 4 * a, gc.data_ptr() + 4 * a, mc.data_ptr() + 4 * a, vc.data_ptr() + 4 * a, mask.data_ptr() + a // 64,
+               b - a, *common, tc.data_ptr() + 8 * (a // 64), f16, st2.data_ptr(), L.ADAMW_SWEEP, s)
+    assert torch.equal(pb, pc) and torch.equal(mb, mc) and torch.equal(vb, vc) and torch.equal(wb, wc) and float(gc.abs().max()) == 0.0
+    assert st2[:2].tolist() == state[:2].tolist() == [5, 1]
 
 
 # ------------------------------------------------------------------------------------------------------------------------------------
@@ -239,6 +260,55 @@ def test_fused_optimizer_sweep_equals_keep_grads_path(dev):
                 assert eng.step_no == 4 and eng.skipped_steps == 1 and bool(torch.isfinite(eng.flat).all())
         noise, diff = rel(upd[1], upd[0]), rel(upd[2], upd[0])
         assert diff < max(3 * noise, 1e-3) and diff < 0.1, (prec, noise, diff)
+
+
+def test_overlapped_optimizer_pass_walks_the_same_trajectory(dev):
+    """overlap_optimizer=True (the default outside the test-suite): the optimizer pass sweeps the flat buffer chunk by chunk on a third
+    stream, the next forward's chunks wait for their events only, packers and backward for the whole pass.  Same trajectory as the
+    synchronous pass over five steps with two streams on (bf16 and fp16), a forward / state_dict read in between, an in-place weight
+    edit while a pass may be in flight, and the plan partitions the flat buffer."""
+    from hsenet_amd.engine import DualEngine, FlatEncoder
+    import hsenet_amd as H
+    x, s2d = _inputs(2, 140, dev)
+    start = torch.cat([p.detach().flatten() for m in _modules(dev, 150) for p in m.parameters()])
+    for prec in ("bf16", "f16"):
+        upd = []
+        for overlap in (False, False, True):
+            t, a, b = _modules(dev, 150)
+            eng = DualEngine(t, a, b, 2, lr=1e-3, precision=prec, keep_grads=False, overlap_optimizer=overlap, two_streams=True)
+            assert eng.overlap_optimizer is overlap
+            if overlap:
+                plan = eng._opt_plan()
+                assert sorted((a_, b_) for a_, b_, _, _ in plan)[0][0] == 0 and sum(b_ - a_ for a_, b_, _, _ in plan) == eng.params.total
+                assert [k for _, _, u, k in plan if u is eng.u1] == [0, 1] and [u is None for _, _, u, _ in plan][-1]
+            for i in range(5):
+                eng.train_step(x, s2d)
+                if i == 1:
+                    y = eng.forward(x, s2d).clone()                  # an extra forward between steps (waits per chunk, packers for the pass)
+                    eng.wait_optimizer()
+                    assert bool(torch.isfinite(y).all()) and bool(torch.isfinite(eng.flat).all())
+                if i == 2:
+                    with torch.no_grad():
+                        t.vision_tower_stage1.blocks[1].attn.qkv.weight.mul_(1.0)      # a version bump while the pass may be in flight
+            eng.wait_optimizer()
+            torch.cuda.synchronize()
+            assert eng.step_no == 5 and eng.skipped_steps == 0 and float(eng.grad.abs().max()) == 0.0
+            now = torch.cat([p.detach().flatten() for m in (t, a, b) for p in m.parameters()])
+            upd.append(now - start)
+        noise, diff = rel(upd[1], upd[0]), rel(upd[2], upd[0])
+        assert diff < max(3 * noise, 1e-3) and diff < 0.1, (prec, noise, diff)
+    # one encoder (configs[1]) and the 16-bit copies after an overlapped pass: what the next forward multiplies with IS the updated master
+    m = H.ViT_stage1(in_channels=1, img_size=IMG, patch_size=PATCH, num_layers=2, pos_embed="perceptron", classification=True).to(dev)
+    fe = FlatEncoder(m, 2, lr=1e-2, keep_grads=False, overlap_optimizer=True)
+    for _ in range(2):
+        fe.train_step(x)
+    fe.wait_optimizer()
+    torch.cuda.synchronize()
+    W = m.blocks[1].mlp.linear2.weight
+    per = fe.unit.w_elems // fe.unit.Ln
+    o = per + 4 * 768 * 768 + 3072 * 768
+    assert torch.equal(fe.unit.w16[o:o + W.numel()].view(W.shape), W.detach().to(torch.bfloat16))
+    assert torch.equal(fe.unit.w16t[o:o + W.numel()].view(W.shape[1], W.shape[0]), W.detach().to(torch.bfloat16).t())
 
 
 # ------------------------------------------------------------------------------------------------------------------------------------

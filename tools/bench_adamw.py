@@ -39,7 +39,7 @@ def masked():
 
 def fused(zero=1, tab=True):
     L.call("hs_adamw_fused", p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), mask.data_ptr(), n, 1e-4, 0.9, 0.999, 1e-8, 0.1, 1.0,
-           gsq.data_ptr(), 1.0, zero, table.data_ptr() if tab else None, 0, state.data_ptr(), s)
+           gsq.data_ptr(), 1.0, zero, table.data_ptr() if tab else None, 0, state.data_ptr(), L.ADAMW_STEP, s)
 
 
 L.call("hs_sumsq", g.data_ptr(), gsq.data_ptr(), scratch.data_ptr(), n, s)
