@@ -11,6 +11,7 @@
 // Precision follows the reference's autocast policy exactly as the block driver does: Linear operands bf16 with fp32
 // accumulation, everything else (softmax, LayerNorm, sigmoid, pooling, residuals, all parameter gradients) fp32.
 #include "driver.h"
+#include <cstdlib>
 #include <vector>
 
 using namespace hsdrv;
@@ -581,39 +582,42 @@ __global__ __launch_bounds__(256) void adamw_fused_kernel(float* __restrict__ p,
                                                           float* __restrict__ v, const unsigned char* __restrict__ decay, long n, float lr,
                                                           float b1, float b2, float eps, float wd, int zero_grad,
                                                           const uint64_t* __restrict__ table, const int32_t* __restrict__ st) {
-    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
-    if (i >= n) return;
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-    if (st[2]) {                  // skipped step: parameters, moments and 16-bit copies stay; the overflowed gradient is discarded
-        if (zero_grad) *(f32x4*)(g + i) = z4;
-        return;
-    }
+    const bool skip = st[2] != 0;  // skipped step: parameters, moments and 16-bit copies stay; the overflowed gradient is discarded
     const float* sf = (const float*)st;
     const float scale = sf[4], lr1 = lr / sf[5], bc2s = sf[6];
-    const float wde = (decay && !decay[i >> 6]) ? 0.f : wd;
-    f32x4 P = *(const f32x4*)(p + i), M = *(const f32x4*)(m + i), V = *(const f32x4*)(v + i);
-    const f32x4 G = *(const f32x4*)(g + i);
+    // grid-stride: the synchronous pass launches one block per 1024 elements (one trip); a sweep that runs BESIDE the next forward is
+    // launched with a capped grid so that it leaves wave slots and HBM bandwidth to the forward's kernels (hs_adamw_fused)
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long)gridDim.x * 1024) {
+        if (skip) {
+            if (zero_grad) *(f32x4*)(g + i) = z4;
+            continue;
+        }
+        const float wde = (decay && !decay[i >> 6]) ? 0.f : wd;
+        f32x4 P = *(const f32x4*)(p + i), M = *(const f32x4*)(m + i), V = *(const f32x4*)(v + i);
+        const f32x4 G = *(const f32x4*)(g + i);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const float gr = G[e] * scale;
-        float pv = P[e] * (1.0f - lr * wde);
-        const float mv = b1 * M[e] + (1.0f - b1) * gr;
-        const float vv = b2 * V[e] + (1.0f - b2) * gr * gr;
-        M[e] = mv;
-        V[e] = vv;
-        pv -= lr1 * mv / (sqrtf(vv) / bc2s + eps);
-        P[e] = pv;
-    }
-    *(f32x4*)(p + i) = P;
-    *(f32x4*)(m + i) = M;
-    *(f32x4*)(v + i) = V;
-    if (zero_grad) *(f32x4*)(g + i) = z4;
-    if (table) {
-        const uint64_t dst = table[i >> 6];
-        if (dst) {
-            u32x2 pk;
-            pk[0] = pack2h<F16>(P[0], P[1]); pk[1] = pack2h<F16>(P[2], P[3]);
-            *(u32x2*)(uintptr_t)(dst + (uint64_t)((i & 63) * 2)) = pk;
+        for (int e = 0; e < 4; ++e) {
+            const float gr = G[e] * scale;
+            float pv = P[e] * (1.0f - lr * wde);
+            const float mv = b1 * M[e] + (1.0f - b1) * gr;
+            const float vv = b2 * V[e] + (1.0f - b2) * gr * gr;
+            M[e] = mv;
+            V[e] = vv;
+            pv -= lr1 * mv / (sqrtf(vv) / bc2s + eps);
+            P[e] = pv;
+        }
+        *(f32x4*)(p + i) = P;
+        *(f32x4*)(m + i) = M;
+        *(f32x4*)(v + i) = V;
+        if (zero_grad) *(f32x4*)(g + i) = z4;
+        if (table) {
+            const uint64_t dst = table[i >> 6];
+            if (dst) {
+                u32x2 pk;
+                pk[0] = pack2h<F16>(P[0], P[1]); pk[1] = pack2h<F16>(P[2], P[3]);
+                *(u32x2*)(uintptr_t)(dst + (uint64_t)((i & 63) * 2)) = pk;
+            }
         }
     }
 }
@@ -636,7 +640,12 @@ extern "C" int hs_adamw_fused(float* p, float* g, float* m, float* v, const unsi
                            max_grad_norm > 0.f ? max_grad_norm : 0.f, beta1, beta2);
     if (phase != HS_ADAMW_PREPARE) {
         ProfScope prof(HS_PROF_ADAMW, stream, 0, (double)n * (28 + (zero_grad ? 4 : 0)));
-        const dim3 grid((unsigned)((n + 1023) / 1024)), blk(256);
+        // HS_ADAMW_SWEEP runs beside the next forward: a capped grid (default 2048 blocks = 8 per CU's worth of 256-thread blocks on
+        // 256 CUs; HS_ADAMW_SWEEP_BLOCKS, read once) bounds the wave slots and the HBM bandwidth it takes from the forward's kernels
+        static const long sweep_cap = getenv("HS_ADAMW_SWEEP_BLOCKS") ? atol(getenv("HS_ADAMW_SWEEP_BLOCKS")) : 2048;
+        long nb = (n + 1023) / 1024;
+        if (phase == HS_ADAMW_SWEEP && sweep_cap > 0 && nb > sweep_cap) nb = sweep_cap;
+        const dim3 grid((unsigned)nb), blk(256);
         if (w16_is_f16) hipLaunchKernelGGL(adamw_fused_kernel<true>, grid, blk, 0, (hipStream_t)stream, p, g, m, v, decay_mask, (long)n, lr, beta1,
                                            beta2, eps, weight_decay, zero_grad, w16_table, (const int32_t*)state);
         else hipLaunchKernelGGL(adamw_fused_kernel<false>, grid, blk, 0, (hipStream_t)stream, p, g, m, v, decay_mask, (long)n, lr, beta1, beta2,

@@ -538,12 +538,15 @@ class _Engine:
         self.params.zero_grad()
         self.params.grad_dirty = True
 
-    # overlap_optimizer (DualEngine / FlatEncoder; default: on unless keep_grads): the optimizer pass does not end the step, it OPENS the
-    # next one.  After the norm and the one-thread prologue on the step's stream, AdamW sweeps the flat buffer range by range on a third
-    # stream in the order the next forward needs the parameters (encoders' layer chunks interleaved, bottom-up; packers and everything
-    # else last) and records an event per chunk; the next forward's chunks wait for their events only, the packers / the backward for the
-    # whole pass.  AdamW is HBM-bound, the forward's first layers MFMA-bound: at one volume per GPU 1.2 of the step's 15 ms leave the
-    # critical path.  Reading parameters from another stream right after train_step() needs wait_optimizer() (or a device synchronize).
+    # overlap_optimizer (DualEngine / FlatEncoder; default OFF): the optimizer pass does not end the step, it opens the next one.  After
+    # the norm and the one-thread prologue on the step's stream, AdamW sweeps the flat buffer range by range on a third stream in the
+    # order the next forward needs the parameters (encoders' layer chunks interleaved, bottom-up; packers and everything else last) and
+    # records an event per chunk; the next forward's chunks wait for their events only, the packers / the backward for the whole pass.
+    # MEASURED (round 6, same process, interleaved): 14.93 -> 14.7-14.9 ms at one volume per GPU, 34.3 -> 33.9 ms at three (+0.5 / +1 %),
+    # i.e. almost nothing of AdamW's 1.2 ms is hidden: the forward's GEMM blocks (8 waves x 256 VGPRs = a CU's whole register file) and
+    # attention blocks (half of it) cannot be placed on a CU that holds even one AdamW wave, so the two do not really share the chip --
+    # a capped grid (HS_ADAMW_SWEEP_BLOCKS) or a low-priority stream changes nothing.  Kept as an option; off by default because
+    # reading parameters from another stream right after train_step() then needs wait_optimizer() (or a device synchronize).
     overlap_optimizer = False
     _opt_done = None
 
@@ -661,7 +664,7 @@ class FlatEncoder(_Engine):
         self.layer_chunks, bounds = _encoder_bounds(self.unit, probe_names, offs, "", 0, off, n_buckets)
         self._finish(entries, bounds, lr=lr, weight_decay=weight_decay, max_grad_norm=max_grad_norm, group=group,
                      grad_wire=grad_wire, grad_algo=grad_algo, keep_grads=keep_grads)
-        self.overlap_optimizer = (not self.keep_grads) if overlap_optimizer is None else bool(overlap_optimizer)
+        self.overlap_optimizer = bool(overlap_optimizer)
         self.unit.bind(self.params)
         u = self.unit
         self.patches = torch.empty(batch * u.Np, u.Pd, dtype=self.dtype16, device=self.dev)
@@ -736,7 +739,7 @@ class DualEngine(_Engine):
         bounds = [(sp2, off), (sp, sp2)] + b2 + b1
         self._finish(entries, bounds, lr=lr, weight_decay=weight_decay, max_grad_norm=max_grad_norm, group=group,
                      grad_wire=grad_wire, grad_algo=grad_algo, keep_grads=keep_grads)
-        self.overlap_optimizer = (not self.keep_grads) if overlap_optimizer is None else bool(overlap_optimizer)
+        self.overlap_optimizer = bool(overlap_optimizer)
         for u in (self.u1, self.u2, self.p1, self.p2):
             u.bind(self.params)
         self.patches = torch.empty(batch * self.u1.Np, self.u1.Pd, dtype=self.dtype16, device=self.dev)
