@@ -52,7 +52,7 @@ class _Desc(C.Structure):
 class VitDesc(_Desc):
     _fields_ = [("struct_size", C.c_uint32), ("B", C.c_int), ("N", C.c_int), ("d", C.c_int), ("H", C.c_int), ("mlp", C.c_int), ("L", C.c_int),
                 ("prec", C.c_int), ("save_for_bwd", C.c_int), ("ln_eps", C.c_float), ("qkv_bias", C.c_void_p),
-                ("w16", C.c_void_p), ("w16t", C.c_void_p)]
+                ("w16", C.c_void_p), ("w16t", C.c_void_p), ("qkv_bias_grad", C.c_void_p)]
 
 
 class EmbedDesc(_Desc):

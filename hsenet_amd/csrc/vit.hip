@@ -87,7 +87,7 @@ int check_desc(const hs_vit_desc* c) {
     if (c->save_for_bwd < 0 || c->save_for_bwd > 2) return HS_ERR_ARG;
     if (c->save_for_bwd == 2 && c->prec == HS_PREC_F32) return HS_ERR_ARG;   // MLP recompute: the 16-bit paths' option
     if (c->ln_eps < 0.f) return HS_ERR_ARG;
-    if (c->qkv_bias && c->save_for_bwd) return HS_ERR_ARG;          // the biased projection is forward-only
+    if (c->qkv_bias_grad && !c->qkv_bias) return HS_ERR_ARG;
     return HS_OK;
 }
 
@@ -239,7 +239,7 @@ extern "C" int hs_vit_blocks_bwd(const hs_vit_desc* desc, const float* x0, const
                                  size_t ws_bytes, int l_hi, int l_lo, void* stream) {
     RC(check_desc(desc));
     const hs_vit_desc& c = *desc;
-    if (!c.save_for_bwd || c.qkv_bias) return HS_ERR_ARG;
+    if (!c.save_for_bwd) return HS_ERR_ARG;
     if (!x0 || !lp || !np || !lg || !hidden || !ws) return HS_ERR_ARG;
     if (l_lo < 0 || l_hi > c.L || l_lo >= l_hi) return HS_ERR_SHAPE;
     if (l_hi == c.L && (!dy || !ng)) return HS_ERR_ARG;
@@ -321,6 +321,8 @@ extern "C" int hs_vit_blocks_bwd(const hs_vit_desc* desc, const float* x0, const
             if (nt) RC(gemm(P, HS_GEMM_NT, dx_mid, wot, M, d, d, d, d, nullptr, dob, d, nullptr, nullptr, nullptr, nullptr, 0, 1, stream));
             else RC(gemm(P, HS_GEMM_NN, dx_mid, wo, M, d, d, d, d, nullptr, dob, d, nullptr, nullptr, nullptr, nullptr, 0, 1, stream));
             RC(hs_attn_bwd(qkv, o, dob, lse, dqkv, delta, c.B, c.N, c.H, 64, HS_ATTN_Q_PRESCALED | (f16 ? HS_ATTN_F16 : 0), stream));
+            // qkv_bias=True: d(bias) = column sums of dqkv (hs_attn_bwd returns the gradient of the UNSCALED q, k, v)
+            if (c.qkv_bias_grad && c.qkv_bias_grad[l]) RC(hs_colsum(dqkv, 1 + f16, c.qkv_bias_grad[l], M, 3 * d, 3 * d, stream));
             if (nt) RC(gemm(P, HS_GEMM_NT, dqkv, wqkvt, M, d, 3 * d, 3 * d, 3 * d, nullptr, dh, d, nullptr, nullptr, nullptr, nullptr, 0, 1, stream));
             else RC(gemm(P, HS_GEMM_NN, dqkv, wqkv, M, d, 3 * d, 3 * d, d, nullptr, dh, d, nullptr, nullptr, nullptr, nullptr, 0, 1, stream));
             float* dxo = (l == 0) ? dx0 : dx;
@@ -358,6 +360,7 @@ extern "C" int hs_vit_blocks_bwd(const hs_vit_desc* desc, const float* x0, const
                 wgrad_split(d, d, M, P), stream));
         RC(gemm(P, HS_GEMM_NN, dx, wo, M, d, d, d, d, dobf, nullptr, d, nullptr, nullptr, nullptr, nullptr, 0, 1, stream));
         RC(hs_attn_bwd(qkv, o, dob, lse, dqkv, delta, c.B, c.N, c.H, 64, HS_ATTN_F32, stream));
+        if (c.qkv_bias_grad && c.qkv_bias_grad[l]) RC(hs_colsum(dqkv, 0, c.qkv_bias_grad[l], M, 3 * d, 3 * d, stream));
         RC(gemm(P, HS_GEMM_TN, dqkv, h1, 3 * d, d, M, 3 * d, d, g[P_WQKV], nullptr, d, nullptr, nullptr, nullptr, nullptr, HS_EPI_ATOMIC,
                 wgrad_split(3 * d, d, M, P), stream));
         RC(gemm(P, HS_GEMM_NN, dqkv, wqkv, M, d, 3 * d, 3 * d, d, dhf, nullptr, d, nullptr, nullptr, nullptr, nullptr, 0, 1, stream));

@@ -87,6 +87,16 @@ class PatchEmbeddingBlock(nn.Module):
             nn.init.trunc_normal_(self.patch_embeddings[1].weight, mean=0.0, std=0.02, a=-2.0, b=2.0)
             nn.init.zeros_(self.patch_embeddings[1].bias)
 
+    def fused_weight_bias(self):
+        """(weight, bias) PARAMETERS whose memory the fused drivers can read as the [hidden, p1*p2*p3*c] projection of the patchified
+        volume, or None: the perceptron Linear always; the Conv3d when in_channels == 1 -- its [hidden, 1, p1, p2, p3] weight IS that
+        matrix in memory (with more channels the two orders differ: (c, p1, p2, p3) against (p1, p2, p3, c))."""
+        if self.pos_embed == "perceptron":
+            return self.patch_embeddings[1].weight, self.patch_embeddings[1].bias
+        if self.patch_embeddings.weight.shape[1] == 1:
+            return self.patch_embeddings.weight, self.patch_embeddings.bias
+        return None
+
     def linear_weight_bias(self):
         """(weight [hidden, p1*p2*p3*c], bias) of the patch projection in the rearranged feature order '(p1 p2 p3 c)' the patchify
         kernel emits; for 'conv' a (differentiable) re-ordering of the Conv3d weight [hidden, c, p1, p2, p3]."""
@@ -121,8 +131,6 @@ class TransformerBlock(nn.Module):
             raise ValueError("dropout_rate should be between 0 and 1.")
         if hidden_size % num_heads != 0:
             raise ValueError("hidden_size should be divisible by num_heads.")
-        if qkv_bias:
-            raise ValueError("qkv_bias=True is not on the HSENet hot path (vit.py:440 passes False)")
         if dropout_rate != 0.0:
             raise ValueError("dropout_rate must be 0.0 (the reference builds its blocks with 0.0, CLIP_stage1.py:30)")
         self.mlp = MLPBlock(hidden_size, mlp_dim, dropout_rate)
@@ -131,6 +139,8 @@ class TransformerBlock(nn.Module):
         self.norm2 = nn.LayerNorm(hidden_size)
 
     def ordered_params(self):
+        """the 11 tensors every block has, in MONAI's state-dict order (the drivers' layer_params); a qkv_bias=True block's
+        ``attn.qkv.bias`` travels separately (hs_vit_desc.qkv_bias / .qkv_bias_grad)."""
         return [self.mlp.linear1.weight, self.mlp.linear1.bias, self.mlp.linear2.weight, self.mlp.linear2.bias,
                 self.norm1.weight, self.norm1.bias, self.attn.out_proj.weight, self.attn.out_proj.bias,
                 self.attn.qkv.weight, self.norm2.weight, self.norm2.bias]
@@ -198,15 +208,15 @@ class _ViTBase(nn.Module):
 
     def _fused_ok(self, prec, *inputs) -> bool:
         """the fused embedding driver (one autograd node for P1 + token assembly + the 2E3 scorer) serves the 16-bit precisions of the
-        shipped 'perceptron' embedding; inputs that ask for a gradient (never the case for volumes / slice features) take the
-        per-operator Functions."""
-        return (prec != PREC_F32 and self.patch_embedding.pos_embed == "perceptron" and not _unfused()
+        shipped 'perceptron' embedding and of the constructors' default 'conv' embedding on one-channel volumes (fused_weight_bias);
+        inputs that ask for a gradient (never the case for volumes / slice features) take the per-operator Functions."""
+        return (prec != PREC_F32 and self.patch_embedding.fused_weight_bias() is not None and not _unfused()
                 and not any(isinstance(t, torch.Tensor) and t.requires_grad for t in inputs))
 
     def _head16(self):
         """the embedding driver's 16 parameter slots (hs_embed_*): [cls, pos, pe.w, pe.b, score.w, score.b, Wq, Wk, Wv, Wo (w, b each), norm.w, norm.b]."""
         pe = self.patch_embedding
-        head = [getattr(self, "cls_token", None), pe.position_embeddings, pe.patch_embeddings[1].weight, pe.patch_embeddings[1].bias]
+        head = [getattr(self, "cls_token", None), pe.position_embeddings, *pe.fused_weight_bias()]
         sga = getattr(self, "slice_guided_attention", None)
         if sga is not None:
             head += [self.patch_score_proj.weight, self.patch_score_proj.bias]
@@ -221,13 +231,18 @@ class _ViTBase(nn.Module):
         (y, hidden), = fused.run_encoders([fused.EncJob(self, x, image_2d, prec)])
         return y, hidden
 
+    def qkv_biases(self):
+        """[attn.qkv.bias per block] for qkv_bias=True encoders, [] otherwise."""
+        return [blk.attn.qkv.bias for blk in self.blocks] if len(self.blocks) and self.blocks[0].attn.qkv.bias is not None else []
+
     def _stack(self, tokens, prec):
-        params = [p for blk in self.blocks for p in blk.ordered_params()] + [self.norm.weight, self.norm.bias]
+        qb = self.qkv_biases()
+        params = [p for blk in self.blocks for p in blk.ordered_params()] + [self.norm.weight, self.norm.bias] + qb
         need_grad = torch.is_grad_enabled() and (tokens.requires_grad or any(p.requires_grad for p in params))
         cache = self.__dict__.get("_w16cache")
         if cache is None:
             cache = self.__dict__["_w16cache"] = Fn.W16Cache()
-        y, hidden = Fn.BlocksFn.apply(tokens, self.num_heads, self.mlp_dim, prec, need_grad, cache, *params)
+        y, hidden = Fn.BlocksFn.apply(tokens, self.num_heads, self.mlp_dim, prec, need_grad, cache, len(qb), *params)
         return y, [hidden[i] for i in range(hidden.shape[0])]
 
 

@@ -190,14 +190,16 @@ def _seeds(desc, train: bool) -> None:
 def encoder_head_params(m) -> List[Tuple[str, nn.Parameter]]:
     """embedding-driver parameters in ITS order (hs_embed_*: cls, pos, pe.w, pe.b [, scorer x12]) with their state-dict names."""
     out = []
-    if getattr(m.patch_embedding, "pos_embed", "perceptron") != "perceptron":
-        raise L.HsError("the fused engines drive pos_embed='perceptron' encoders (every shipped configuration); "
-                        "a pos_embed='conv' encoder runs through the module API")
+    wb = m.patch_embedding.fused_weight_bias()
+    if wb is None:
+        raise L.HsError("the fused engines drive the 'perceptron' patch embedding (every shipped configuration) and the 'conv' one on "
+                        "one-channel volumes; a multi-channel pos_embed='conv' encoder runs through the module API")
+    conv = m.patch_embedding.pos_embed == "conv"
     if hasattr(m, "cls_token"):
         out.append(("cls_token", m.cls_token))
     out += [("patch_embedding.position_embeddings", m.patch_embedding.position_embeddings),
-            ("patch_embedding.patch_embeddings.1.weight", m.patch_embedding.patch_embeddings[1].weight),
-            ("patch_embedding.patch_embeddings.1.bias", m.patch_embedding.patch_embeddings[1].bias)]
+            ("patch_embedding.patch_embeddings.weight" if conv else "patch_embedding.patch_embeddings.1.weight", wb[0]),
+            ("patch_embedding.patch_embeddings.bias" if conv else "patch_embedding.patch_embeddings.1.bias", wb[1])]
     if isinstance(m, ViT_stage2):
         out += [("patch_score_proj.weight", m.patch_score_proj.weight), ("patch_score_proj.bias", m.patch_score_proj.bias)]
         sga = m.slice_guided_attention
@@ -246,6 +248,10 @@ class EncoderUnit:
         self.Ln = len(model.blocks)
         sv = (2 if recompute_mlp else 1) if trainable else 0
         self.desc = L.VitDesc(batch, self.N, self.d, model.num_heads, model.mlp_dim, self.Ln, prec, sv, 0.0, None)
+        self._qb = self._qg = None
+        if model.qkv_biases():                    # qkv_bias=True (vit.py:385): pointer tables (re-made by bind() after adoption)
+            self._qb = Fn._ptr_array(model.qkv_biases())
+            self.desc.qkv_bias = C.cast(self._qb, C.c_void_p)
         self.edesc = L.EmbedDesc(batch, self.Np, self.Pd, self.d, int(self.has_cls), int(self.scorer), 32, int(trainable), 0.0)
         self.edesc.prec = prec
         lib = L.load()
@@ -316,6 +322,13 @@ class EncoderUnit:
                 params.w16_is_f16 = self.prec == L.PREC_F16
                 self._w16_mapped = True
         self._wkey = None
+        qb = m.qkv_biases()
+        if qb:
+            self._qb = Fn._ptr_array(qb)
+            self.desc.qkv_bias = C.cast(self._qb, C.c_void_p)
+            if self.trainable:
+                self._qg = Fn._ptr_array([b.grad for b in qb])
+                self.desc.qkv_bias_grad = C.cast(self._qg, C.c_void_p)
         blocks = [p for blk in m.blocks for p in blk.ordered_params()]
         self._lp = Fn._ptr_array(blocks)
         self._np = Fn._ptr_array([m.norm.weight, m.norm.bias])

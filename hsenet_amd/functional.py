@@ -681,15 +681,20 @@ class BlocksFn(torch.autograd.Function):
     differentiate the hidden-state list).  cache: the module's W16Cache (16-bit precisions) or None."""
 
     @staticmethod
-    def forward(ctx, x0, H, mlp, prec, need_grad, cache, *params):
+    def forward(ctx, x0, H, mlp, prec, need_grad, cache, n_qb, *params):
         x0 = _f32(x0).contiguous()
         params = tuple(p.contiguous() for p in params)
         _need(x0, *params)
         B, N, d = x0.shape
+        qbias = params[len(params) - n_qb:] if n_qb else ()        # (qkv_bias=True encoders: one [3d] bias per layer, behind the norm)
+        params = params[:len(params) - n_qb] if n_qb else params
         Ln = (len(params) - 2) // 11
+        if n_qb not in (0, Ln):
+            raise L.HsError("one qkv bias per layer expected")
         # need_grad is decided by the caller (grad mode is off inside Function.forward, and
         # ctx.needs_input_grad ignores torch.no_grad())
-        desc = L.VitDesc(B, N, d, H, mlp, Ln, prec, int(need_grad), 0.0, None)
+        qb_arr = _ptr_array(qbias) if n_qb else None
+        desc = L.VitDesc(B, N, d, H, mlp, Ln, prec, int(need_grad), 0.0, C.cast(qb_arr, C.c_void_p) if n_qb else None)
         lp, npar = _ptr_array(params[:-2]), _ptr_array(params[-2:])
         w16 = w16t = None
         if cache is not None and prec != L.PREC_F32:
@@ -705,8 +710,8 @@ class BlocksFn(torch.autograd.Function):
         L.call("hs_vit_blocks_fwd", C.byref(desc), x0.data_ptr(), lp, npar, y.data_ptr(), hidden.data_ptr(), ws.data_ptr() + off,
                nbytes, _s())
         if need_grad:
-            ctx.save_for_backward(x0, hidden, ws, *params)
-            ctx.desc, ctx.ws_off, ctx.nbytes = desc, off, nbytes
+            ctx.save_for_backward(x0, hidden, ws, *params, *qbias)
+            ctx.desc, ctx.ws_off, ctx.nbytes, ctx.n_qb, ctx.qb_arr = desc, off, nbytes, n_qb, qb_arr
             ctx.w16 = (w16, w16t)            # keeps the copies this graph was built on alive (a later precision switch makes new sets)
         ctx.mark_non_differentiable(hidden)
         return y, hidden
@@ -714,15 +719,20 @@ class BlocksFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, _dh):
         x0, hidden, ws, *params = ctx.saved_tensors
-        desc = ctx.desc
+        desc, n_qb = ctx.desc, ctx.n_qb
         dy = _f32(dy).contiguous()
         dx0 = torch.empty_like(x0)
         grads = _flat_grads(params)
-        lp, npar = _ptr_array(params[:-2]), _ptr_array(params[-2:])
-        lg, ng = _ptr_array(grads[:-2]), _ptr_array(grads[-2:])
+        nblk = len(params) - n_qb
+        lp, npar = _ptr_array(params[:nblk - 2]), _ptr_array(params[nblk - 2:nblk])
+        lg, ng = _ptr_array(grads[:nblk - 2]), _ptr_array(grads[nblk - 2:nblk])
+        if n_qb:
+            qg = _ptr_array(grads[nblk:])
+            desc.qkv_bias_grad = C.cast(qg, C.c_void_p)
         L.call("hs_vit_blocks_bwd", C.byref(desc), x0.data_ptr(), lp, npar, dy.data_ptr(), dx0.data_ptr(), lg, ng, hidden.data_ptr(),
                ws.data_ptr() + ctx.ws_off, ctx.nbytes, desc.L, 0, _s())
-        return (dx0, None, None, None, None, None, *grads)
+        desc.qkv_bias_grad = None
+        return (dx0, None, None, None, None, None, None, *grads)
 
 
 def _opt_ptr_array(tensors: Sequence[Optional[torch.Tensor]], n: int):

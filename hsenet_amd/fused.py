@@ -121,7 +121,8 @@ class EncJob:
         self.N, self.Ln = self.Np + int(self.has_cls), len(module.blocks)
         self.blocks = [p.contiguous() for blk in module.blocks for p in blk.ordered_params()]
         self.norm = [module.norm.weight.contiguous(), module.norm.bias.contiguous()]
-        every = [h for h in self.head if h is not None] + self.blocks + self.norm
+        self.qbias = [b.contiguous() for b in module.qkv_biases()]       # qkv_bias=True encoders (vit.py:385): one [3d] bias per layer
+        every = [h for h in self.head if h is not None] + self.blocks + self.norm + self.qbias
         Fn._need(*every)
         self.need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in every)
         self.patches = Fn.shared_patches.get(x, pe.patch_size, prec)
@@ -135,7 +136,9 @@ class EncJob:
         self.edesc.prec = prec
         if self.scorer:
             Fn._set_dropout(self.edesc, module.training)
-        self.desc = L.VitDesc(self.B, self.N, self.d, module.num_heads, module.mlp_dim, self.Ln, prec, sv, 0.0, None)
+        self._qb = Fn._ptr_array(self.qbias) if self.qbias else None
+        self.desc = L.VitDesc(self.B, self.N, self.d, module.num_heads, module.mlp_dim, self.Ln, prec, sv, 0.0,
+                              C.cast(self._qb, C.c_void_p) if self.qbias else None)
         self.lp, self.np_ = Fn._ptr_array(self.blocks), Fn._ptr_array(self.norm)
         self.ep = Fn._opt_ptr_array(self.head, 16)
         cache = module.__dict__.get("_w16cache")
@@ -168,21 +171,26 @@ class EncJob:
     def owned(self, lo: int, hi: int) -> List[Optional[torch.Tensor]]:
         """the parameters whose gradients the backward of layers [lo, hi) COMPLETES, in owned_slots' order (None = an embedding-driver
         slot this module does not have)."""
-        src = {"b": lambda l, i: self.blocks[l * 11 + i], "n": lambda _, i: self.norm[i], "h": lambda _, i: self.head[i]}
-        return [src[kind](l, i) for kind, l, i in owned_slots(self.Ln, lo, hi)]
+        src = {"b": lambda l, i: self.blocks[l * 11 + i], "n": lambda _, i: self.norm[i], "h": lambda _, i: self.head[i],
+               "q": lambda l, _: self.qbias[l]}
+        return [src[kind](l, i) for kind, l, i in owned_slots(self.Ln, lo, hi, bool(self.qbias))]
 
     def backward(self, lo: int, hi: int, dy: Optional[torch.Tensor], grads: Sequence[Optional[torch.Tensor]]) -> None:
         """layers [lo, hi) (+ the final norm for hi == L, the embedding for lo == 0); grads: zeroed tensors in owned(lo, hi)'s order."""
         lg, ng, eg = (C.c_void_p * (self.Ln * 11))(), (C.c_void_p * 2)(), (C.c_void_p * 16)()
-        for (kind, l, i), g in zip(owned_slots(self.Ln, lo, hi), grads):
+        qg = (C.c_void_p * self.Ln)()
+        for (kind, l, i), g in zip(owned_slots(self.Ln, lo, hi, bool(self.qbias)), grads):
             if g is None:
                 continue
             if kind == "b":
                 lg[l * 11 + i] = g.data_ptr()
             elif kind == "n":
                 ng[i] = g.data_ptr()
+            elif kind == "q":
+                qg[l] = g.data_ptr()
             else:
                 eg[i] = g.data_ptr()
+        self.desc.qkv_bias_grad = C.cast(qg, C.c_void_p) if self.qbias else None
         s = Fn._s()
         L.call("hs_vit_blocks_bwd", C.byref(self.desc), self.x0.data_ptr(), self.lp, self.np_, Fn._p(dy), Fn._p(self.dx0), lg, ng,
                self.hidden.data_ptr(), self.ws.data_ptr() + self.ws_off, self.ws_bytes, hi, lo, s)
@@ -191,10 +199,10 @@ class EncJob:
                    self.ews.data_ptr() + self.ews_off, self.ews_bytes, s)
 
 
-def owned_slots(n_layers: int, lo: int, hi: int):
+def owned_slots(n_layers: int, lo: int, hi: int, qkv_bias: bool = False):
     """[(kind, layer, index)] of the parameter gradients that the backward of layers [lo, hi) completes, in a fixed order:
     ('b', l, i) block parameter i (MONAI order, TransformerBlock.ordered_params) of layer l; ('n', 0, i) the final norm's weight / bias;
-    ('h', 0, i) slot i of the embedding driver's 16.  A layer's linear2.bias (i = 3) belongs to the chunk ABOVE it: its gradient is the
+    ('h', 0, i) slot i of the embedding driver's 16; ('q', l, 0) layer l's qkv bias (qkv_bias=True encoders).  A layer's linear2.bias (i = 3) belongs to the chunk ABOVE it: its gradient is the
     column sum of the residual-stream gradient entering the layer, which the driver emits from the LayerNorm backward of layer l + 1 (the
     final norm's for the top layer)."""
     out = []
@@ -203,6 +211,8 @@ def owned_slots(n_layers: int, lo: int, hi: int):
             if i == 3 and l == hi - 1 and hi < n_layers:
                 continue
             out.append(("b", l, i))
+        if qkv_bias:
+            out.append(("q", l, 0))
     if hi == n_layers:
         out += [("n", 0, 0), ("n", 0, 1)]
     if lo > 0:

@@ -81,7 +81,7 @@ typedef struct hs_gemm_args {
 /* ---- library ------------------------------------------------------------------------------------------ */
 /* ABI version.  2 (round 6): every descriptor struct starts with `struct_size` (= sizeof of the struct the CALLER was compiled
  * against; a library built from a different header refuses the call with HS_ERR_ARG instead of reading past a shorter struct);
- * hs_vit_desc gained w16 / w16t (caller-owned 16-bit weight copies), hs_embed_desc / hs_packer_desc carry `prec` since round 5;
+ * hs_vit_desc gained w16 / w16t (caller-owned 16-bit weight copies) and qkv_bias_grad, hs_embed_desc / hs_packer_desc carry `prec` since round 5;
  * hs_attn_bwd2, hs_attn_bwd_ws_bytes and hs_attn_bwd_ws_error (round 4) are gone, hs_attn_bwd's flag bits 4 and 8 are retired;
  * new: hs_vit_weights_elems, hs_vit_cast_weights, hs_adamw_fused.  A consumer checks hs_version() == HS_ABI_VERSION at load time
  * (hsenet_amd/_lib.py does). */
@@ -255,8 +255,8 @@ typedef struct hs_vit_desc {
     int save_for_bwd;    /* 1: keep per-layer activations in ws for hs_vit_blocks_bwd; 2 (HS_PREC_BF16): the same WITHOUT the MLP's two
                           * [rows][mlp] activations (46 % of the saved bytes): the backward re-runs fc1 + GELU per layer (+1 GEMM of 12) */
     float ln_eps;        /* LayerNorm epsilon; 0 = 1e-5 (MONAI / nn.LayerNorm default).  timm's ViT (the 2-D branch) uses 1e-6 */
-    const float* const* qkv_bias;   /* NULL (MONAI SABlock, qkv_bias=False), or L device pointers to the [3d] bias of each
-                                       layer's qkv Linear (timm ViT, forward only: hs_vit_blocks_bwd rejects it) */
+    const float* const* qkv_bias;   /* NULL (MONAI SABlock, qkv_bias=False: every shipped call site), or L device pointers to the [3d] bias
+                                       of each layer's qkv Linear (MONAI qkv_bias=True, vit.py:385; timm's ViT in the 2-D branch) */
     /* 16-bit precisions only: CALLER-OWNED 16-bit copies of the four weight matrices of every layer, hs_vit_weights_elems(desc)
      * elements each, layer l at l * (elems / L) in the order [Wqkv | Wo | W1 | W2]; w16 = the matrices as stored ([out][in]), w16t =
      * their transposes ([in][out]: the dgrads' NT operand).  NULL (either): the driver re-makes that copy inside `ws` on every call
@@ -264,6 +264,8 @@ typedef struct hs_vit_desc {
      * equal to the fp32 parameters (hs_vit_cast_weights after a parameter change; hs_adamw_fused writes w16 as it updates). */
     const void* w16;
     const void* w16t;
+    float* const* qkv_bias_grad;    /* hs_vit_blocks_bwd with qkv_bias: NULL (biases frozen), or L device pointers; layer l's [3d] bias
+                                       gradient (the column sums of dqkv) ACCUMULATES into entry l (NULL entries are skipped) */
 } hs_vit_desc;
 
 size_t hs_vit_workspace_bytes(const hs_vit_desc* desc);

@@ -30,13 +30,13 @@ def test_default_batch_and_pmc_summary_are_consistent():
     blocks = bench.DEFAULT_BATCH * 33 * 12                   # attention-backward grid: 33 blocks of 128 keys/queries x 12 heads per volume
     assert abs(blocks / 512.0 - round(blocks / 512.0)) < 0.02 and blocks / 512.0 < round(blocks / 512.0)      # just under a whole number of rounds
     pmc = bench.measured_pmc("attn_bwd_dkdv", bench.DEFAULT_BATCH, "dual256")
-    assert pmc and pmc["source"] == "profiles/r05_pmc.json" and pmc["hbm_bytes_per_launch"] > 1e9 and 0.4 < pmc["mfma_busy_frac"] < 0.8
+    assert pmc and pmc["source"] == "profiles/r06_pmc.json" and pmc["hbm_bytes_per_launch"] > 1e9 and 0.4 < pmc["mfma_busy_frac"] < 0.8
     # round 5: the summary names the library it was collected with, and a run that loaded another library does not get its counters
-    e = json.load(open(os.path.join(ROOT, "profiles", "r05_pmc.json")))
+    e = json.load(open(os.path.join(ROOT, "profiles", "r06_pmc.json")))
     assert len(e["_build_id"]) == 16 and e["_bench_value"] > 0 and pmc["build_id"] == e["_build_id"]
-    assert bench.measured_pmc("attn_bwd_dkdv", bench.DEFAULT_BATCH, "dual256", e["_build_id"])["source"] == "profiles/r05_pmc.json"
+    assert bench.measured_pmc("attn_bwd_dkdv", bench.DEFAULT_BATCH, "dual256", e["_build_id"])["source"] == "profiles/r06_pmc.json"
     stale = bench.measured_pmc("attn_bwd_dkdv", bench.DEFAULT_BATCH, "dual256", "0" * 16)
-    assert stale == {"stale": "profiles/r05_pmc.json", "build_id": e["_build_id"]}
+    assert stale == {"stale": "profiles/r06_pmc.json", "build_id": e["_build_id"]}
     # round 4: FETCH_SIZE and WRITE_SIZE are kept apart in the committed summary (the verdict's item 3(0)), and sum to the total
     for k in ("gemm_nt16_bias_gelu", "gemm_nt16_dgelu", "gemm_tn_group", "attn_bwd_dkdv"):
         assert abs(e[k]["fetch_bytes_per_launch"] + e[k]["write_bytes_per_launch"] - e[k]["hbm_bytes_per_launch"]) < 1.0, k
@@ -44,7 +44,7 @@ def test_default_batch_and_pmc_summary_are_consistent():
 
 
 def test_committed_bench_line_keeps_the_contract():
-    lines = sorted(glob.glob(os.path.join(ROOT, "profiles", "r05_bench_dual_default.json")))
+    lines = sorted(glob.glob(os.path.join(ROOT, "profiles", "r06_bench_dual_default.json")))
     assert lines, "the bench line of the default run is committed with the profiles"
     d = json.load(open(lines[-1]))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
@@ -70,13 +70,25 @@ def test_committed_bench_line_keeps_the_contract():
     assert d["f32_mode"]["value"] > 0 and d["f32_mode"]["batch_per_gpu"] == 1
     ev = d["eval_forward"]
     assert ev["f16"] > 0 and ev["bf16"] > 0 and ev["f32"] > 0 and ev["f16_rel_err_vs_f32"] < 1e-3 < ev["bf16_rel_err_vs_f32"]
-    assert d["batch1"]["value"] > 0 and d["config"]["grad_exchange"] == "fp32/allreduce" and d["config"]["batch_changed_from"] == 20
+    assert d["batch1"]["value"] > 0 and d["config"]["grad_exchange"] == "fp32/allreduce" and "batch_changed_from" not in d["config"]
     # round 5: the fp16 train step beside the headline, the reference's own per-device batches, the one-sample eval latency
     f = d["f16_train"]
     assert f["outputs_finite"] is True and 0.9 < f["vs_bf16"] < 1.1 and f["loss_scale"] == 2.0 ** 25
     assert f["accuracy"]["f16_fwd_rel_err"] < 1e-3 < f["accuracy"]["bf16_fwd_rel_err"] and f["accuracy"]["f16_grad_rel_err"] < 2e-3 < f["accuracy"]["bf16_grad_rel_err"]
     assert d["batch1"]["value"] < d["batch2"]["value"] < d["batch3"]["value"] < d["value"] and d["batch3"]["batch_per_gpu"] == 3
     assert 0 < d["eval_latency_ms"]["f16"] < 50 and d["dtype"] == "bf16"
+    # round 6: the forward-only attention figure beside the forward + backward one, the batch sweep as one object, the fp16 skip counter,
+    # and the drop-in train step (module API + autograd + torch.optim.AdamW) beside the engine's on the same box
+    af = d["attention_fwd"]
+    assert af["kernels"] == ["attn_fwd"] and af["frac"] > a["frac"] and af["frac"] >= 0.40
+    sw = d["batch_sweep"]["volumes_per_gpu"]
+    assert list(sw) == ["1", "2", "3", "13", "53"] and sw["1"] < sw["3"] < sw["13"] < sw["53"] * 1.01 and sw["53"] == d["value"]
+    assert f["steps_skipped"] == 0 and f["steps_applied"] >= f["steps"]
+    m = d["module_api_train"]
+    for b, floor in (("b1", 0.82), ("b3", 0.88), ("b13", 0.92)):
+        for prec in ("bf16", "f16"):
+            r = m[b][prec]
+            assert r["finite"] is True and abs(r["vs_engine"] - r["module"] / r["engine"]) < 1e-3 and floor < r["vs_engine"] < 1.08, (b, prec, r)
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     # the step is the sum of its kernels: per-class totals of the instrumented pass (3 steps) against ms_per_step

@@ -442,3 +442,89 @@ def test_packer_fn_reads_the_patch_view_in_place(dev):
     assert rel(g1, full.grad) < 1e-5
     odd = torch.randn(3, T, 2 * 768, device=dev)[:, :, :768]                  # not a row-offset view: packed first
     assert torch.equal(p1(odd), p1(odd.contiguous()))
+
+
+@pytest.mark.parametrize("prec,tol", [("bf16", 1e-2), ("f16", 1.5e-3)])
+def test_default_conv_embedding_on_the_fused_paths(dev, prec, tol):
+    """pos_embed='conv' is the constructors' DEFAULT (vit.py:237,375).  On one-channel volumes -- every call site of the reference -- the
+    Conv3d weight [hidden, 1, p1, p2, p3] IS the perceptron's [hidden, p1*p2*p3] matrix in memory, so the fused node chain and the
+    engines take it as it stands (state-dict keys `patch_embeddings.weight / .bias`); forward and gradients against the oracle's
+    F.conv3d form."""
+    import hsenet_amd as H
+    from hsenet_amd.engine import FlatEncoder
+    from oracle import ref_cpu as R
+    kw = dict(in_channels=1, img_size=IMG, patch_size=PATCH, num_layers=2, pos_embed="conv", classification=True)
+    ref = R.ViT_stage2(**kw).eval()
+    sd = R.seeded_state_dict(ref, 4300)
+    ref.load_state_dict(sd)
+    x, s2d = R.synthetic_volume((2, 1) + IMG, 4301), R.synthetic_slices(2, 4302)
+    yr, _ = ref(x, s2d)
+    (yr * yr).mean().backward()
+    want = {n: p.grad for n, p in ref.named_parameters()}
+    ls = 1024.0 if prec == "f16" else 1.0
+    H.set_precision(prec)
+    try:
+        m = H.ViT_stage2(**kw).eval()
+        m.load_state_dict(sd)
+        m = m.to(dev)
+        assert list(m.state_dict())[:4] == list(ref.state_dict())[:4] and "patch_embedding.patch_embeddings.weight" in m.state_dict()
+        assert m._fused_ok(H.encoder._prec(m), x)                       # the fused chain, not the per-operator fallback
+        y, hidden = m(x.to(dev), s2d.to(dev))
+        ((y * y).mean() * ls).backward()
+    finally:
+        H.set_precision("bf16")
+    assert rel(y.detach(), yr.detach()) < tol and len(hidden) == 2
+    gtol = 4e-2 if prec == "bf16" else 8e-3
+    for n in ("patch_embedding.patch_embeddings.weight", "patch_embedding.patch_embeddings.bias", "patch_embedding.position_embeddings",
+              "blocks.0.attn.qkv.weight", "slice_guided_attention.Wq.weight"):
+        assert rel(dict(m.named_parameters())[n].grad / ls, want[n]) < gtol, n
+    m.zero_grad(set_to_none=True)
+    eng = FlatEncoder(m, 2, lr=1e-3, precision=prec, keep_grads=True)
+    eng.train_step(x.to(dev), s2d.to(dev), optimizer=False)
+    got = dict(m.named_parameters())
+    for n in ("patch_embedding.patch_embeddings.weight", "patch_embedding.patch_embeddings.bias", "blocks.1.mlp.linear1.weight"):
+        assert rel(got[n].grad / eng.loss_scale, want[n]) < gtol, n
+
+
+@pytest.mark.parametrize("prec,tol,gtol", [("f32", 1e-5, 1e-4), ("bf16", 1e-2, 4e-2), ("f16", 1.5e-3, 8e-3)])
+def test_qkv_bias_true_trains_on_every_path(dev, prec, tol, gtol):
+    """qkv_bias=True (accepted by the reference's constructors, vit.py:385; no shipped call site passes it): the biased projection with its
+    q third pre-scaled, and the bias gradient as the column sums of dqkv -- module API (fused chain at 16 bits, per-operator Functions at
+    f32) and the engine, forward and every gradient against the oracle."""
+    import hsenet_amd as H
+    from hsenet_amd.engine import FlatEncoder
+    from oracle import ref_cpu as R
+    kw = dict(in_channels=1, img_size=IMG, patch_size=PATCH, num_layers=2, pos_embed="perceptron", classification=True, qkv_bias=True)
+    ref = R.ViT_stage1(**kw).eval()
+    sd = R.seeded_state_dict(ref, 4400)
+    ref.load_state_dict(sd)
+    x = R.synthetic_volume((2, 1) + IMG, 4401)
+    yr, _ = ref(x)
+    (yr * yr).mean().backward()
+    want = {n: p.grad for n, p in ref.named_parameters()}
+    assert float(want["blocks.0.attn.qkv.bias"].norm()) > 0
+    ls = 1024.0 if prec == "f16" else 1.0
+    H.set_precision(prec)
+    try:
+        m = H.ViT_stage1(**kw).eval()
+        m.load_state_dict(sd)
+        m = m.to(dev)
+        y, _ = m(x.to(dev))
+        ((y * y).mean() * ls).backward()
+    finally:
+        H.set_precision("bf16")
+    assert rel(y.detach(), yr.detach()) < tol
+    got = dict(m.named_parameters())
+    assert set(got) == set(want)
+    for n in want:
+        if float(want[n].norm()) > 1e-3 * max(float(w.norm()) for w in want.values()):
+            assert rel(got[n].grad / ls, want[n]) < gtol, n
+    if prec == "f32":
+        return
+    m.zero_grad(set_to_none=True)
+    eng = FlatEncoder(m, 2, lr=1e-3, precision=prec, keep_grads=True)
+    eng.train_step(x.to(dev), optimizer=False)
+    for n in ("blocks.0.attn.qkv.bias", "blocks.1.attn.qkv.bias", "blocks.0.attn.qkv.weight", "blocks.1.mlp.linear2.bias"):
+        assert rel(got[n].grad / eng.loss_scale, want[n]) < gtol, n
+    eng.train_step(x.to(dev))                                     # and a full step moves the biases
+    assert not torch.equal(got["blocks.0.attn.qkv.bias"].detach().cpu(), sd["blocks.0.attn.qkv.bias"])
