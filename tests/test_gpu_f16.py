@@ -204,26 +204,35 @@ def test_attn_fwd_f16(dev, N):
     assert torch.isfinite(o).all() and torch.isfinite(lse).all() and rel(o.float(), ref) < 2e-3 and rel(lse, torch.logsumexp(sN, -1)) < 1e-4
 
 
-@pytest.mark.parametrize("std", [1.5, 3.0])
-def test_attn_fwd_f16_peaked_rows_at_full_length(dev, std):
+@pytest.mark.parametrize("std,shift", [(1.5, 0.0), (1.5, -8.0), (3.0, -12.0), (3.0, 0.0)])
+def test_attn_fwd_f16_peaked_rows_at_full_length(dev, std, shift):
     """trained attention is peaky: logits with standard deviation 1.5-3 over N = 4097 keys.  The optimistic fp16 forward keeps a row
-    when its l = sum(P) lies in [1, 2^15): with l near 1 thousands of P values are fp16 subnormals (< 6.1e-5), each rounded to a
-    multiple of 6e-8 -- a packed-P error of up to ~N * 3e-8 / l ~ 1e-4.  Against fp64 on the same fp16 operands the output must stay
-    inside the fp16 forward's budget (round 5's advisor asked for this case; random-init logits have std 0.31)."""
+    when its un-referenced l = sum(exp(s)) lies in [1, 2^15): with l near 1 (a negative mean logit: `shift`) thousands of P values are
+    fp16 subnormals (< 6.1e-5), each rounded to a multiple of 6e-8 -- a packed-P error of up to ~N * 3e-8 / l ~ 1e-4; with l beyond
+    2^15 (std 3, no shift) the rows go to the running-maximum kernel.  Against fp64 on the same fp16 operands the output must stay
+    inside the fp16 forward's budget either way, row by row (round 5's advisor asked for this case; random-init logits have std 0.31)."""
     from hsenet_amd import functional as Fn, _lib as L
     B, H, N = 1, 2, 4097
     g = np.random.default_rng(77)
     qkv = torch.from_numpy(g.standard_normal((B, N, 3 * H * 64), dtype=np.float32)).to(dev)
     qkv[..., :H * 64] *= std                     # logits q.k / 8 with std(q) = std, std(k) = 1: standard deviation `std`
+    if shift:                                    # one extra component of q and k whose product is the same for every pair: the mean logit
+        for h in range(H):
+            qkv[..., h * 64] = 8.0
+            qkv[..., H * 64 + h * 64] = shift
     qkv = qkv.half()
     q, k, v = (t.view(B, N, H, 64).permute(0, 2, 1, 3).double() for t in qkv.split(H * 64, dim=-1))
     s = q @ k.transpose(-1, -2) / 8.0
-    assert abs(float(s.std()) - std) < 0.15 * std
-    l_ref = torch.exp(s).sum(-1)                 # the optimistic kernel's un-referenced row sums: spread over many decades
-    assert float(l_ref.min()) < 4097 and float(l_ref.max()) > 4097
+    assert abs(float(s.std()) - std) < 0.2 * std and abs(float(s.mean()) - shift) < 0.3
+    l_ref = torch.exp(s).sum(-1)                 # the optimistic kernel's un-referenced row sums
+    inside = float(((l_ref >= 1) & (l_ref < 2 ** 15)).double().mean())
+    print(f"std {std} shift {shift}: l in [{float(l_ref.min()):.3g}, {float(l_ref.max()):.3g}], {100 * inside:.0f} % of the rows inside the fp16 window")
     ref = (torch.softmax(s, -1) @ v).permute(0, 2, 1, 3).reshape(B, N, H * 64)
     o, lse = Fn.attn_fwd(qkv, H, L.PREC_F16)
-    assert torch.isfinite(o).all() and rel(o.float(), ref) < 1.5e-3 and rel(lse, torch.logsumexp(s, -1)) < 1e-4
+    # (the shifted cases carry the mean logit in ONE component of q whose fp16 rounding after the dh^-0.5 log2(e) pre-scale moves every
+    # logit of a row by the same ~1e-3 nats: softmax and output are unaffected, lse moves with it)
+    lse_err = float((lse.double() - torch.logsumexp(s, -1)).abs().max())
+    assert torch.isfinite(o).all() and rel(o.float(), ref) < 1.5e-3 and lse_err < (5e-4 if shift == 0 else 4e-3), lse_err
     worst = float(((o.double() - ref).norm(dim=-1) / ref.norm(dim=-1).clamp_min(1e-6)).max())
     assert worst < 8e-3, worst                   # no single row falls out of the fp16 budget either
 
