@@ -528,3 +528,41 @@ def test_qkv_bias_true_trains_on_every_path(dev, prec, tol, gtol):
         assert rel(got[n].grad / eng.loss_scale, want[n]) < gtol, n
     eng.train_step(x.to(dev))                                     # and a full step moves the biases
     assert not torch.equal(got["blocks.0.attn.qkv.bias"].detach().cpu(), sd["blocks.0.attn.qkv.bias"])
+
+
+def test_two_live_graphs_and_gradient_accumulation_through_the_fused_chain(dev):
+    """two forward calls before one backward (micro-batches of a gradient-accumulation step, or two towers' calls in one loss): each call
+    owns its workspaces and its chunk chain -- the residual-stream gradient that travels inside a chain's workspace cannot be confused
+    with the other chain's -- and the weight copies are shared read-only.  Gradients of loss(x1) + loss(x2) in one backward equal the sum
+    of two separate backward passes, and equal accumulation into existing .grad tensors."""
+    import hsenet_amd as H
+    mods = _modules(dev, 160)
+    x1, s1 = _inputs(2, 170, dev)
+    x2, s2 = _inputs(2, 180, dev)
+    params = [p for m in mods for p in m.parameters()]
+
+    def loss(x, s):
+        return H.encode_images(*mods, x, s).square().mean()
+    for m in mods:
+        m.zero_grad(set_to_none=True)
+    (loss(x1, s1) + loss(x2, s2)).backward()                         # two live graphs, one backward
+    both = torch.cat([p.grad.flatten() for p in params]).clone()
+    for m in mods:
+        m.zero_grad(set_to_none=True)
+    loss(x1, s1).backward()
+    g1 = torch.cat([p.grad.flatten() for p in params]).clone()
+    loss(x2, s2).backward()                                          # accumulates into the existing .grad (AccumulateGrad adds in place)
+    acc = torch.cat([p.grad.flatten() for p in params]).clone()
+    for m in mods:
+        m.zero_grad(set_to_none=True)
+    loss(x2, s2).backward()
+    g2 = torch.cat([p.grad.flatten() for p in params]).clone()
+    assert rel(both, g1 + g2) < 1e-5 and rel(acc, g1 + g2) < 1e-5 and rel(g1, g2) > 1e-2
+    # retain_graph: a second backward through the same chain re-walks the workspaces from the top
+    for m in mods:
+        m.zero_grad(set_to_none=True)
+    l = loss(x1, s1)
+    l.backward(retain_graph=True)
+    l.backward()
+    twice = torch.cat([p.grad.flatten() for p in params])
+    assert rel(twice, 2 * g1) < 1e-5
