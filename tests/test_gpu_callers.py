@@ -232,3 +232,76 @@ def test_frozen_tower_trainable_packers_under_ddp_autocast(dev, tmp_path):
     got2 = torch.load(out_path2)
     assert all(bool(torch.isfinite(v).all()) for v in got2.values())
     assert all(torch.equal(got2[k], start[k]) for k in got2 if k.startswith("vision_tower."))
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# the whole trainable vision side (dual tower + two packers) under DDP over RCCL: the fused node chain forks the 2E3 encoder onto a side
+# stream INSIDE its autograd nodes -- to DDP's reducer (bucket copies and all-reduces issued from gradient hooks on the stream of the
+# hook) every gradient must be complete on the caller's stream.  World size 1 on the one GPU there is: RCCL's own stream, DDP's buckets
+# and hooks all run; the result must equal the same steps without DDP.
+# ------------------------------------------------------------------------------------------------------------------------------
+class _TrainableSide(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        import hsenet_amd as H
+        from oracle import ref_cpu as R
+
+        class Cfg:
+            vision_tower = "vit_stage2_dual_encoders"
+            vision_select_layer, vision_select_feature, image_channel, remain_2d3d_ViT_type = -1, "patch", 1, "dual_vits"
+            image_size, patch_size = IMG, PATCH
+        self.vision_tower = H.build_vision_tower(Cfg())
+        for t in (self.vision_tower.vision_tower_stage1, self.vision_tower.vision_tower_stage2):
+            del t.blocks[LAYERS:]
+        pk = dict(grid=GRID, kernel_size=KERN)
+        self.mm_projector = H.VisualPacker_3d_phi_v3(IMG, PATCH, 768, OUT, "mlp", 2, **pk)
+        self.mm_projector2 = H.VisualPacker_3d_phi_v3(IMG, PATCH, 768, OUT, "mlp", 2, **pk)
+        for i, m in enumerate((self.vision_tower, self.mm_projector, self.mm_projector2)):
+            m.load_state_dict(R.seeded_state_dict(m, 910 + i))
+
+    def forward(self, x, s2d):
+        import hsenet_amd as H
+        return H.encode_images(self.vision_tower, self.mm_projector, self.mm_projector2, x, s2d)
+
+
+def _trainable_steps(model, fwd, x, s2d, steps):
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=0.1, fused=True)
+    for _ in range(steps):
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out = fwd(x, s2d)
+        out.float().square().mean().backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+        opt.step()
+    torch.cuda.synchronize()
+    return torch.cat([p.detach().flatten() for p in model.parameters()]).cpu()
+
+
+def _rccl1_worker(rank, world, port, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    try:
+        from torch.nn.parallel import DistributedDataParallel as DDP
+        from oracle import ref_cpu as R
+        model = _TrainableSide().to(dev).eval()
+        ddp = DDP(model, device_ids=[0], find_unused_parameters=False, bucket_cap_mb=5)      # small buckets: many all-reduces during the backward
+        x, s2d = R.synthetic_volume((2, 1) + IMG, 920).to(dev), R.synthetic_slices(2, 921).to(dev)
+        torch.save(_trainable_steps(model, ddp, x, s2d, 3), out_path)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_trainable_dual_tower_under_ddp_over_rccl(dev, tmp_path):
+    from oracle import ref_cpu as R
+    out_path = str(tmp_path / "ddp_rccl1.pt")
+    mp.spawn(_rccl1_worker, args=(1, _port(), out_path), nprocs=1, join=True)
+    got = torch.load(out_path)
+    model = _TrainableSide().to(dev).eval()
+    start = torch.cat([p.detach().flatten() for p in model.parameters()]).cpu()
+    x, s2d = R.synthetic_volume((2, 1) + IMG, 920).to(dev), R.synthetic_slices(2, 921).to(dev)
+    want = _trainable_steps(model, model, x, s2d, 3)
+    moved, diff = float((want - start).norm()), float((want - got).norm())
+    print(f"trainable dual tower + packers, DDP over RCCL (world 1) vs no DDP: parameters moved {moved:.3e}, differ by {diff:.3e}")
+    assert moved > 0 and diff < 5e-2 * moved and bool(torch.isfinite(got).all())
