@@ -41,7 +41,7 @@ def _pick_concurrent_stream(device, candidates: int = 4, beside=()) -> torch.cud
     candidate with which they all overlap."""
     cands = [torch.cuda.Stream(device=device) for _ in range(candidates)]
     sleep = getattr(torch.cuda, "_sleep", None)
-    if sleep is None:
+    if sleep is None or torch.cuda.is_current_stream_capturing():      # (the probe synchronises: not inside a graph capture)
         return cands[0]
     import time
     cycles = 2_000_000                                   # ~1 ms at 2 GHz
