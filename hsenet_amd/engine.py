@@ -510,7 +510,7 @@ class _Engine:
     significant bits: forward within 1e-3 of the fp32 reference, gradients within ~2e-3).  fp16 has 5 exponent bits, so the loss
     gradient is multiplied by ``loss_scale`` (a power of two; default: default_loss_scale of the loss' element count) before the
     backward pass -- the flat gradient then holds loss_scale x the true gradient -- and the factor is taken out inside the AdamW pass
-    (``hs_adamw_masked``'s grad_scale), which also skips a step whose gradient norm is not finite (what torch.cuda.amp.GradScaler
+    (``hs_adamw_fused``'s grad_scale), which also skips a step whose gradient norm is not finite (what torch.cuda.amp.GradScaler
     does); ``unscaled_grad()`` returns the true gradient for inspection."""
 
     loss_scale = 1.0
