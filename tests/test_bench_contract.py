@@ -41,6 +41,10 @@ def test_default_batch_and_pmc_summary_are_consistent():
     for k in ("gemm_nt16_bias_gelu", "gemm_nt16_dgelu", "gemm_tn_group", "attn_bwd_dkdv"):
         assert abs(e[k]["fetch_bytes_per_launch"] + e[k]["write_bytes_per_launch"] - e[k]["hbm_bytes_per_launch"]) < 1.0, k
     assert bench.measured_pmc("attn_bwd_dkdv", 7, "dual256") == {}                  # nothing committed for that batch: traffic = null
+    # the committed counters belong to the library the tree builds: a kernel edit without re-running tools/r6_profiles.sh would make the
+    # driver's bench line carry `traffic: null`
+    from hsenet_amd.build import source_id
+    assert e["_build_id"] == source_id(), "profiles/r06_pmc.json was collected with another library build: re-run tools/r6_profiles.sh"
 
 
 def test_committed_bench_line_keeps_the_contract():
