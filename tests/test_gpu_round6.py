@@ -324,7 +324,7 @@ def _module_step(mods, x, s2d, scale=1.0):
     return out.detach(), {f"{i}.{n}": p.grad.detach() / scale for i, m in enumerate(mods) for n, p in m.named_parameters()}
 
 
-@pytest.mark.parametrize("prec,tol_o,tol_g", [("bf16", 5e-3, 4e-2), ("f16", 6e-4, 6e-3)])
+@pytest.mark.parametrize("prec,tol_o,tol_g", [("bf16", 7e-3, 4e-2), ("f16", 8e-4, 6e-3)])
 def test_fused_module_nodes_equal_the_per_operator_functions(dev, prec, tol_o, tol_g, monkeypatch):
     """encode_images through the fused autograd nodes (fused.ChunkFn: both encoders, embedding + blocks, cached weight copies, the 2E3
     chain on a side stream inside each node; PackerFn reading the [:, 1:] view in place) against the same modules on one Function per reference operator (HS_MODULE_UNFUSED=1): outputs and every one of the 316
